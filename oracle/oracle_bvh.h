@@ -1,0 +1,525 @@
+/*
+ * oracle_bvh.h -- TEST INFRASTRUCTURE ONLY (CPU oracle).
+ *
+ * Acceleration-structure build and TraceRay semantics.  The reference only
+ * CALLS this arithmetic (BuildRaytracingAccelerationStructure at
+ * libs/DXRFramework/Helpers/BottomLevelASGenerator.cpp:333 and
+ * TopLevelASGenerator.cpp:404, DispatchRays at RtContext.cpp:218-221, HLSL
+ * TraceRay at ProgressiveRaytracing.hlsl:34,53 and RaytracingCommon.hlsli:94);
+ * the implementation lives in the un-vendored, unpinned submodule
+ * externals/D3D12RaytracingFallback (.gitmodules:4-6).  PARITY UNPINNED for
+ * node layout, traversal order and intersection arithmetic: what follows is
+ * this engine's own deterministic definition, built on the public DXR
+ * functional-spec semantics (ray flags, back-face rule, TMin/TMax, hit-group
+ * indexing), and it is what the HIP kernels must reproduce bit for bit.
+ *
+ * Geometry conventions follow RtModel.cpp:33-81 (interleaved 24-B vertices,
+ * u32 indices, one geometry per BLAS, OPAQUE) and TopLevelASGenerator.cpp:
+ * 344-362 (instance = 3x4 row-major object-to-world, mask 0xFF, flags NONE).
+ *
+ * Definition summary (DESIGN.md has the long form):
+ *   BLAS/TLAS   LBVH: 30-bit Morton code of the primitive-AABB centre in the
+ *               structure's AABB, key = morton<<32 | index, ascending sort,
+ *               Karras-2012 radix tree, bottom-up exact min/max refit.
+ *   ray/box     slab test with precomputed 1/d, min/max ignoring NaN,
+ *               hit iff max(lo, tmin) <= min(hi, tcur) * (1 + 2^-16).
+ *   ray/tri     Moller-Trumbore, u,v for v1,v2 (RaytracingCommon.hlsli:55),
+ *               front face  <=>  det > 0  (clockwise from the origin in a
+ *               left-handed frame, DXR spec), TMin < t < TMax exclusive.
+ *   candidate   accepted only if its own AABB (and, for a transformed
+ *               instance, the instance's world AABB) passes the slab test
+ *               over [tmin, t]: this makes BVH traversal and the brute-force
+ *               loop agree exactly, because float slab tests are monotone
+ *               under box inclusion.
+ *   closest     smaller t wins; equal t -> smaller (instance, primitive).
+ */
+#ifndef ORACLE_BVH_H
+#define ORACLE_BVH_H
+
+#include <algorithm>
+#include <vector>
+#include "../include/dxr_amd_types.h"
+#include "oracle_math.h"
+
+namespace orc {
+
+struct Box { V3 lo, hi; };
+
+static inline Box box_empty()
+{
+    float inf = u2f(0x7f800000u);
+    Box b = { v3(inf, inf, inf), v3(-inf, -inf, -inf) };
+    return b;
+}
+static inline float min2(float a, float b) { return a < b ? a : b; }
+static inline float max2(float a, float b) { return a > b ? a : b; }
+static inline void box_grow(Box &b, V3 p)
+{
+    b.lo = v3(min2(b.lo.x, p.x), min2(b.lo.y, p.y), min2(b.lo.z, p.z));
+    b.hi = v3(max2(b.hi.x, p.x), max2(b.hi.y, p.y), max2(b.hi.z, p.z));
+}
+static inline void box_merge(Box &b, const Box &o) { box_grow(b, o.lo); box_grow(b, o.hi); }
+
+/* ---- LBVH ---------------------------------------------------------------- */
+
+static inline uint32_t expand10(uint32_t v)
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8))  & 0x0300F00Fu;
+    v = (v | (v << 4))  & 0x030C30C3u;
+    v = (v | (v << 2))  & 0x09249249u;
+    return v;
+}
+
+static inline uint32_t quant10(float c, float lo, float ext)
+{
+    if (!(ext > 0.0f)) return 0;
+    float n = (c - lo) / ext;
+    float q = n * 1024.0f;
+    q = fmin_(fmax_(q, 0.0f), 1023.0f);
+    return (uint32_t)q;
+}
+
+static inline uint64_t morton_key(const Box &prim, const Box &scene, uint32_t index)
+{
+    V3 c = vscale(vadd(prim.lo, prim.hi), 0.5f);
+    V3 ext = vsub(scene.hi, scene.lo);
+    uint32_t qx = quant10(c.x, scene.lo.x, ext.x);
+    uint32_t qy = quant10(c.y, scene.lo.y, ext.y);
+    uint32_t qz = quant10(c.z, scene.lo.z, ext.z);
+    uint32_t m = (expand10(qx) << 2) | (expand10(qy) << 1) | expand10(qz);
+    return ((uint64_t)m << 32) | index;
+}
+
+struct Bvh {
+    uint32_t n = 0;                    /* primitives */
+    std::vector<rt_bvh_node> nodes;    /* 2n-1 */
+    std::vector<uint64_t> keys;        /* sorted */
+    std::vector<uint32_t> parent;      /* per node, root = 0xFFFFFFFF */
+    uint32_t max_depth = 0;            /* edges on the longest root-leaf path */
+    Box bounds;
+    uint32_t root() const { return 0; }   /* n==1: node 0 is the single leaf */
+};
+
+static inline int delta(const std::vector<uint64_t> &k, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    return __builtin_clzll(k[i] ^ k[j]);
+}
+
+static inline void lbvh_build(const std::vector<Box> &prims, Bvh &out)
+{
+    const int n = (int)prims.size();
+    out.n = (uint32_t)n;
+    out.nodes.assign(n ? 2 * n - 1 : 0, rt_bvh_node());
+    out.parent.assign(out.nodes.size(), 0xFFFFFFFFu);
+    out.keys.resize(n);
+    out.bounds = box_empty();
+    out.max_depth = 0;
+    if (n == 0) return;
+    for (int i = 0; i < n; i++) box_merge(out.bounds, prims[i]);
+    for (int i = 0; i < n; i++) out.keys[i] = morton_key(prims[i], out.bounds, (uint32_t)i);
+    std::sort(out.keys.begin(), out.keys.end());
+
+    const uint32_t leaf0 = (uint32_t)(n - 1);
+    for (int k = 0; k < n; k++) {
+        uint32_t prim = (uint32_t)(out.keys[k] & 0xFFFFFFFFu);
+        rt_bvh_node &nd = out.nodes[leaf0 + k];
+        nd.bmin[0] = prims[prim].lo.x; nd.bmin[1] = prims[prim].lo.y; nd.bmin[2] = prims[prim].lo.z;
+        nd.bmax[0] = prims[prim].hi.x; nd.bmax[1] = prims[prim].hi.y; nd.bmax[2] = prims[prim].hi.z;
+        nd.left = prim;
+        nd.right = RT_LEAF;
+    }
+    const std::vector<uint64_t> &k = out.keys;
+    for (int i = 0; i < n - 1; i++) {
+        int d = (delta(k, n, i, i + 1) - delta(k, n, i, i - 1)) > 0 ? 1 : -1;
+        int dmin = delta(k, n, i, i - d);
+        int lmax = 2;
+        while (delta(k, n, i, i + lmax * d) > dmin) lmax *= 2;
+        int l = 0;
+        for (int t = lmax / 2; t >= 1; t /= 2)
+            if (delta(k, n, i, i + (l + t) * d) > dmin) l += t;
+        int j = i + l * d;
+        int dnode = delta(k, n, i, j);
+        int s = 0;
+        int t = l;
+        do {
+            t = (t + 1) >> 1;
+            if (delta(k, n, i, i + (s + t) * d) > dnode) s += t;
+        } while (t > 1);
+        int gamma = i + s * d + std::min(d, 0);
+        uint32_t left  = (std::min(i, j) == gamma)     ? leaf0 + (uint32_t)gamma       : (uint32_t)gamma;
+        uint32_t right = (std::max(i, j) == gamma + 1) ? leaf0 + (uint32_t)(gamma + 1) : (uint32_t)(gamma + 1);
+        out.nodes[i].left = left;
+        out.nodes[i].right = right;
+        out.parent[left] = (uint32_t)i;
+        out.parent[right] = (uint32_t)i;
+    }
+    /* bottom-up refit: every internal node after both children; walk from leaves */
+    std::vector<uint8_t> visits(n > 1 ? n - 1 : 0, 0);
+    for (int kk = 0; kk < n; kk++) {
+        uint32_t cur = out.parent[leaf0 + kk];
+        uint32_t depth = 1;
+        while (cur != 0xFFFFFFFFu) {
+            if (visits[cur]++ == 0) break;        /* first arrival: sibling not done */
+            rt_bvh_node &nd = out.nodes[cur];
+            const rt_bvh_node &a = out.nodes[nd.left];
+            const rt_bvh_node &b = out.nodes[nd.right];
+            for (int c = 0; c < 3; c++) {
+                nd.bmin[c] = min2(a.bmin[c], b.bmin[c]);
+                nd.bmax[c] = max2(a.bmax[c], b.bmax[c]);
+            }
+            cur = out.parent[cur];
+            depth++;
+        }
+        (void)depth;
+    }
+    /* depth of the deepest leaf */
+    for (int kk = 0; kk < n; kk++) {
+        uint32_t d = 0;
+        for (uint32_t cur = out.parent[leaf0 + kk]; cur != 0xFFFFFFFFu; cur = out.parent[cur]) d++;
+        out.max_depth = std::max(out.max_depth, d);
+    }
+}
+
+/* ---- scene --------------------------------------------------------------- */
+
+struct Model {
+    std::vector<rt_vertex> verts;
+    std::vector<uint32_t> idx;
+    uint32_t ntris = 0;
+    Bvh blas;
+};
+
+struct Instance {
+    uint32_t model;
+    float m[12];       /* object-to-world, 3x4 row-major (TopLevelASGenerator.cpp:355-357) */
+    float inv[12];     /* world-to-object */
+    bool identity;
+    Box world;
+};
+
+struct Scene {
+    std::vector<Model> models;
+    std::vector<Instance> inst;
+    Bvh tlas;
+    bool built = false;
+};
+
+static inline void tri_verts(const Model &m, uint32_t prim, V3 &a, V3 &b, V3 &c)
+{
+    const rt_float3 &p0 = m.verts[m.idx[3 * prim + 0]].position;
+    const rt_float3 &p1 = m.verts[m.idx[3 * prim + 1]].position;
+    const rt_float3 &p2 = m.verts[m.idx[3 * prim + 2]].position;
+    a = v3(p0.x, p0.y, p0.z); b = v3(p1.x, p1.y, p1.z); c = v3(p2.x, p2.y, p2.z);
+}
+
+static inline Box tri_box(V3 a, V3 b, V3 c)
+{
+    Box bx = box_empty();
+    box_grow(bx, a); box_grow(bx, b); box_grow(bx, c);
+    return bx;
+}
+
+static inline bool is_identity(const float m[12])
+{
+    static const float id[12] = {1,0,0,0, 0,1,0,0, 0,0,1,0};
+    for (int i = 0; i < 12; i++) if (!(m[i] == id[i])) return false;
+    return true;
+}
+
+/* world-to-object = inverse of the 3x4 affine (adjugate / determinant, fp32) */
+static inline void invert3x4(const float m[12], float o[12])
+{
+    float a = m[0], b = m[1], c = m[2];
+    float d = m[4], e = m[5], f = m[6];
+    float g = m[8], h = m[9], i = m[10];
+    float A = e * i - f * h;
+    float B = f * g - d * i;
+    float C = d * h - e * g;
+    float det = a * A;
+    det = det + b * B;
+    det = det + c * C;
+    float id = 1.0f / det;
+    o[0] = A * id;  o[1] = (c * h - b * i) * id;  o[2]  = (b * f - c * e) * id;
+    o[4] = B * id;  o[5] = (a * i - c * g) * id;  o[6]  = (c * d - a * f) * id;
+    o[8] = C * id;  o[9] = (b * g - a * h) * id;  o[10] = (a * e - b * d) * id;
+    float tx = m[3], ty = m[7], tz = m[11];
+    for (int r = 0; r < 3; r++) {
+        float s = o[4 * r + 0] * tx;
+        s = s + o[4 * r + 1] * ty;
+        s = s + o[4 * r + 2] * tz;
+        o[4 * r + 3] = -s;
+    }
+}
+
+static inline V3 xform_point(const float m[12], V3 p)
+{
+    float x = m[0] * p.x; x = x + m[1] * p.y; x = x + m[2]  * p.z; x = x + m[3];
+    float y = m[4] * p.x; y = y + m[5] * p.y; y = y + m[6]  * p.z; y = y + m[7];
+    float z = m[8] * p.x; z = z + m[9] * p.y; z = z + m[10] * p.z; z = z + m[11];
+    return v3(x, y, z);
+}
+static inline V3 xform_dir(const float m[12], V3 p)
+{
+    float x = m[0] * p.x; x = x + m[1] * p.y; x = x + m[2]  * p.z;
+    float y = m[4] * p.x; y = y + m[5] * p.y; y = y + m[6]  * p.z;
+    float z = m[8] * p.x; z = z + m[9] * p.y; z = z + m[10] * p.z;
+    return v3(x, y, z);
+}
+
+static inline void scene_build(Scene &s)
+{
+    for (Model &m : s.models) {
+        std::vector<Box> boxes(m.ntris);
+        for (uint32_t p = 0; p < m.ntris; p++) {
+            V3 a, b, c;
+            tri_verts(m, p, a, b, c);
+            boxes[p] = tri_box(a, b, c);
+        }
+        lbvh_build(boxes, m.blas);
+    }
+    std::vector<Box> ib(s.inst.size());
+    for (size_t i = 0; i < s.inst.size(); i++) {
+        Instance &in = s.inst[i];
+        const Box &b = s.models[in.model].blas.bounds;
+        in.identity = is_identity(in.m);
+        if (in.identity) {
+            in.world = b;
+            for (int k = 0; k < 12; k++) in.inv[k] = in.m[k];
+        } else {
+            invert3x4(in.m, in.inv);
+            in.world = box_empty();
+            for (int c = 0; c < 8; c++) {
+                V3 p = v3((c & 1) ? b.hi.x : b.lo.x, (c & 2) ? b.hi.y : b.lo.y, (c & 4) ? b.hi.z : b.lo.z);
+                box_grow(in.world, xform_point(in.m, p));
+            }
+        }
+        ib[i] = in.world;
+    }
+    lbvh_build(ib, s.tlas);
+    s.built = true;
+}
+
+/* ---- rays ---------------------------------------------------------------- */
+
+struct Ray { V3 o; float tmin; V3 d; float tmax; };
+
+struct Hit {
+    float t, u, v;
+    uint32_t prim, inst;
+};
+
+struct Counters { uint32_t nodes, tris; };
+
+struct RayInv { V3 o, inv; };
+
+static inline RayInv ray_inv(V3 o, V3 d)
+{
+    RayInv r;
+    r.o = o;
+    r.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    return r;
+}
+
+/* Conservative slab test: true iff max(lo, t0) <= min(hi, t1) * (1 + 2^-16);
+ * *entry = max(lo,t0).  The slack absorbs the few-ulp disagreement between a
+ * slab distance and the Moller-Trumbore distance to a triangle lying in a
+ * flat (zero-thickness) box; multiplying by a positive constant keeps the
+ * test monotone under box inclusion, which is what the exactness argument in
+ * the header needs.  All distances here are >= 0 because t0 >= 0. */
+#define ORC_SLAB_SLACK 1.0000152587890625f
+static inline bool slab(const RayInv &r, const float bmin[3], const float bmax[3], float t0, float t1, float *entry)
+{
+    float ax = (bmin[0] - r.o.x) * r.inv.x, bx = (bmax[0] - r.o.x) * r.inv.x;
+    float ay = (bmin[1] - r.o.y) * r.inv.y, by = (bmax[1] - r.o.y) * r.inv.y;
+    float az = (bmin[2] - r.o.z) * r.inv.z, bz = (bmax[2] - r.o.z) * r.inv.z;
+    float lo = fmax_(fmax_(fmin_(ax, bx), fmin_(ay, by)), fmax_(fmin_(az, bz), t0));
+    float hi = fmin_(fmin_(fmax_(ax, bx), fmax_(ay, by)), fmin_(fmax_(az, bz), t1));
+    *entry = lo;
+    return lo <= hi * ORC_SLAB_SLACK;
+}
+static inline bool slab_box(const RayInv &r, const Box &b, float t0, float t1)
+{
+    float lo[3] = {b.lo.x, b.lo.y, b.lo.z}, hi[3] = {b.hi.x, b.hi.y, b.hi.z}, e;
+    return slab(r, lo, hi, t0, t1, &e);
+}
+
+/* Moller-Trumbore + own-AABB validation.  o,d in the triangle's space. */
+static inline bool tri_candidate(V3 o, V3 d, const RayInv &ri, float tmin, float tmax,
+                                 V3 v0, V3 v1, V3 v2, bool cull_back, float *t, float *u, float *v)
+{
+    V3 e1 = vsub(v1, v0);
+    V3 e2 = vsub(v2, v0);
+    V3 p = cross3(d, e2);
+    float det = dot3(e1, p);
+    if (cull_back) { if (!(det > 0.0f)) return false; }
+    else           { if (det == 0.0f || det != det) return false; }
+    float inv = 1.0f / det;
+    V3 tv = vsub(o, v0);
+    float uu = dot3(tv, p) * inv;
+    if (!(uu >= 0.0f) || uu > 1.0f) return false;
+    V3 q = cross3(tv, e1);
+    float vv = dot3(d, q) * inv;
+    if (!(vv >= 0.0f) || !(uu + vv <= 1.0f)) return false;
+    float tt = dot3(e2, q) * inv;
+    if (!(tt > tmin) || !(tt < tmax)) return false;
+    Box b = tri_box(v0, v1, v2);
+    if (!slab_box(ri, b, tmin, tt)) return false;
+    *t = tt; *u = uu; *v = vv;
+    return true;
+}
+
+static inline bool better(float t, uint32_t inst, uint32_t prim, const Hit &h)
+{
+    if (t < h.t) return true;
+    if (t > h.t) return false;
+    if (h.inst == RT_NO_HIT) return false;   /* t == ray.tmax is excluded by t < tmax */
+    if (inst != h.inst) return inst < h.inst;
+    return prim < h.prim;
+}
+
+struct ObjRay { V3 o, d; RayInv ri; };
+
+static inline ObjRay to_object(const Instance &in, const Ray &r)
+{
+    ObjRay o;
+    if (in.identity) { o.o = r.o; o.d = r.d; }
+    else { o.o = xform_point(in.inv, r.o); o.d = xform_dir(in.inv, r.d); }
+    o.ri = ray_inv(o.o, o.d);
+    return o;
+}
+
+/* one candidate triangle of one instance against the running best */
+static inline bool test_prim(const Scene &s, uint32_t ii, uint32_t prim, const Ray &r, const RayInv &wri,
+                             const ObjRay &orr, uint32_t flags, Hit &best)
+{
+    const Instance &in = s.inst[ii];
+    const Model &m = s.models[in.model];
+    V3 a, b, c;
+    tri_verts(m, prim, a, b, c);
+    float t, u, v;
+    bool cull = (flags & RT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES) != 0;
+    /* closest: candidates in (tmin, ray.tmax); ordering vs best handled by better() */
+    if (!tri_candidate(orr.o, orr.d, orr.ri, r.tmin, r.tmax, a, b, c, cull, &t, &u, &v)) return false;
+    if (!in.identity && !slab_box(wri, in.world, r.tmin, t)) return false;
+    if (!better(t, ii, prim, best)) return false;
+    best.t = t; best.u = u; best.v = v; best.prim = prim; best.inst = ii;
+    return true;
+}
+
+static inline Hit miss_hit(const Ray &r)
+{
+    Hit h; h.t = r.tmax; h.u = 0; h.v = 0; h.prim = RT_NO_HIT; h.inst = RT_NO_HIT;
+    return h;
+}
+
+/* topology-independent truth: every instance x every triangle */
+static inline Hit trace_brute(const Scene &s, const Ray &r, uint32_t flags)
+{
+    Hit best = miss_hit(r);
+    RayInv wri = ray_inv(r.o, r.d);
+    bool first = (flags & RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH) != 0;
+    for (uint32_t ii = 0; ii < s.inst.size(); ii++) {
+        ObjRay orr = to_object(s.inst[ii], r);
+        uint32_t nt = s.models[s.inst[ii].model].ntris;
+        for (uint32_t p = 0; p < nt; p++) {
+            if (test_prim(s, ii, p, r, wri, orr, flags, best) && first) return best;
+        }
+    }
+    return best;
+}
+
+/*
+ * Canonical two-level stack traversal.  Order: test both children; if both
+ * are hit descend into the one with the smaller entry distance (tie: left)
+ * and push the other.  Counters: nodes = AABBs slab-tested (roots included),
+ * tris = triangles handed to the Moller-Trumbore test.
+ */
+static inline bool traverse_blas(const Scene &s, uint32_t ii, const Ray &r, const RayInv &wri,
+                                 uint32_t flags, Hit &best, Counters &cnt)
+{
+    const Instance &in = s.inst[ii];
+    const Bvh &bv = s.models[in.model].blas;
+    if (bv.n == 0) return false;
+    bool first = (flags & RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH) != 0;
+    ObjRay orr = to_object(in, r);
+    uint32_t stack[128];
+    int sp = 0;
+    float e;
+    cnt.nodes++;
+    if (!slab(orr.ri, bv.nodes[0].bmin, bv.nodes[0].bmax, r.tmin, best.t, &e)) return false;
+    uint32_t cur = 0;
+    for (;;) {
+        const rt_bvh_node &nd = bv.nodes[cur];
+        if (nd.right == RT_LEAF) {
+            cnt.tris++;
+            if (test_prim(s, ii, nd.left, r, wri, orr, flags, best) && first) return true;
+            if (sp == 0) break;
+            cur = stack[--sp];
+            continue;
+        }
+        const rt_bvh_node &a = bv.nodes[nd.left];
+        const rt_bvh_node &b = bv.nodes[nd.right];
+        float ea, eb;
+        cnt.nodes += 2;
+        bool ha = slab(orr.ri, a.bmin, a.bmax, r.tmin, best.t, &ea);
+        bool hb = slab(orr.ri, b.bmin, b.bmax, r.tmin, best.t, &eb);
+        if (ha && hb) {
+            if (eb < ea) { stack[sp++] = nd.left;  cur = nd.right; }
+            else         { stack[sp++] = nd.right; cur = nd.left; }
+        } else if (ha) cur = nd.left;
+        else if (hb)   cur = nd.right;
+        else {
+            if (sp == 0) break;
+            cur = stack[--sp];
+        }
+    }
+    return false;
+}
+
+static inline Hit trace_bvh(const Scene &s, const Ray &r, uint32_t flags, Counters &cnt)
+{
+    Hit best = miss_hit(r);
+    cnt.nodes = 0; cnt.tris = 0;
+    const Bvh &tl = s.tlas;
+    if (tl.n == 0) return best;
+    bool first = (flags & RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH) != 0;
+    RayInv wri = ray_inv(r.o, r.d);
+    uint32_t stack[128];
+    int sp = 0;
+    float e;
+    cnt.nodes++;
+    if (!slab(wri, tl.nodes[0].bmin, tl.nodes[0].bmax, r.tmin, best.t, &e)) return best;
+    uint32_t cur = 0;
+    for (;;) {
+        const rt_bvh_node &nd = tl.nodes[cur];
+        if (nd.right == RT_LEAF) {
+            if (traverse_blas(s, nd.left, r, wri, flags, best, cnt) && first) return best;
+            if (sp == 0) break;
+            cur = stack[--sp];
+            continue;
+        }
+        const rt_bvh_node &a = tl.nodes[nd.left];
+        const rt_bvh_node &b = tl.nodes[nd.right];
+        float ea, eb;
+        cnt.nodes += 2;
+        bool ha = slab(wri, a.bmin, a.bmax, r.tmin, best.t, &ea);
+        bool hb = slab(wri, b.bmin, b.bmax, r.tmin, best.t, &eb);
+        if (ha && hb) {
+            if (eb < ea) { stack[sp++] = nd.left;  cur = nd.right; }
+            else         { stack[sp++] = nd.right; cur = nd.left; }
+        } else if (ha) cur = nd.left;
+        else if (hb)   cur = nd.right;
+        else {
+            if (sp == 0) break;
+            cur = stack[--sp];
+        }
+    }
+    return best;
+}
+
+}  // namespace orc
+
+#endif
