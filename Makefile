@@ -1,0 +1,40 @@
+# Builds the product library (HIP, gfx950) and, for the tests, the CPU oracle.
+#   make            -> dxrexperiments_amd/lib/libdxrexperiments_amd.so
+#   make oracle     -> oracle/liboracle.so   (test infrastructure only)
+# -ffp-contract=off is REQUIRED: the kernels' arithmetic is defined without FMA
+# (bit parity with the oracle); divide and sqrt must be the correctly rounded forms.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC = dxrexperiments_amd/csrc
+LIBDIR = dxrexperiments_amd/lib
+LIB = $(LIBDIR)/libdxrexperiments_amd.so
+HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math \
+           -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero \
+           -Wall -Wno-unused-function -Iinclude
+SRCS = $(CSRC)/rt_api.hip $(CSRC)/rt_bvh_build.hip $(CSRC)/rt_trace.hip $(CSRC)/rt_pipeline.hip \
+       $(CSRC)/rt_obj.cpp $(CSRC)/rt_host.cpp $(CSRC)/rt_dds.cpp
+HDRS = $(wildcard $(CSRC)/*.h) include/dxr_amd.h include/dxr_amd_types.h
+OBJS = $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
+
+all: $(LIB)
+
+build/%.hip.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+build/%.cpp.o: $(CSRC)/%.cpp $(HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle liboracle.so
+
+clean:
+	rm -rf build $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

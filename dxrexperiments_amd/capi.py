@@ -1,0 +1,458 @@
+"""ctypes binding of the C ABI declared in include/dxr_amd.h.
+
+This is the ONLY compute path of the package: every call goes to the HIP
+library dxrexperiments_amd/lib/libdxrexperiments_amd.so.  There is no CPU
+fallback; if the library is missing or no GPU is usable the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import rtypes as T
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdxrexperiments_amd.so")
+_LIB = None
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("dxr_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays_primary", "rays_secondary", "rays_shadow", "primary_hits", "secondary_hits")] + \
+               [(n, C.c_float) for n in ("ms_primary", "ms_shade0", "ms_trace_secondary", "ms_trace_shadow0", "ms_shade1",
+                                          "ms_trace_shadow1", "ms_resolve", "ms_total")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# name -> (restype, argtypes); every symbol include/dxr_amd.h declares
+_p, _u32, _i, _f, _sz = C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_size_t
+_pp = C.POINTER(C.c_void_p)
+_pu = C.POINTER(C.c_uint32)
+SIGNATURES = {
+    "rt_version": (C.c_char_p, []),
+    "rt_last_error": (C.c_char_p, []),
+    "rt_device_count": (_i, []),
+    "rt_context_create": (_i, [_i, _pp]),
+    "rt_context_create_on_stream": (_i, [_i, _p, _pp]),
+    "rt_context_destroy": (_i, [_p]),
+    "rt_context_synchronize": (_i, [_p]),
+    "rt_context_get_stream": (_i, [_p, _pp]),
+    "rt_context_get_device": (_i, [_p, C.POINTER(_i)]),
+    "rt_model_create_from_obj": (_i, [_p, C.c_char_p, _pp]),
+    "rt_model_create_from_arrays": (_i, [_p, _p, _u32, _p, _u32, _pp]),
+    "rt_model_get_counts": (_i, [_p, _pu, _pu]),
+    "rt_model_read_geometry": (_i, [_p, _p, _p]),
+    "rt_model_retain": (_i, [_p]),
+    "rt_model_destroy": (_i, [_p]),
+    "rt_scene_create": (_i, [_p, _pp]),
+    "rt_scene_add_model": (_i, [_p, _p, _p]),
+    "rt_scene_get_num_instances": (_i, [_p, _pu]),
+    "rt_scene_build": (_i, [_p, _u32]),
+    "rt_scene_destroy": (_i, [_p]),
+    "rt_scene_bvh_info": (_i, [_p, _i, _pu, _pu, _pu]),
+    "rt_scene_bvh_read": (_i, [_p, _i, _p, _p, _p]),
+    "rt_scene_instance_info": (_i, [_p, _u32, _p, _p]),
+    "rt_scene_build_ms": (_i, [_p, C.POINTER(_f)]),
+    "rt_trace_batch": (_i, [_p, _p, _p, _p, _sz, _u32, _u32, _u32, _p, _p, _p, _p, _p, _p, _p]),
+    "rt_trace_last_ms": (_i, [_p, C.POINTER(_f)]),
+    "rt_pipeline_create": (_i, [_p, _u32, _pp]),
+    "rt_pipeline_destroy": (_i, [_p]),
+    "rt_pipeline_get_name": (C.c_char_p, [_p]),
+    "rt_pipeline_set_scene": (_i, [_p, _p]),
+    "rt_pipeline_add_material": (_i, [_p, _p]),
+    "rt_pipeline_set_material": (_i, [_p, _u32, _p]),
+    "rt_pipeline_set_environment_cube": (_i, [_p, _p, _u32]),
+    "rt_pipeline_set_environment_constant": (_i, [_p, _p]),
+    "rt_pipeline_load_environment_dds": (_i, [_p, C.c_char_p]),
+    "rt_pipeline_create_output": (_i, [_p, _u32, _u32, _u32]),
+    "rt_pipeline_bind_output": (_i, [_p, _p, _u32, _u32]),
+    "rt_pipeline_build_acceleration_structures": (_i, [_p]),
+    "rt_pipeline_set_depth_limits": (_i, [_p, _u32, _u32]),
+    "rt_pipeline_set_accumulation_mode": (_i, [_p, _u32]),
+    "rt_pipeline_clear_output": (_i, [_p]),
+    "rt_pipeline_update": (_i, [_p, _p]),
+    "rt_pipeline_render": (_i, [_p, _u32, _u32]),
+    "rt_pipeline_render_tile": (_i, [_p, _u32, _u32, _u32, _u32, _u32, _u32]),
+    "rt_pipeline_get_num_outputs": (_i, [_p, C.POINTER(_i)]),
+    "rt_pipeline_get_output_device_ptr": (_i, [_p, _u32, _pp]),
+    "rt_pipeline_read_output": (_i, [_p, _p, _sz]),
+    "rt_pipeline_get_stats": (_i, [_p, C.POINTER(Stats)]),
+    "rt_pipeline_enable_timing": (_i, [_p, _i]),
+    "rt_pipeline_read_primary_hits": (_i, [_p, _p, _p, _p]),
+    "rt_camera_look": (_i, [_p, _p, _p, _p, _p]),
+    "rt_camera_basis": (_i, [_p, _p, _f, _f, _p, _p, _p]),
+    "rt_progressive_host_create": (_i, [_u32, _pp]),
+    "rt_progressive_host_destroy": (_i, [_p]),
+    "rt_progressive_host_options": (_i, [_p, _pp]),
+    "rt_progressive_host_set_flags": (_i, [_p, _i, _i]),
+    "rt_progressive_host_reset": (_i, [_p]),
+    "rt_progressive_host_update": (_i, [_p, _p, _f, _u32, _u32, _u32, _p]),
+    "rt_debug_math": (_i, [_p, _i, _p, _p, _p, _sz]),
+    "rt_debug_sample": (_i, [_p, _i, _p, _p, _f, _p, _p, _p, _sz]),
+    "rt_debug_sample_cube": (_i, [_p, _p, _u32, _p, _p, _sz]),
+}
+
+
+def lib():
+    """Load the HIP library; raises if it has not been built (there is no fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("HIP library %s not found: run `make` (or __graft_entry__.build()) first; "
+                              "dxrexperiments_amd has no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise RtError(rc, lib().rt_last_error().decode(errors="replace"))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a if shape is None else a.reshape(shape)
+
+
+def device_count():
+    n = lib().rt_device_count()
+    if n < 0:
+        raise RtError(n, lib().rt_last_error().decode(errors="replace"))
+    return n
+
+
+class Context:
+    """RtContext (libs/DXRFramework/RtContext.h:15)."""
+
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        if stream is None:
+            _check(lib().rt_context_create(device, C.byref(h)))
+        else:
+            _check(lib().rt_context_create_on_stream(device, C.c_void_p(stream), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rt_context_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def synchronize(self):
+        _check(lib().rt_context_synchronize(self.h))
+
+    @property
+    def stream(self):
+        s = C.c_void_p()
+        _check(lib().rt_context_get_stream(self.h, C.byref(s)))
+        return s.value or 0
+
+    # device math probes (tests)
+    def math(self, fn, x, y=None):
+        x = _f32(x)
+        y = _f32(y) if y is not None else x
+        out = np.empty_like(x)
+        _check(lib().rt_debug_math(self.h, fn, _ptr(x), _ptr(y), _ptr(out), x.size))
+        return out
+
+    def sample(self, kind, seeds, vecs, exponent=0.0):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        vecs = _f32(vecs, (-1, 3))
+        n = seeds.size
+        out = np.empty((n, 3), np.float32)
+        pb = np.empty((n, 2), np.float32)
+        so = np.empty(n, np.uint32)
+        _check(lib().rt_debug_sample(self.h, kind, _ptr(seeds), _ptr(vecs), exponent, _ptr(out), _ptr(pb), _ptr(so), n))
+        return out, pb, so
+
+    def sample_cube(self, faces, dirs):
+        faces = _f32(faces)
+        dirs = _f32(dirs, (-1, 3))
+        out = np.empty_like(dirs)
+        _check(lib().rt_debug_sample_cube(self.h, _ptr(faces), faces.shape[1], _ptr(dirs), _ptr(out), dirs.shape[0]))
+        return out
+
+
+class Model:
+    """RtModel (libs/DXRFramework/RtModel.h:13)."""
+
+    def __init__(self, ctx, verts=None, indices=None, path=None):
+        self.ctx = ctx
+        h = C.c_void_p()
+        if path is not None:
+            _check(lib().rt_model_create_from_obj(ctx.h, os.fsencode(path), C.byref(h)))
+        else:
+            v = np.ascontiguousarray(verts, dtype=T.VERTEX)
+            i = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+            _check(lib().rt_model_create_from_arrays(ctx.h, _ptr(v), v.shape[0], _ptr(i), i.shape[0], C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rt_model_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def counts(self):
+        nv, nt = C.c_uint32(), C.c_uint32()
+        _check(lib().rt_model_get_counts(self.h, C.byref(nv), C.byref(nt)))
+        return nv.value, nt.value
+
+    def geometry(self):
+        nv, nt = self.counts()
+        v = np.empty(nv, T.VERTEX)
+        i = np.empty((nt, 3), np.uint32)
+        _check(lib().rt_model_read_geometry(self.h, _ptr(v), _ptr(i)))
+        return v, i
+
+
+class Scene:
+    """RtScene (libs/DXRFramework/RtScene.h:14-37)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        _check(lib().rt_scene_create(ctx.h, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rt_scene_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def add_model(self, model, transform=None):
+        x = _f32(T.IDENTITY_3X4 if transform is None else transform, 12)
+        _check(lib().rt_scene_add_model(self.h, model.h, _ptr(x)))
+
+    @property
+    def num_instances(self):
+        n = C.c_uint32()
+        _check(lib().rt_scene_get_num_instances(self.h, C.byref(n)))
+        return n.value
+
+    def build(self, hit_group_count=2):
+        _check(lib().rt_scene_build(self.h, hit_group_count))
+
+    def build_ms(self):
+        ms = C.c_float()
+        _check(lib().rt_scene_build_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def bvh(self, which):
+        n, nn, md = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(lib().rt_scene_bvh_info(self.h, which, C.byref(n), C.byref(nn), C.byref(md)))
+        nodes = np.empty(nn.value, T.BVH_NODE)
+        keys = np.empty(n.value, np.uint64)
+        parents = np.empty(nn.value, np.uint32)
+        _check(lib().rt_scene_bvh_read(self.h, which, _ptr(nodes), _ptr(keys), _ptr(parents)))
+        return nodes, keys, parents, md.value
+
+    def instance_info(self, i):
+        box = np.empty(6, np.float32)
+        inv = np.empty(12, np.float32)
+        _check(lib().rt_scene_instance_info(self.h, i, _ptr(box), _ptr(inv)))
+        return box, inv
+
+    def trace(self, origin_tmin, dir_tmax, flags=0, canonical=False):
+        """Batch TraceRay from host arrays; returns dict of numpy arrays."""
+        o = _f32(origin_tmin, (-1, 4))
+        d = _f32(dir_tmax, (-1, 4))
+        n = o.shape[0]
+        t = np.empty(n, np.float32); u = np.empty(n, np.float32); v = np.empty(n, np.float32)
+        prim = np.empty(n, np.uint32); inst = np.empty(n, np.uint32)
+        cn = np.zeros(n, np.uint32); ct = np.zeros(n, np.uint32)
+        _check(lib().rt_trace_batch(self.ctx.h, self.h, _ptr(o), _ptr(d), n, flags, 1 if canonical else 0, 0,
+                                    _ptr(t), _ptr(u), _ptr(v), _ptr(prim), _ptr(inst),
+                                    _ptr(cn) if canonical else None, _ptr(ct) if canonical else None))
+        return dict(t=t, u=u, v=v, prim=prim, inst=inst, nodes=cn, tris=ct)
+
+    def trace_device(self, o_ptr, d_ptr, n, flags=0, canonical=False, t=0, u=0, v=0, prim=0, inst=0, nodes=0, tris=0):
+        """Batch TraceRay on device pointers (ints); asynchronous on the context stream."""
+        cv = lambda x: C.c_void_p(x) if x else None
+        _check(lib().rt_trace_batch(self.ctx.h, self.h, cv(o_ptr), cv(d_ptr), n, flags, 1 if canonical else 0, 1,
+                                    cv(t), cv(u), cv(v), cv(prim), cv(inst), cv(nodes), cv(tris)))
+
+    def trace_last_ms(self):
+        ms = C.c_float()
+        _check(lib().rt_trace_last_ms(self.ctx.h, C.byref(ms)))
+        return ms.value
+
+
+class Pipeline:
+    """ProgressiveRaytracingPipeline (include/ProgressiveRaytracingPipeline.h:15-78)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        _check(lib().rt_pipeline_create(ctx.h, 0, C.byref(h)))
+        self.h = h
+        self.width = self.height = 0
+        self.format = T.FORMAT_R32G32B32A32_FLOAT
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rt_pipeline_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    @property
+    def name(self):
+        return lib().rt_pipeline_get_name(self.h).decode()
+
+    def set_scene(self, scene):
+        self._keep.append(scene)
+        _check(lib().rt_pipeline_set_scene(self.h, scene.h))
+
+    def add_material(self, m):
+        m = np.ascontiguousarray(m, dtype=T.MATERIAL_PARAMS)
+        _check(lib().rt_pipeline_add_material(self.h, _ptr(m)))
+
+    def set_material(self, index, m):
+        m = np.ascontiguousarray(m, dtype=T.MATERIAL_PARAMS)
+        _check(lib().rt_pipeline_set_material(self.h, index, _ptr(m)))
+
+    def set_environment_cube(self, faces):
+        f = _f32(faces)
+        assert f.ndim == 4 and f.shape[0] == 6 and f.shape[1] == f.shape[2] and f.shape[3] == 4
+        _check(lib().rt_pipeline_set_environment_cube(self.h, _ptr(f), f.shape[1]))
+
+    def set_environment_constant(self, rgb):
+        c = _f32(rgb, 3)
+        _check(lib().rt_pipeline_set_environment_constant(self.h, _ptr(c)))
+
+    def load_environment_dds(self, path):
+        _check(lib().rt_pipeline_load_environment_dds(self.h, os.fsencode(path)))
+
+    def create_output(self, width, height, fmt=T.FORMAT_R32G32B32A32_FLOAT):
+        _check(lib().rt_pipeline_create_output(self.h, fmt, width, height))
+        self.width, self.height, self.format = width, height, fmt
+
+    def bind_output(self, device_ptr, width, height):
+        _check(lib().rt_pipeline_bind_output(self.h, C.c_void_p(device_ptr), width, height))
+        self.width, self.height, self.format = width, height, T.FORMAT_R32G32B32A32_FLOAT
+
+    def build_acceleration_structures(self):
+        _check(lib().rt_pipeline_build_acceleration_structures(self.h))
+
+    def set_depth_limits(self, max_radiance_depth=1, max_shadow_depth=2):
+        _check(lib().rt_pipeline_set_depth_limits(self.h, max_radiance_depth, max_shadow_depth))
+
+    def set_accumulation_mode(self, mode):
+        _check(lib().rt_pipeline_set_accumulation_mode(self.h, mode))
+
+    def clear_output(self):
+        _check(lib().rt_pipeline_clear_output(self.h))
+
+    def update(self, constants):
+        c = np.ascontiguousarray(constants)
+        assert c.nbytes == 188
+        _check(lib().rt_pipeline_update(self.h, _ptr(c)))
+
+    def render(self, tile=None):
+        if tile is None:
+            _check(lib().rt_pipeline_render(self.h, self.width, self.height))
+        else:
+            _check(lib().rt_pipeline_render_tile(self.h, self.width, self.height, *tile))
+
+    def output_device_ptr(self):
+        p = C.c_void_p()
+        _check(lib().rt_pipeline_get_output_device_ptr(self.h, 0, C.byref(p)))
+        return p.value
+
+    def read_output(self):
+        if self.format == T.FORMAT_R16G16B16A16_FLOAT:
+            out = np.empty((self.height, self.width, 4), np.float16)
+        else:
+            out = np.empty((self.height, self.width, 4), np.float32)
+        _check(lib().rt_pipeline_read_output(self.h, _ptr(out), out.nbytes))
+        return out
+
+    def enable_timing(self, on=True):
+        _check(lib().rt_pipeline_enable_timing(self.h, int(on)))
+
+    def stats(self):
+        s = Stats()
+        _check(lib().rt_pipeline_get_stats(self.h, C.byref(s)))
+        return s.as_dict()
+
+    def primary_hits(self, n):
+        t = np.empty(n, np.float32); prim = np.empty(n, np.uint32); inst = np.empty(n, np.uint32)
+        _check(lib().rt_pipeline_read_primary_hits(self.h, _ptr(t), _ptr(prim), _ptr(inst)))
+        return t, prim, inst
+
+
+def camera_look(eye, at, up):
+    eye, at, up = _f32(eye, 3), _f32(at, 3), _f32(up, 3)
+    f = np.empty(3, np.float32); u = np.empty(3, np.float32)
+    _check(lib().rt_camera_look(_ptr(eye), _ptr(at), _ptr(up), _ptr(f), _ptr(u)))
+    return f, u
+
+
+def camera_basis(forward, up, fov, aspect):
+    forward, up = _f32(forward, 3), _f32(up, 3)
+    U = np.empty(4, np.float32); V = np.empty(4, np.float32); W = np.empty(4, np.float32)
+    _check(lib().rt_camera_basis(_ptr(forward), _ptr(up), fov, aspect, _ptr(U), _ptr(V), _ptr(W)))
+    return U, V, W
+
+
+def camera_array(eye, at, up, fov, aspect):
+    """Pack the 11 floats rt_progressive_host_update takes."""
+    return np.array([*eye, *at, *up, fov, aspect], np.float32)
+
+
+class ProgressiveHost:
+    """Host-side frame logic of ProgressiveRaytracingPipeline::update (.cpp:177-213)."""
+
+    def __init__(self, rng_seed=1234):
+        h = C.c_void_p()
+        _check(lib().rt_progressive_host_create(rng_seed, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rt_progressive_host_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    @property
+    def options(self):
+        """Live numpy view (DEBUG_OPTIONS record) of mShaderDebugOptions."""
+        p = C.c_void_p()
+        _check(lib().rt_progressive_host_options(self.h, C.byref(p)))
+        buf = (C.c_uint8 * T.DEBUG_OPTIONS.itemsize).from_address(p.value)
+        return np.frombuffer(buf, dtype=T.DEBUG_OPTIONS, count=1)
+
+    def set_flags(self, accumulation_enabled=True, animation_paused=True):
+        _check(lib().rt_progressive_host_set_flags(self.h, int(accumulation_enabled), int(animation_paused)))
+
+    def reset(self):
+        _check(lib().rt_progressive_host_reset(self.h))
+
+    def update(self, camera11, elapsed_time, elapsed_frames, width, height):
+        cam = _f32(camera11, 11)
+        out = np.zeros((), T.PER_FRAME_CONSTANTS)
+        _check(lib().rt_progressive_host_update(self.h, _ptr(cam), elapsed_time, elapsed_frames, width, height, _ptr(out)))
+        return out

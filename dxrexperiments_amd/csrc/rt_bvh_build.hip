@@ -1,0 +1,468 @@
+// rt_bvh_build.hip -- BLAS / TLAS construction on the GPU.
+//
+// Stands in for what the reference enqueues through the Fallback Layer:
+//   RtModel::build  -> BottomLevelASGenerator::Generate -> BuildRaytracingAccelerationStructure
+//       (libs/DXRFramework/RtModel.cpp:86-118, Helpers/BottomLevelASGenerator.cpp:279-343)
+//   RtScene::build  -> TopLevelASGenerator::Generate    -> BuildRaytracingAccelerationStructure
+//       (libs/DXRFramework/RtScene.cpp:18-52, Helpers/TopLevelASGenerator.cpp:309-414)
+// The builder itself (source absent from the reference checkout) is this engine's
+// own: an LBVH whose every integer step is fully determined, so the CPU oracle and
+// these kernels produce identical node arrays:
+//   1. primitive AABBs + structure AABB           (exact float min/max)
+//   2. key = morton30(centre of AABB) << 32 | primitive index   (unique keys)
+//   3. ascending radix sort of the 62-bit keys
+//   4. Karras 2012 binary radix tree over the sorted keys (integer only)
+//   5. bottom-up AABB union (exact float min/max; order independent)
+//   6. traversal layout: 64-B two-child slabs, subtrees of <= leaf_max primitives
+//      collapsed into leaves, triangles gathered in sorted order.
+#include "rt_internal.h"
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+namespace {
+
+struct Box6 { float lo[3]; float hi[3]; };
+
+// order-preserving float <-> uint map for atomicMin / atomicMax
+__device__ __forceinline__ uint32_t f_enc(float f)
+{
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float f_dec(uint32_t k)
+{
+    uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(b);
+}
+#define ENC_POS_INF 0xFF800000u
+#define ENC_NEG_INF 0x007FFFFFu
+
+__device__ __forceinline__ float wave_min(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__global__ void k_init_bounds(uint32_t *enc)
+{
+    if (threadIdx.x < 3) enc[threadIdx.x] = ENC_POS_INF;
+    else if (threadIdx.x < 6) enc[threadIdx.x] = ENC_NEG_INF;
+}
+
+__device__ __forceinline__ void reduce_bounds(const Box6 &b, bool valid, uint32_t *enc)
+{
+    const float inf = __uint_as_float(0x7f800000u);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float lo = wave_min(valid ? b.lo[c] : inf);
+        float hi = wave_max(valid ? b.hi[c] : -inf);
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&enc[c], f_enc(lo));
+            atomicMax(&enc[3 + c], f_enc(hi));
+        }
+    }
+}
+
+__global__ void k_tri_boxes(const rt_vertex *__restrict__ verts, const uint32_t *__restrict__ idx, uint32_t n,
+                            Box6 *__restrict__ boxes, uint32_t *enc)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    Box6 b;
+    bool valid = i < n;
+    if (valid) {
+        rt_float3 p0 = verts[idx[3 * i + 0]].position;
+        rt_float3 p1 = verts[idx[3 * i + 1]].position;
+        rt_float3 p2 = verts[idx[3 * i + 2]].position;
+        b.lo[0] = fminf(fminf(p0.x, p1.x), p2.x); b.hi[0] = fmaxf(fmaxf(p0.x, p1.x), p2.x);
+        b.lo[1] = fminf(fminf(p0.y, p1.y), p2.y); b.hi[1] = fmaxf(fmaxf(p0.y, p1.y), p2.y);
+        b.lo[2] = fminf(fminf(p0.z, p1.z), p2.z); b.hi[2] = fmaxf(fmaxf(p0.z, p1.z), p2.z);
+        boxes[i] = b;
+    }
+    reduce_bounds(b, valid, enc);
+}
+
+__global__ void k_box_bounds(const Box6 *__restrict__ boxes, uint32_t n, uint32_t *enc)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    Box6 b;
+    bool valid = i < n;
+    if (valid) b = boxes[i];
+    reduce_bounds(b, valid, enc);
+}
+
+__global__ void k_decode_bounds(const uint32_t *enc, float *out)
+{
+    if (threadIdx.x < 6) out[threadIdx.x] = f_dec(enc[threadIdx.x]);
+}
+
+__device__ __forceinline__ uint32_t expand10(uint32_t v)
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__device__ __forceinline__ uint32_t quant10(float c, float lo, float ext)
+{
+    if (!(ext > 0.0f)) return 0;
+    float q = (c - lo) / ext * 1024.0f;
+    q = fminf(fmaxf(q, 0.0f), 1023.0f);
+    return (uint32_t)q;
+}
+
+__global__ void k_morton(const Box6 *__restrict__ boxes, uint32_t n, const float *__restrict__ bounds,
+                         uint64_t *__restrict__ keys)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Box6 b = boxes[i];
+    uint32_t m = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float ctr = (b.lo[c] + b.hi[c]) * 0.5f;
+        float ext = bounds[3 + c] - bounds[c];
+        m |= expand10(quant10(ctr, bounds[c], ext)) << (2 - c);
+    }
+    keys[i] = ((uint64_t)m << 32) | i;
+}
+
+__global__ void k_leaves(const uint64_t *__restrict__ keys, const Box6 *__restrict__ boxes, uint32_t n,
+                         rt_bvh_node *__restrict__ nodes, uint32_t *__restrict__ parents)
+{
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t prim = (uint32_t)(keys[k] & 0xFFFFFFFFull);
+    Box6 b = boxes[prim];
+    rt_bvh_node nd;
+    nd.bmin[0] = b.lo[0]; nd.bmin[1] = b.lo[1]; nd.bmin[2] = b.lo[2];
+    nd.bmax[0] = b.hi[0]; nd.bmax[1] = b.hi[1]; nd.bmax[2] = b.hi[2];
+    nd.left = prim;
+    nd.right = RT_LEAF;
+    nodes[n - 1 + k] = nd;
+    if (n == 1) parents[0] = 0xFFFFFFFFu;
+}
+
+__device__ __forceinline__ int key_delta(const uint64_t *__restrict__ k, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    return __clzll((long long)(k[i] ^ k[j]));
+}
+
+// Karras, "Maximizing parallelism in the construction of BVHs, octrees, and k-d trees", HPG 2012.
+__global__ void k_karras(const uint64_t *__restrict__ keys, int n, rt_bvh_node *__restrict__ nodes,
+                         uint32_t *__restrict__ parents, uint2 *__restrict__ ranges)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int d = (key_delta(keys, n, i, i + 1) - key_delta(keys, n, i, i - 1)) > 0 ? 1 : -1;
+    int dmin = key_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (key_delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (key_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = key_delta(keys, n, i, j);
+    int s = 0;
+    int t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (key_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    int gamma = i + s * d + min(d, 0);
+    int first = min(i, j), last = max(i, j);
+    uint32_t leaf0 = (uint32_t)(n - 1);
+    uint32_t left = (first == gamma) ? leaf0 + (uint32_t)gamma : (uint32_t)gamma;
+    uint32_t right = (last == gamma + 1) ? leaf0 + (uint32_t)(gamma + 1) : (uint32_t)(gamma + 1);
+    nodes[i].left = left;
+    nodes[i].right = right;
+    parents[left] = (uint32_t)i;
+    parents[right] = (uint32_t)i;
+    if (i == 0) parents[0] = 0xFFFFFFFFu;
+    ranges[i] = make_uint2((uint32_t)first, (uint32_t)last);
+}
+
+__global__ void k_refit_init(uint32_t *__restrict__ enc, uint32_t n_internal)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_internal * 6) return;
+    enc[i] = (i % 6) < 3 ? ENC_POS_INF : ENC_NEG_INF;
+}
+
+// Bottom-up union with device-scope integer atomics on order-preserving keys.  A
+// thread climbs while it still changes something; whoever made a node at least as
+// large keeps climbing with a box that covers this one, so every ancestor ends at
+// the exact min/max of its leaves without any inter-workgroup ordering protocol.
+__global__ void k_refit(const rt_bvh_node *__restrict__ nodes, const uint32_t *__restrict__ parents, uint32_t n,
+                        uint32_t *__restrict__ enc, uint32_t *__restrict__ max_depth)
+{
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t depth = 0;
+    if (k < n) {
+        const rt_bvh_node nd = nodes[n - 1 + k];
+        uint32_t e[6];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { e[c] = f_enc(nd.bmin[c]); e[3 + c] = f_enc(nd.bmax[c]); }
+        bool climbing = true;
+        for (uint32_t cur = parents[n - 1 + k]; cur != 0xFFFFFFFFu; cur = parents[cur]) {
+            depth++;
+            if (climbing) {
+                bool changed = false;
+                uint32_t *p = enc + (size_t)cur * 6;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    changed |= atomicMin(&p[c], e[c]) > e[c];
+                    changed |= atomicMax(&p[3 + c], e[3 + c]) < e[3 + c];
+                }
+                climbing = changed;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) depth = max(depth, (uint32_t)__shfl_xor((int)depth, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(max_depth, depth);
+}
+
+__global__ void k_refit_decode(const uint32_t *__restrict__ enc, rt_bvh_node *__restrict__ nodes, uint32_t n_internal)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_internal) return;
+    const uint32_t *p = enc + (size_t)i * 6;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        nodes[i].bmin[c] = f_dec(p[c]);
+        nodes[i].bmax[c] = f_dec(p[3 + c]);
+    }
+}
+
+__device__ __forceinline__ int child_code(uint32_t c, uint32_t n, const uint2 *__restrict__ ranges, uint32_t leaf_max,
+                                          const rt_bvh_node *__restrict__ nodes, bool tlas)
+{
+    if (c >= n - 1) {   // canonical leaf
+        uint32_t k = c - (n - 1);
+        return tlas ? ~(int)nodes[c].left : ~(int)((k << 3) | 0u);
+    }
+    uint2 r = ranges[c];
+    uint32_t cnt = r.y - r.x + 1;
+    if (!tlas && cnt <= leaf_max) return ~(int)((r.x << 3) | (cnt - 1));
+    return (int)c;
+}
+
+__global__ void k_layout(const rt_bvh_node *__restrict__ nodes, const uint2 *__restrict__ ranges, uint32_t n,
+                         uint32_t leaf_max, int tlas, Slab *__restrict__ slabs)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const rt_bvh_node nd = nodes[i];
+    const rt_bvh_node a = nodes[nd.left];
+    const rt_bvh_node b = nodes[nd.right];
+    Slab s;
+    s.q0 = make_float4(a.bmin[0], a.bmax[0], a.bmin[1], a.bmax[1]);
+    s.q1 = make_float4(b.bmin[0], b.bmax[0], b.bmin[1], b.bmax[1]);
+    s.q2 = make_float4(a.bmin[2], a.bmax[2], b.bmin[2], b.bmax[2]);
+    int c0 = child_code(nd.left, n, ranges, leaf_max, nodes, tlas != 0);
+    int c1 = child_code(nd.right, n, ranges, leaf_max, nodes, tlas != 0);
+    s.q3 = make_float4(__int_as_float(c0), __int_as_float(c1), 0.0f, 0.0f);
+    slabs[i] = s;
+}
+
+__global__ void k_gather_tris(const uint64_t *__restrict__ keys, const rt_vertex *__restrict__ verts,
+                              const uint32_t *__restrict__ idx, uint32_t n, TriRec *__restrict__ tris)
+{
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t prim = (uint32_t)(keys[k] & 0xFFFFFFFFull);
+    rt_float3 p0 = verts[idx[3 * prim + 0]].position;
+    rt_float3 p1 = verts[idx[3 * prim + 1]].position;
+    rt_float3 p2 = verts[idx[3 * prim + 2]].position;
+    TriRec t;
+    t.a = make_float4(p0.x, p0.y, p0.z, p1.x);
+    t.b = make_float4(p1.y, p1.z, p2.x, p2.y);
+    t.c = make_float4(p2.z, __uint_as_float(prim), 0.0f, 0.0f);
+    tris[k] = t;
+}
+
+inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+// Steps 2..6 for a structure whose primitive boxes and bounds are already on the device.
+int lbvh_from_boxes(rt_context *ctx, BvhDev &bv, const Box6 *boxes, uint32_t n, const float *d_bounds, bool tlas,
+                    DevBuf &tmp_keys, DevBuf &tmp_sort, DevBuf &tmp_enc, DevBuf &tmp_depth)
+{
+    hipStream_t st = ctx->stream;
+    const unsigned B = 256;
+    bv.n = n;
+    RT_TRY(bv.nodes.reserve(sizeof(rt_bvh_node) * (2 * (size_t)n - 1)));
+    RT_TRY(bv.keys.reserve(sizeof(uint64_t) * n));
+    RT_TRY(bv.parents.reserve(sizeof(uint32_t) * (2 * (size_t)n - 1)));
+    RT_TRY(bv.ranges.reserve(sizeof(uint2) * (n > 1 ? n - 1 : 1)));
+    RT_TRY(bv.slabs.reserve(sizeof(Slab) * (n > 1 ? n - 1 : 1)));
+    RT_TRY(tmp_keys.reserve(sizeof(uint64_t) * n));
+    RT_TRY(tmp_depth.reserve(sizeof(uint32_t)));
+
+    k_morton<<<grid_for(n, B), B, 0, st>>>(boxes, n, d_bounds, tmp_keys.as<uint64_t>());
+    size_t sort_bytes = 0;
+    HIP_TRY(rocprim::radix_sort_keys(nullptr, sort_bytes, tmp_keys.as<uint64_t>(), bv.keys.as<uint64_t>(), n, 0, 62, st));
+    RT_TRY(tmp_sort.reserve(sort_bytes));
+    HIP_TRY(rocprim::radix_sort_keys(tmp_sort.p, sort_bytes, tmp_keys.as<uint64_t>(), bv.keys.as<uint64_t>(), n, 0, 62, st));
+
+    rt_bvh_node *nodes = bv.nodes.as<rt_bvh_node>();
+    uint32_t *parents = bv.parents.as<uint32_t>();
+    k_leaves<<<grid_for(n, B), B, 0, st>>>(bv.keys.as<uint64_t>(), boxes, n, nodes, parents);
+    HIP_TRY(hipMemsetAsync(tmp_depth.p, 0, sizeof(uint32_t), st));
+    if (n > 1) {
+        k_karras<<<grid_for(n - 1, B), B, 0, st>>>(bv.keys.as<uint64_t>(), (int)n, nodes, parents, bv.ranges.as<uint2>());
+        RT_TRY(tmp_enc.reserve(sizeof(uint32_t) * 6 * (size_t)(n - 1)));
+        k_refit_init<<<grid_for((size_t)(n - 1) * 6, B), B, 0, st>>>(tmp_enc.as<uint32_t>(), n - 1);
+        k_refit<<<grid_for(n, B), B, 0, st>>>(nodes, parents, n, tmp_enc.as<uint32_t>(), tmp_depth.as<uint32_t>());
+        k_refit_decode<<<grid_for(n - 1, B), B, 0, st>>>(tmp_enc.as<uint32_t>(), nodes, n - 1);
+        k_layout<<<grid_for(n - 1, B), B, 0, st>>>(nodes, bv.ranges.as<uint2>(), n, tlas ? 1u : ctx->leaf_max, tlas ? 1 : 0,
+                                                   bv.slabs.as<Slab>());
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&bv.max_depth, tmp_depth.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(bv.bounds, d_bounds, 6 * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    bv.fast_depth = bv.max_depth + 1;
+    return RT_OK;
+}
+
+}  // namespace
+
+int rt_build_blas(rt_context *ctx, rt_model *m)
+{
+    if (m->built) return RT_OK;
+    hipStream_t st = ctx->stream;
+    const unsigned B = 256;
+    const uint32_t n = m->n_tris;
+    DevBuf boxes, enc, bounds, tkeys, tsort, tenc, tdepth;
+    int rc = RT_OK;
+    do {
+        if ((rc = boxes.reserve(sizeof(Box6) * (size_t)n)) != RT_OK) break;
+        if ((rc = enc.reserve(6 * sizeof(uint32_t))) != RT_OK) break;
+        if ((rc = bounds.reserve(6 * sizeof(float))) != RT_OK) break;
+        if ((rc = m->tris.reserve(sizeof(TriRec) * (size_t)n)) != RT_OK) break;
+        k_init_bounds<<<1, 64, 0, st>>>(enc.as<uint32_t>());
+        k_tri_boxes<<<grid_for(n, B), B, 0, st>>>(m->d_verts.as<rt_vertex>(), m->d_idx.as<uint32_t>(), n, boxes.as<Box6>(),
+                                                  enc.as<uint32_t>());
+        k_decode_bounds<<<1, 64, 0, st>>>(enc.as<uint32_t>(), bounds.as<float>());
+        if ((rc = lbvh_from_boxes(ctx, m->blas, boxes.as<Box6>(), n, bounds.as<float>(), false, tkeys, tsort, tenc, tdepth)) != RT_OK) break;
+        k_gather_tris<<<grid_for(n, B), B, 0, st>>>(m->blas.keys.as<uint64_t>(), m->d_verts.as<rt_vertex>(),
+                                                    m->d_idx.as<uint32_t>(), n, m->tris.as<TriRec>());
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            rt_set_error("BLAS build kernels failed");
+            rc = RT_ERR_HIP;
+            break;
+        }
+        if (n == 1) m->blas.root_code = ~(int)0;                                   // leaf(first 0, count 1)
+        else if (n <= ctx->leaf_max) m->blas.root_code = ~(int)(n - 1);            // leaf(first 0, count n)
+        else m->blas.root_code = 0;
+        m->built = true;
+    } while (0);
+    boxes.release(); enc.release(); bounds.release(); tkeys.release(); tsort.release(); tenc.release(); tdepth.release();
+    return rc;
+}
+
+// world-to-object = inverse of the affine 3x4 (adjugate / determinant in fp32,
+// operation order fixed: see DESIGN.md "Instances")
+static void invert3x4(const float m[12], float o[12])
+{
+    float a = m[0], b = m[1], c = m[2];
+    float d = m[4], e = m[5], f = m[6];
+    float g = m[8], h = m[9], i = m[10];
+    float A = e * i - f * h;
+    float B = f * g - d * i;
+    float C = d * h - e * g;
+    float det = a * A;
+    det = det + b * B;
+    det = det + c * C;
+    float id = 1.0f / det;
+    o[0] = A * id; o[1] = (c * h - b * i) * id; o[2] = (b * f - c * e) * id;
+    o[4] = B * id; o[5] = (a * i - c * g) * id; o[6] = (c * d - a * f) * id;
+    o[8] = C * id; o[9] = (b * g - a * h) * id; o[10] = (a * e - b * d) * id;
+    for (int r = 0; r < 3; r++) {
+        float s = o[4 * r + 0] * m[3];
+        s = s + o[4 * r + 1] * m[7];
+        s = s + o[4 * r + 2] * m[11];
+        o[4 * r + 3] = -s;
+    }
+}
+
+int rt_build_tlas(rt_context *ctx, rt_scene *s)
+{
+    hipStream_t st = ctx->stream;
+    const uint32_t n = (uint32_t)s->inst.size();
+    static const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    s->h_inst.assign(n, InstanceRec());
+    std::vector<Box6> hb(n);
+    uint32_t deepest = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        rt_model *m = s->inst[i].model;
+        InstanceRec &r = s->h_inst[i];
+        const float *x = s->inst[i].xform;
+        bool identity = true;
+        for (int k = 0; k < 12; k++) identity = identity && (x[k] == ident[k]);
+        const float *bb = m->blas.bounds;
+        if (identity) {
+            memcpy(r.inv, x, sizeof r.inv);
+            for (int c = 0; c < 3; c++) { r.wlo[c] = bb[c]; r.whi[c] = bb[3 + c]; }
+        } else {
+            invert3x4(x, r.inv);
+            const float inf = __builtin_inff();
+            for (int c = 0; c < 3; c++) { r.wlo[c] = inf; r.whi[c] = -inf; }
+            for (int corner = 0; corner < 8; corner++) {
+                float px = (corner & 1) ? bb[3] : bb[0];
+                float py = (corner & 2) ? bb[4] : bb[1];
+                float pz = (corner & 4) ? bb[5] : bb[2];
+                for (int rr = 0; rr < 3; rr++) {
+                    float w = x[4 * rr + 0] * px;
+                    w = w + x[4 * rr + 1] * py;
+                    w = w + x[4 * rr + 2] * pz;
+                    w = w + x[4 * rr + 3];
+                    r.wlo[rr] = w < r.wlo[rr] ? w : r.wlo[rr];
+                    r.whi[rr] = w > r.whi[rr] ? w : r.whi[rr];
+                }
+            }
+        }
+        r.root_code = m->blas.root_code;
+        r.flags = identity ? RT_INST_IDENTITY : 0u;
+        r.slabs = m->blas.slabs.as<Slab>();
+        r.tris = m->tris.as<TriRec>();
+        r.cnodes = m->blas.nodes.as<rt_bvh_node>();
+        r.verts = m->d_verts.as<rt_vertex>();
+        r.indices = m->d_idx.as<uint32_t>();
+        r.n_prims = m->n_tris;
+        r.material = i;
+        for (int c = 0; c < 3; c++) { hb[i].lo[c] = r.wlo[c]; hb[i].hi[c] = r.whi[c]; }
+        deepest = m->blas.fast_depth > deepest ? m->blas.fast_depth : deepest;
+    }
+    DevBuf boxes, enc, bounds, tkeys, tsort, tenc, tdepth;
+    int rc = RT_OK;
+    do {
+        if ((rc = s->d_inst.reserve(sizeof(InstanceRec) * (size_t)n)) != RT_OK) break;
+        if ((rc = boxes.reserve(sizeof(Box6) * (size_t)n)) != RT_OK) break;
+        if ((rc = enc.reserve(6 * sizeof(uint32_t))) != RT_OK) break;
+        if ((rc = bounds.reserve(6 * sizeof(float))) != RT_OK) break;
+        if (hipMemcpyAsync(s->d_inst.p, s->h_inst.data(), sizeof(InstanceRec) * n, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(boxes.p, hb.data(), sizeof(Box6) * n, hipMemcpyHostToDevice, st) != hipSuccess) {
+            rt_set_error("instance upload failed");
+            rc = RT_ERR_HIP;
+            break;
+        }
+        k_init_bounds<<<1, 64, 0, st>>>(enc.as<uint32_t>());
+        k_box_bounds<<<grid_for(n, 256), 256, 0, st>>>(boxes.as<Box6>(), n, enc.as<uint32_t>());
+        k_decode_bounds<<<1, 64, 0, st>>>(enc.as<uint32_t>(), bounds.as<float>());
+        if ((rc = lbvh_from_boxes(ctx, s->tlas, boxes.as<Box6>(), n, bounds.as<float>(), true, tkeys, tsort, tenc, tdepth)) != RT_OK) break;
+        s->tlas.root_code = (n == 1) ? ~(int)0 : 0;     // single instance: root is the leaf of instance 0
+        s->stack_need = s->tlas.fast_depth + deepest + 2;
+    } while (0);
+    boxes.release(); enc.release(); bounds.release(); tkeys.release(); tsort.release(); tenc.release(); tdepth.release();
+    return rc;
+}

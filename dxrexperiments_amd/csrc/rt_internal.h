@@ -1,0 +1,185 @@
+// rt_internal.h -- objects behind the opaque C-ABI handles (include/dxr_amd.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/dxr_amd.h"
+
+void rt_set_error(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            rt_set_error("%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return RT_ERR_HIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+#define RT_TRY(expr)              \
+    do {                          \
+        int r_ = (expr);          \
+        if (r_ != RT_OK) return r_; \
+    } while (0)
+
+#define RT_REQUIRE(cond, msg)                        \
+    do {                                             \
+        if (!(cond)) {                               \
+            rt_set_error("%s: %s", __func__, msg);   \
+            return RT_ERR_INVALID_ARG;               \
+        }                                            \
+    } while (0)
+
+// Owning device allocation; grows on demand, never shrinks.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t n)
+    {
+        if (n <= bytes) return RT_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, n ? n : 16);
+        if (e != hipSuccess) {
+            rt_set_error("hipMalloc(%zu): %s", n, hipGetErrorString(e));
+            p = nullptr;
+            return e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP;
+        }
+        bytes = n ? n : 16;
+        return RT_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+// ---- device-visible records -------------------------------------------------
+
+// One traversal slab = one internal BVH2 node with BOTH child boxes (64 B, one
+// aligned half cache line, fetched as 4 x dwordx4).
+//   q0 = c0.lo.x c0.hi.x c0.lo.y c0.hi.y
+//   q1 = c1.lo.x c1.hi.x c1.lo.y c1.hi.y
+//   q2 = c0.lo.z c0.hi.z c1.lo.z c1.hi.z
+//   q3 = code0 code1 (int bits) 0 0
+// Child code: >= 0 internal slab index; < 0 leaf: ~code = (first << 3) | (count-1)
+// for a BLAS (triangles first..first+count-1 of the sorted triangle array), or the
+// instance index for the TLAS.
+struct Slab { float4 q0, q1, q2, q3; };
+
+// One triangle in leaf order: the three ORIGINAL vertex positions (so that the
+// Moller-Trumbore edges and the triangle's own AABB are recomputed from the same
+// floats the canonical BVH was built from) plus the primitive id.  48 B.
+struct TriRec { float4 a, b, c; };   // a = v0.xyz v1.x ; b = v1.yz v2.xy ; c = v2.z prim 0 0
+
+#define RT_INST_IDENTITY 1u
+
+struct InstanceRec {
+    float inv[12];              // world-to-object, 3x4 row-major
+    float wlo[3]; int root_code;
+    float whi[3]; uint32_t flags;
+    const Slab *slabs;
+    const TriRec *tris;
+    const rt_bvh_node *cnodes;  // canonical nodes of the BLAS
+    const rt_vertex *verts;
+    const uint32_t *indices;
+    uint32_t n_prims;
+    uint32_t material;
+};
+
+struct SceneDev {
+    const InstanceRec *inst;
+    const Slab *tlas_slabs;
+    const rt_bvh_node *tlas_cnodes;
+    uint32_t n_inst;
+    int tlas_root_code;
+};
+
+// ---- host objects --------------------------------------------------------------
+
+struct rt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_trace_ms = 0.0f;
+    uint32_t leaf_max = 4;       // triangles per collapsed leaf in the traversal layout
+    DevBuf scratch[8];           // staging for host-pointer batch calls
+};
+
+struct BvhDev {
+    uint32_t n = 0;              // primitives
+    uint32_t max_depth = 0;
+    float bounds[6] = {0, 0, 0, 0, 0, 0};
+    DevBuf nodes;                // rt_bvh_node[2n-1]   canonical
+    DevBuf keys;                 // uint64[n]           sorted morton keys
+    DevBuf parents;              // uint32[2n-1]
+    DevBuf ranges;               // uint2[n-1]          leaf range of every internal node
+    DevBuf slabs;                // Slab[max(n-1,1)]    traversal layout
+    int root_code = -1;
+    uint32_t fast_depth = 0;     // stack entries the traversal layout can need
+    void release() { nodes.release(); keys.release(); parents.release(); ranges.release(); slabs.release(); }
+};
+
+struct rt_model {
+    rt_context *ctx = nullptr;
+    int refs = 1;
+    uint32_t n_verts = 0, n_tris = 0;
+    std::vector<rt_vertex> h_verts;
+    std::vector<uint32_t> h_idx;
+    DevBuf d_verts, d_idx;
+    DevBuf tris;                 // TriRec[n_tris] in sorted order
+    BvhDev blas;
+    bool built = false;
+};
+
+struct SceneInstance {
+    rt_model *model;
+    float xform[12];
+};
+
+struct rt_scene {
+    rt_context *ctx = nullptr;
+    std::vector<SceneInstance> inst;
+    std::vector<InstanceRec> h_inst;
+    DevBuf d_inst;
+    BvhDev tlas;
+    bool built = false;
+    float build_ms = 0.0f;
+    uint32_t stack_need = 0;     // traversal stack entries needed (TLAS + deepest BLAS + sentinel)
+    SceneDev dev() const
+    {
+        SceneDev s;
+        s.inst = d_inst.as<InstanceRec>();
+        s.tlas_slabs = tlas.slabs.as<Slab>();
+        s.tlas_cnodes = tlas.nodes.as<rt_bvh_node>();
+        s.n_inst = (uint32_t)inst.size();
+        s.tlas_root_code = tlas.root_code;
+        return s;
+    }
+};
+
+// ---- internal entry points shared between translation units ---------------------
+
+// rt_bvh_build.hip
+int rt_build_blas(rt_context *ctx, rt_model *m);
+int rt_build_tlas(rt_context *ctx, rt_scene *s);
+
+// rt_trace.hip
+struct TraceOut {
+    float *t, *u, *v;
+    uint32_t *prim, *inst, *cnt_nodes, *cnt_tris;
+};
+int rt_launch_trace(rt_context *ctx, const rt_scene *s, const float4 *origin_tmin, const float4 *dir_tmax, size_t n,
+                    uint32_t ray_flags, uint32_t kernel, const TraceOut &out);
+
+// rt_obj.cpp
+int rt_obj_parse(const char *path, std::vector<rt_vertex> &verts, std::vector<uint32_t> &idx);

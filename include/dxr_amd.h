@@ -1,0 +1,185 @@
+/*
+ * dxr_amd.h -- C ABI of the MI355X-native progressive ray tracer.
+ *
+ * This is the drop-in boundary for ONE path of philcn/DXRExperiments: the
+ * ProgressiveRaytracingPipeline (BLAS/TLAS build, traversal, ray-triangle
+ * intersection, raygen / closest-hit / miss shading, float accumulation).
+ * Each export names the reference interface it stands in for (file:line in
+ * the reference tree).  D3D12 objects become opaque handles; the program /
+ * state / bindings objects of the reference (RtProgram, RtState, RtBindings)
+ * survive only in the C++ wrapper (dxrexperiments_amd/include), because HIP
+ * kernels are linked at build time and there is no shader table to fill.
+ *
+ * Conventions
+ *   - every function returns RT_OK (0) or a negative RT_ERR_* code and never
+ *     throws; rt_last_error() returns the message of the calling thread's
+ *     most recent failure.
+ *   - a context is bound to one GPU and one HIP stream and is not thread
+ *     safe; distinct contexts may be used from distinct threads.
+ *   - host pointers passed in are copied before the call returns.
+ *   - render / trace calls are asynchronous on the context's stream unless
+ *     they return data to host memory; rt_context_synchronize() joins.
+ *   - there is NO CPU fallback: without a usable HIP device every call that
+ *     needs one fails with RT_ERR_HIP.
+ */
+#ifndef DXR_AMD_H
+#define DXR_AMD_H
+
+#include <stddef.h>
+#include "dxr_amd_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_context  rt_context;
+typedef struct rt_model    rt_model;
+typedef struct rt_scene    rt_scene;
+typedef struct rt_pipeline rt_pipeline;
+typedef struct rt_progressive_host rt_progressive_host;
+
+/* ---- library ------------------------------------------------------------- */
+
+const char *rt_version(void);
+const char *rt_last_error(void);
+/* number of visible HIP devices, or a negative RT_ERR_* code */
+int rt_device_count(void);
+
+/* ---- RtContext (libs/DXRFramework/RtContext.h:15-46) ----------------------- */
+
+/* RtContext::create (RtContext.h:15, RtContext.cpp:12-29): device + queue. */
+int rt_context_create(int device, rt_context **out);
+/* Same, but work is issued on the caller's hipStream_t (e.g. PyTorch's). */
+int rt_context_create_on_stream(int device, void *hip_stream, rt_context **out);
+int rt_context_destroy(rt_context *ctx);
+/* DeviceResources::WaitForGpu (src/utils/DeviceResources.cpp:559) */
+int rt_context_synchronize(rt_context *ctx);
+int rt_context_get_stream(rt_context *ctx, void **hip_stream_out);
+int rt_context_get_device(rt_context *ctx, int *device_out);
+
+/* ---- RtModel (libs/DXRFramework/RtModel.h:13, RtModel.cpp:24-118) ---------- */
+
+/* RtModel::create(ctx, filePath) (RtModel.h:13).  Wavefront OBJ only; see
+ * DESIGN.md for the vertex/primitive ordering this reader defines. */
+int rt_model_create_from_obj(rt_context *ctx, const char *path, rt_model **out);
+/* The arrays RtModel's constructor builds (RtModel.cpp:33-81). */
+int rt_model_create_from_arrays(rt_context *ctx, const rt_vertex *verts, uint32_t n_verts,
+                                const uint32_t *indices, uint32_t n_tris, rt_model **out);
+int rt_model_get_counts(const rt_model *m, uint32_t *n_verts, uint32_t *n_tris);
+/* copy the ingested geometry back (host buffers sized by get_counts) */
+int rt_model_read_geometry(const rt_model *m, rt_vertex *verts, uint32_t *indices);
+int rt_model_retain(rt_model *m);
+int rt_model_destroy(rt_model *m);
+
+/* ---- RtScene (libs/DXRFramework/RtScene.h:14-37, RtScene.cpp:18-52) -------- */
+
+int rt_scene_create(rt_context *ctx, rt_scene **out);                     /* RtScene::create  RtScene.h:14 */
+/* RtScene::addModel(model, XMMATRIX) (RtScene.h:30): object-to-world as the
+ * 3x4 row-major rows the instance desc stores (TopLevelASGenerator.cpp:355-357). */
+int rt_scene_add_model(rt_scene *s, rt_model *m, const float transform3x4[12]);
+int rt_scene_get_num_instances(const rt_scene *s, uint32_t *n);           /* RtScene.h:32 */
+/* RtScene::build(ctx, hitGroupCount) (RtScene.cpp:18-52): BLAS per distinct
+ * model (RtModel::build, RtModel.cpp:86-118), then the TLAS, all on the GPU. */
+int rt_scene_build(rt_scene *s, uint32_t hit_group_count);
+int rt_scene_destroy(rt_scene *s);
+
+/* Inspection of the canonical acceleration structures (tests, tools).
+ * which = -1: TLAS; which >= 0: BLAS of the model used by instance `which`. */
+int rt_scene_bvh_info(const rt_scene *s, int which, uint32_t *n_prims, uint32_t *n_nodes, uint32_t *max_depth);
+int rt_scene_bvh_read(const rt_scene *s, int which, rt_bvh_node *nodes, uint64_t *sorted_keys, uint32_t *parents);
+int rt_scene_instance_info(const rt_scene *s, uint32_t instance, float world_box[6], float world_to_object[12]);
+/* milliseconds the last rt_scene_build spent on the GPU (BLAS + TLAS) */
+int rt_scene_build_ms(const rt_scene *s, float *ms);
+
+/* ---- raw TraceRay over a batch (HLSL TraceRay semantics, used by tests and
+ *      the traversal benchmark; ProgressiveRaytracing.hlsl:34,53,
+ *      RaytracingCommon.hlsli:94) ------------------------------------------- */
+
+#define RT_MEM_HOST   0u
+#define RT_MEM_DEVICE 1u
+#define RT_TRACE_FAST       0u   /* production kernel */
+#define RT_TRACE_CANONICAL  1u   /* reference-order kernel, also fills the counters */
+
+/* origin_tmin / dir_tmax: n x float4.  Outputs (each may be NULL): t (-1 on
+ * miss), u, v, prim, inst (RT_NO_HIT on miss), nodes / tris traversal
+ * counters (RT_TRACE_CANONICAL only).  mem says where ALL pointers live. */
+int rt_trace_batch(rt_context *ctx, const rt_scene *s,
+                   const float *origin_tmin, const float *dir_tmax, size_t n,
+                   uint32_t ray_flags, uint32_t kernel, uint32_t mem,
+                   float *t, float *u, float *v, uint32_t *prim, uint32_t *inst,
+                   uint32_t *cnt_nodes, uint32_t *cnt_tris);
+/* average GPU milliseconds of the traversal kernel in the last rt_trace_batch */
+int rt_trace_last_ms(rt_context *ctx, float *ms);
+
+/* ---- RaytracingPipeline / ProgressiveRaytracingPipeline
+ *      (include/RaytracingPipeline.h:8-39, include/ProgressiveRaytracingPipeline.h:19-40,
+ *       src/ProgressiveRaytracingPipeline.cpp) ------------------------------- */
+
+#define RT_PIPELINE_PROGRESSIVE 0u
+
+int rt_pipeline_create(rt_context *ctx, uint32_t kind, rt_pipeline **out);   /* ::create  ProgressiveRaytracingPipeline.h:19 */
+int rt_pipeline_destroy(rt_pipeline *p);
+const char *rt_pipeline_get_name(const rt_pipeline *p);                      /* getName   :40 */
+int rt_pipeline_set_scene(rt_pipeline *p, rt_scene *s);                      /* setScene  .cpp:93-97 */
+int rt_pipeline_add_material(rt_pipeline *p, const rt_material_params *m);   /* addMaterial .h:30; material i <-> instance i */
+int rt_pipeline_set_material(rt_pipeline *p, uint32_t index, const rt_material_params *m);
+/* loadResources (.cpp:104-125): the environment cube map (t1/space2).  faces =
+ * 6 x size x size RGBA float32, D3D face order +X -X +Y -Y +Z -Z. */
+int rt_pipeline_set_environment_cube(rt_pipeline *p, const float *faces_rgba32f, uint32_t size);
+int rt_pipeline_set_environment_constant(rt_pipeline *p, const float rgb[3]);
+/* DDS cube map, DXGI_FORMAT_R16G16B16A16_FLOAT or R32G32B32A32_FLOAT, mip 0 used */
+int rt_pipeline_load_environment_dds(rt_pipeline *p, const char *path);
+/* createOutputResource(format, w, h) (.cpp:127-149); accumulation is always fp32,
+ * `format` selects what rt_pipeline_read_output converts to. */
+int rt_pipeline_create_output(rt_pipeline *p, uint32_t format, uint32_t width, uint32_t height);
+/* Render into caller-owned device memory (w*h*4 floats), e.g. a torch tensor. */
+int rt_pipeline_bind_output(rt_pipeline *p, void *device_rgba32f, uint32_t width, uint32_t height);
+int rt_pipeline_build_acceleration_structures(rt_pipeline *p);               /* .cpp:99-102 */
+/* MAX_RADIANCE_RAY_DEPTH / MAX_SHADOW_RAY_DEPTH (RaytracingCommon.hlsli:11-12); defaults 1, 2 */
+int rt_pipeline_set_depth_limits(rt_pipeline *p, uint32_t max_radiance_depth, uint32_t max_shadow_depth);
+int rt_pipeline_set_accumulation_mode(rt_pipeline *p, uint32_t mode);        /* RT_ACCUM_* */
+int rt_pipeline_clear_output(rt_pipeline *p);
+/* update(): the 188-byte constant buffer the reference fills each frame (.cpp:177-213) */
+int rt_pipeline_update(rt_pipeline *p, const rt_per_frame_constants *constants);
+/* render(cmdList, frameIndex, w, h) (.cpp:215-247): one 1-spp progressive frame. */
+int rt_pipeline_render(rt_pipeline *p, uint32_t width, uint32_t height);
+/* same, restricted to pixel rectangle [x0,x1) x [y0,y1) (tile sharding) */
+int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height,
+                            uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
+int rt_pipeline_get_num_outputs(const rt_pipeline *p, int *n);               /* getNumOutputs .h:34 */
+int rt_pipeline_get_output_device_ptr(rt_pipeline *p, uint32_t id, void **ptr); /* getOutputResource .h:35 */
+/* synchronises; host buffer is w*h*4 floats (RGBA32F) or halfs (RGBA16F) */
+int rt_pipeline_read_output(rt_pipeline *p, void *host, size_t bytes);
+/* synchronises; timings need rt_pipeline_enable_timing(p, 1) */
+int rt_pipeline_get_stats(rt_pipeline *p, rt_stats *out);
+int rt_pipeline_enable_timing(rt_pipeline *p, int enable);
+/* per-pixel primary-hit records of the last render (tests): w*h each, may be NULL */
+int rt_pipeline_read_primary_hits(rt_pipeline *p, float *t, uint32_t *prim, uint32_t *inst);
+
+/* ---- host-side frame logic (src/ProgressiveRaytracingPipeline.cpp:151-213,
+ *      libs/MiniEngine/Camera.cpp:19-36) --------------------------------------- */
+
+/* camera = eye[3] at[3] up[3] vfov aspect(width/height) */
+int rt_camera_look(const float eye[3], const float at[3], const float up[3], float forward_out[3], float up_out[3]);
+int rt_camera_basis(const float forward[3], const float up[3], float vfov, float aspect,
+                    float U[4], float V[4], float W[4]);                    /* calculateCameraVariables :151-168 */
+int rt_progressive_host_create(uint32_t rng_seed, rt_progressive_host **out);
+int rt_progressive_host_destroy(rt_progressive_host *h);
+int rt_progressive_host_options(rt_progressive_host *h, rt_debug_options **options);   /* mShaderDebugOptions :74-84 */
+int rt_progressive_host_set_flags(rt_progressive_host *h, int accumulation_enabled, int animation_paused);
+int rt_progressive_host_reset(rt_progressive_host *h);                      /* frameDirty :309-311 */
+int rt_progressive_host_update(rt_progressive_host *h, const float camera[11], float elapsed_time,
+                               uint32_t elapsed_frames, uint32_t width, uint32_t height,
+                               rt_per_frame_constants *out);                /* update :177-213 */
+
+/* ---- device math probes (tests): evaluate the kernels' deterministic
+ *      sin/cos/exp/log/pow/sqrt/div and samplers on the GPU ------------------- */
+int rt_debug_math(rt_context *ctx, int fn, const float *x, const float *y, float *out, size_t n);
+int rt_debug_sample(rt_context *ctx, int kind, const uint32_t *seeds, const float *vec3_in, float exponent,
+                    float *vec3_out, float *pdf_brdf, uint32_t *seeds_out, size_t n);
+int rt_debug_sample_cube(rt_context *ctx, const float *faces_rgba32f, uint32_t size, const float *dirs, float *out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DXR_AMD_H */

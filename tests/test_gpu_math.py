@@ -1,0 +1,88 @@
+"""Device arithmetic == oracle arithmetic, bit for bit (sqrt, divide, the engine-defined
+sin/cos/exp/log/pow, min/max, the RNG-driven samplers, Fresnel, cube-map sampling)."""
+import numpy as np
+import pytest
+
+from util import rng
+
+pytestmark = pytest.mark.gpu
+
+FN = dict(sin=0, cos=1, exp=2, log=3, pow=4, sqrt=5, div=6, min=7, max=8)
+
+
+def same_bits(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    nan = np.isnan(a) & np.isnan(b)
+    return np.array_equal(a.view(np.uint32)[~nan], b.view(np.uint32)[~nan]) or np.array_equal(a[~nan], b[~nan])
+
+
+def specials():
+    return np.array([0.0, -0.0, 1.0, -1.0, 0.5, 2.0, 1e-38, 1e-45, -1e-45, 3e-39, 1e38, 3.4e38, np.inf, -np.inf, np.nan,
+                     1.17549435e-38, 88.4, 88.6, -85.9, -86.1, -104.0, 6.2831855, 3.1415927], np.float32)
+
+
+@pytest.mark.parametrize("fn", ["sin", "cos", "exp", "log", "sqrt"])
+def test_unary_bit_exact(gpu, oracle, fn):
+    r = rng(10)
+    if fn in ("sin", "cos"):
+        x = np.concatenate([r.uniform(0, 6.2832, 1 << 20), r.uniform(-1000, 1000, 1 << 18)]).astype(np.float32)
+    elif fn == "exp":
+        x = r.uniform(-100, 95, 1 << 20).astype(np.float32)
+    else:
+        x = np.exp(r.uniform(-87, 88, 1 << 20)).astype(np.float32)
+    if fn != "log":
+        x = np.concatenate([x, specials()])
+    if fn in ("sin", "cos"):            # the kernels are defined for |x| < 2^16 * pi/2
+        x = x[np.abs(x) < 1.0e5]
+    got = gpu.math(FN[fn], x)
+    want = oracle.math(fn, x)
+    assert same_bits(got, want), "%s differs on %d inputs" % (fn, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("fn", ["div", "min", "max", "pow"])
+def test_binary_bit_exact(gpu, oracle, fn):
+    r = rng(11)
+    n = 1 << 20
+    if fn == "pow":
+        x = np.concatenate([r.uniform(0, 1, n), [0.0, 1.0, 0.5]]).astype(np.float32)
+        y = np.concatenate([np.exp(r.uniform(-6, 7, n)), [5.0, 403.4288, 1.0 / 404.4288]]).astype(np.float32)
+    else:
+        x = (r.standard_normal(n) * np.exp(r.uniform(-40, 40, n))).astype(np.float32)
+        y = (r.standard_normal(n) * np.exp(r.uniform(-40, 40, n))).astype(np.float32)
+        s = specials()
+        x = np.concatenate([x, np.repeat(s, s.size)])
+        y = np.concatenate([y, np.tile(s, s.size)])
+    got = gpu.math(FN[fn], x, y)
+    want = oracle.math(fn, x, y)
+    if fn in ("min", "max"):      # sign of zero may differ between v_min_f32 and the written-out form
+        ok = (got == want) | (np.isnan(got) & np.isnan(want))
+        assert ok.all()
+    else:
+        assert same_bits(got, want), "%s differs on %d inputs" % (fn, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("kind,idx", [("cos", 0), ("uniform", 1), ("phong", 2), ("perp", 3)])
+def test_samplers_bit_exact(gpu, oracle, kind, idx):
+    r = rng(12)
+    n = 1 << 18
+    seeds = r.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    v = r.standard_normal((n, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v = v.astype(np.float32)
+    v[:6] = np.eye(3, dtype=np.float32).repeat(2, 0) * np.array([1, -1] * 3, np.float32)[:, None]
+    exponent = float(oracle.math("exp", np.array([6.0], np.float32))[0])
+    g = gpu.sample(idx, seeds, v, exponent)
+    o = oracle.sample(kind, seeds, v, exponent)
+    assert same_bits(g[0], o[0])
+    assert same_bits(g[1], o[1])
+    assert np.array_equal(g[2], o[2])
+
+
+def test_cube_sampling_bit_exact(gpu, oracle):
+    from dxrexperiments_amd import scenes
+    faces = scenes.sky_cubemap(16)
+    r = rng(13)
+    d = r.standard_normal((1 << 16, 3)).astype(np.float32)
+    d[:8] = [[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [1, 1, 1], [0, 0, 0]]
+    d[8] = [np.nan, 0, 1]
+    assert same_bits(gpu.sample_cube(faces, d), oracle.sample_cube(faces, d))

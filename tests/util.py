@@ -1,0 +1,133 @@
+"""Shared helpers for the parity tests: scene construction on both sides, ray sets."""
+import os
+
+import numpy as np
+
+from dxrexperiments_amd import rtypes as T
+from dxrexperiments_amd import scenes
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CORNELL_OBJ = os.path.join(GOLDEN, "cornell.obj")
+
+CULL = T.RAY_FLAG_CULL_BACK_FACING_TRIANGLES
+ANY = T.RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH | T.RAY_FLAG_SKIP_CLOSEST_HIT_SHADER
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+def triangle_soup(n, seed, extent=10.0, size=0.6):
+    """n random triangles (own vertices, flat normals)."""
+    r = rng(seed)
+    c = r.uniform(-extent, extent, (n, 1, 3))
+    p = (c + r.uniform(-size, size, (n, 3, 3))).astype(np.float32).reshape(-1, 3)
+    v = np.zeros(3 * n, T.VERTEX)
+    v["position"] = p
+    fn = np.cross(p[1::3] - p[0::3], p[2::3] - p[0::3])
+    l = np.linalg.norm(fn, axis=1, keepdims=True)
+    l[l == 0] = 1
+    v["normal"] = np.repeat((fn / l).astype(np.float32), 3, axis=0)
+    return v, np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+
+
+def random_xforms(n, seed, spread=8.0):
+    r = rng(seed)
+    out = np.zeros((n, 12), np.float32)
+    for i in range(n):
+        a, b, c = r.uniform(0, 2 * np.pi, 3)
+        rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+        ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+        rx = np.array([[1, 0, 0], [0, np.cos(c), -np.sin(c)], [0, np.sin(c), np.cos(c)]])
+        s = np.diag(r.uniform(0.5, 1.5, 3))
+        m = np.zeros((3, 4))
+        m[:, :3] = rz @ ry @ rx @ s
+        m[:, 3] = r.uniform(-spread, spread, 3)
+        out[i] = m.astype(np.float32).reshape(12)
+    return out
+
+
+class Pair:
+    """The same scene on the oracle and on the GPU."""
+
+    def __init__(self, oracle, capi, ctx, models, instances):
+        """models: list of (verts, idx); instances: list of (model_index, xform or None)."""
+        self.o = oracle.Scene()
+        self.g = capi.Scene(ctx)
+        self.gmodels = []
+        for v, i in models:
+            self.o.add_model(v, i)
+            self.gmodels.append(capi.Model(ctx, v, i))
+        for mi, x in instances:
+            self.o.add_instance(mi, x)
+            self.g.add_model(self.gmodels[mi], x)
+        self.o.build()
+        self.g.build()
+        self.n_instances = len(instances)
+
+
+def random_rays(n, seed, lo, hi, tmin=0.0, tmax=1e38):
+    """Rays with origins in a box grown around [lo,hi] aimed at random points inside it."""
+    r = rng(seed)
+    lo, hi = np.asarray(lo, np.float64), np.asarray(hi, np.float64)
+    c, e = 0.5 * (lo + hi), 0.5 * (hi - lo)
+    o = c + r.uniform(-1.6, 1.6, (n, 3)) * e
+    t = c + r.uniform(-1.0, 1.0, (n, 3)) * e
+    d = t - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    O = np.zeros((n, 4), np.float32); D = np.zeros((n, 4), np.float32)
+    O[:, :3] = o; O[:, 3] = tmin
+    D[:, :3] = d; D[:, 3] = tmax
+    return O, D
+
+
+def primary_rays(pf, W, H):
+    """RayGen's ray set-up in numpy fp32 (same operation order as the kernels)."""
+    cp = pf["cameraParams"]
+    f = np.float32
+    xs, ys = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing="xy")
+    dx = ((xs + f(0.5)) / f(W)) * f(2.0) - f(1.0)
+    dy = ((ys + f(0.5)) / f(H)) * f(2.0) - f(1.0)
+    d = dx[..., None] * cp["U"][:3] + (-dy)[..., None] * cp["V"][:3]
+    d = d + cp["W"][:3]
+    dot = d[..., 0] * d[..., 0]
+    dot = dot + d[..., 1] * d[..., 1]
+    dot = dot + d[..., 2] * d[..., 2]
+    d = d * (f(1.0) / np.sqrt(dot))[..., None]
+    n = W * H
+    o = np.zeros((n, 4), np.float32)
+    j = cp["jitters"] * f(30.0)
+    o[:, 0] = cp["worldEyePos"][0] + j[0]
+    o[:, 1] = cp["worldEyePos"][1] + j[1]
+    o[:, 2] = cp["worldEyePos"][2] + f(0.0)
+    dd = np.zeros((n, 4), np.float32)
+    dd[:, :3] = d.reshape(-1, 3)
+    dd[:, 3] = f(1.0e38)
+    return o, dd
+
+
+def assert_hits_equal(a, b, what="", closest=True):
+    """Bit-exact comparison of two hit dictionaries (miss t = -1 on both sides)."""
+    hit_a = a["inst"] != T.RT_NO_HIT
+    hit_b = b["inst"] != T.RT_NO_HIT
+    assert np.array_equal(hit_a, hit_b), "%s: hit/miss differs on %d rays" % (what, int((hit_a != hit_b).sum()))
+    if not closest:
+        return
+    for k in ("inst", "prim"):
+        bad = np.nonzero(a[k] != b[k])[0]
+        assert bad.size == 0, "%s: %s differs on %d rays, first %d: %s vs %s" % (what, k, bad.size, bad[0], a[k][bad[0]], b[k][bad[0]])
+    for k in ("t", "u", "v"):
+        x, y = a[k][hit_a], b[k][hit_a]
+        bad = np.nonzero(x.view(np.uint32) != y.view(np.uint32))[0]
+        bad = bad[x[bad] != y[bad]]        # +0 / -0 compare equal
+        assert bad.size == 0, "%s: %s differs on %d rays (first: %r vs %r)" % (what, k, bad.size, x[bad[0]], y[bad[0]])
+
+
+def nodes_equal(a, b):
+    """Canonical node arrays equal (floats by value so that -0 == +0)."""
+    return (np.array_equal(a["left"], b["left"]) and np.array_equal(a["right"], b["right"])
+            and np.array_equal(a["bmin"], b["bmin"]) and np.array_equal(a["bmax"], b["bmax"]))
+
+
+def cam_array(cam, aspect):
+    return np.array([*cam["eye"], *cam["at"], *cam["up"], cam["fov"], aspect], np.float32)
