@@ -25,11 +25,17 @@ class RtError(RuntimeError):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays_primary", "rays_secondary", "rays_shadow", "primary_hits", "secondary_hits")] + \
                [(n, C.c_float) for n in ("ms_primary", "ms_shade0", "ms_trace_secondary", "ms_trace_shadow0", "ms_shade1",
-                                          "ms_trace_shadow1", "ms_resolve", "ms_total")]
+                                          "ms_trace_shadow1", "ms_resolve", "ms_total")] + [("frames", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
+
+class StageWork(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("nodes", C.c_uint64), ("tris", C.c_uint64)]
+
+
+STAGES = ("primary", "secondary", "shadow0", "shadow1")
 
 # name -> (restype, argtypes); every symbol include/dxr_amd.h declares
 _p, _u32, _i, _f, _sz = C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_size_t
@@ -86,6 +92,9 @@ SIGNATURES = {
     "rt_pipeline_get_stats": (_i, [_p, C.POINTER(Stats)]),
     "rt_pipeline_enable_timing": (_i, [_p, _i]),
     "rt_pipeline_read_primary_hits": (_i, [_p, _p, _p, _p]),
+    "rt_pipeline_get_totals": (_i, [_p, C.POINTER(Stats)]),
+    "rt_pipeline_reset_totals": (_i, [_p]),
+    "rt_pipeline_count_work": (_i, [_p, C.POINTER(StageWork)]),
     "rt_camera_look": (_i, [_p, _p, _p, _p, _p]),
     "rt_camera_basis": (_i, [_p, _p, _f, _f, _p, _p, _p]),
     "rt_progressive_host_create": (_i, [_u32, _pp]),
@@ -389,8 +398,23 @@ class Pipeline:
         _check(lib().rt_pipeline_read_output(self.h, _ptr(out), out.nbytes))
         return out
 
-    def enable_timing(self, on=True):
-        _check(lib().rt_pipeline_enable_timing(self.h, int(on)))
+    def enable_timing(self, frames=1):
+        """Record HIP events around every stage kernel, remembering the last `frames` frames (0 = off)."""
+        _check(lib().rt_pipeline_enable_timing(self.h, int(frames)))
+
+    def totals(self):
+        s = Stats()
+        _check(lib().rt_pipeline_get_totals(self.h, C.byref(s)))
+        return s.as_dict()
+
+    def reset_totals(self):
+        _check(lib().rt_pipeline_reset_totals(self.h))
+
+    def count_work(self):
+        """Canonical-traversal work of the last frame per stage: {stage: dict(rays, nodes, tris)}."""
+        w = (StageWork * len(STAGES))()
+        _check(lib().rt_pipeline_count_work(self.h, w))
+        return {n: dict(rays=int(w[i].rays), nodes=int(w[i].nodes), tris=int(w[i].tris)) for i, n in enumerate(STAGES)}
 
     def stats(self):
         s = Stats()

@@ -139,7 +139,20 @@ int rt_context_create_on_stream(int device, void *hip_stream, rt_context **out)
 
 int rt_context_destroy(rt_context *ctx)
 {
-    if (!ctx) return RT_OK;
+    rt_context_release(ctx);
+    return RT_OK;
+}
+
+}  // extern "C"
+
+void rt_context_retain(rt_context *ctx) { if (ctx) ctx->refs++; }
+
+void rt_scene_retain(rt_scene *s) { if (s) s->refs++; }
+
+// The context lives until its handle AND every object created on it are gone.
+void rt_context_release(rt_context *ctx)
+{
+    if (!ctx || --ctx->refs > 0) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf &b : ctx->scratch) b.release();
@@ -147,8 +160,9 @@ int rt_context_destroy(rt_context *ctx)
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
-    return RT_OK;
 }
+
+extern "C" {
 
 int rt_context_synchronize(rt_context *ctx)
 {
@@ -177,11 +191,13 @@ int rt_context_get_device(rt_context *ctx, int *device_out)
 static int model_finish(rt_context *ctx, rt_model *m, rt_model **out)
 {
     m->ctx = ctx;
+    rt_context_retain(ctx);
     m->n_verts = (uint32_t)m->h_verts.size();
     m->n_tris = (uint32_t)(m->h_idx.size() / 3);
     for (uint32_t i : m->h_idx)
         if (i >= m->n_verts) {
             rt_set_error("index %u out of range (%u vertices)", i, m->n_verts);
+            rt_context_release(ctx);
             delete m;
             return RT_ERR_INVALID_ARG;
         }
@@ -191,6 +207,7 @@ static int model_finish(rt_context *ctx, rt_model *m, rt_model **out)
     if (rc == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { rt_set_error("geometry upload failed"); rc = RT_ERR_HIP; }
     if (rc != RT_OK) {
         m->d_verts.release(); m->d_idx.release();
+        rt_context_release(ctx);
         delete m;
         return rc;
     }
@@ -249,7 +266,9 @@ int rt_model_destroy(rt_model *m)
     if (--m->refs > 0) return RT_OK;
     (void)hipSetDevice(m->ctx->device);
     m->d_verts.release(); m->d_idx.release(); m->tris.release(); m->blas.release();
+    rt_context *ctx = m->ctx;
     delete m;
+    rt_context_release(ctx);
     return RT_OK;
 }
 
@@ -261,6 +280,7 @@ int rt_scene_create(rt_context *ctx, rt_scene **out)
     rt_scene *s = new (std::nothrow) rt_scene();
     if (!s) { rt_set_error("out of host memory"); return RT_ERR_OOM; }
     s->ctx = ctx;
+    rt_context_retain(ctx);
     *out = s;
     return RT_OK;
 }
@@ -314,11 +334,14 @@ int rt_scene_build(rt_scene *s, uint32_t hit_group_count)
 int rt_scene_destroy(rt_scene *s)
 {
     if (!s) return RT_OK;
+    if (--s->refs > 0) return RT_OK;
     (void)hipSetDevice(s->ctx->device);
     for (SceneInstance &in : s->inst) rt_model_destroy(in.model);
     s->d_inst.release();
     s->tlas.release();
+    rt_context *ctx = s->ctx;
     delete s;
+    rt_context_release(ctx);
     return RT_OK;
 }
 

@@ -330,7 +330,7 @@ int lbvh_from_boxes(rt_context *ctx, BvhDev &bv, const Box6 *boxes, uint32_t n, 
     HIP_TRY(hipMemcpyAsync(&bv.max_depth, tmp_depth.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(bv.bounds, d_bounds, 6 * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    bv.fast_depth = bv.max_depth + 1;
+    bv.fast_depth = bv.max_depth;      // at most one pending entry per internal node on the current path
     return RT_OK;
 }
 

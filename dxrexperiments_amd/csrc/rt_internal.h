@@ -106,6 +106,7 @@ struct SceneDev {
 // ---- host objects --------------------------------------------------------------
 
 struct rt_context {
+    int refs = 1;                // handle + every model / scene / pipeline created on it
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -148,6 +149,7 @@ struct SceneInstance {
 
 struct rt_scene {
     rt_context *ctx = nullptr;
+    int refs = 1;                // handle + every pipeline it is set on
     std::vector<SceneInstance> inst;
     std::vector<InstanceRec> h_inst;
     DevBuf d_inst;
@@ -180,6 +182,11 @@ struct TraceOut {
 };
 int rt_launch_trace(rt_context *ctx, const rt_scene *s, const float4 *origin_tmin, const float4 *dir_tmax, size_t n,
                     uint32_t ray_flags, uint32_t kernel, const TraceOut &out);
+
+// rt_api.hip
+void rt_context_retain(rt_context *ctx);
+void rt_context_release(rt_context *ctx);
+void rt_scene_retain(rt_scene *s);
 
 // rt_obj.cpp
 int rt_obj_parse(const char *path, std::vector<rt_vertex> &verts, std::vector<uint32_t> &idx);

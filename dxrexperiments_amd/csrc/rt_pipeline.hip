@@ -368,7 +368,7 @@ RT_DEV void wave_add(uint32_t v, uint32_t *counter)
 template <int STACK>
 __global__ void __launch_bounds__(PBLOCK) k_primary(PipeDev pd)
 {
-    __shared__ int smem[STACK * PBLOCK];
+    __shared__ int smem[StackShape<STACK>::LDSN * PBLOCK];
     const uint32_t q = blockIdx.x * PBLOCK + threadIdx.x;
     if (q >= pd.cap) return;
     const uint32_t px = pd.x0 + q % pd.tw, py = pd.y0 + q / pd.tw;
@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(PBLOCK)
 k_trace_shadow(SceneDev sc, const float4 *__restrict__ O, const float4 *__restrict__ D, const uint32_t *__restrict__ count,
                uint32_t stride, uint32_t batches, uint32_t *__restrict__ vis)
 {
-    __shared__ int smem[STACK * PBLOCK];
+    __shared__ int smem[StackShape<STACK>::LDSN * PBLOCK];
     const uint32_t n = *count;
     const uint32_t idx = blockIdx.x * PBLOCK + threadIdx.x;
     const uint32_t per = (n + PBLOCK - 1) / PBLOCK * PBLOCK;      // batches start on block boundaries
@@ -425,7 +425,7 @@ k_trace_shadow(SceneDev sc, const float4 *__restrict__ O, const float4 *__restri
 template <int STACK>
 __global__ void __launch_bounds__(PBLOCK) k_trace_secondary(PipeDev pd)
 {
-    __shared__ int smem[STACK * PBLOCK];
+    __shared__ int smem[StackShape<STACK>::LDSN * PBLOCK];
     const uint32_t n = pd.counters[C_N0];
     const uint32_t idx = blockIdx.x * PBLOCK + threadIdx.x;
     const uint32_t per = (n + PBLOCK - 1) / PBLOCK * PBLOCK;
@@ -491,6 +491,61 @@ __global__ void __launch_bounds__(PBLOCK) k_resolve(PipeDev pd)
     *dst = o;
 }
 
+__global__ void k_add_totals(const uint32_t *__restrict__ counters, unsigned long long *__restrict__ totals, uint32_t cap)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    totals[0] += cap;
+    totals[1] += counters[C_SECONDARY];
+    totals[2] += counters[C_SHADOW];
+    totals[3] += counters[C_N0];
+    totals[4] += counters[C_N1];
+    totals[5] += 1;
+}
+
+RT_DEV void wave_add64(unsigned long long v, unsigned long long *counter)
+{
+    for (int o = 32; o > 0; o >>= 1) v += (unsigned long long)__shfl_xor((long long)v, o, 64);
+    if ((threadIdx.x & 63u) == 0u && v) atomicAdd(counter, v);
+}
+
+// canonical-order re-trace of a queue: sums rays / nodes / triangles into out[0..2]
+__global__ void __launch_bounds__(PBLOCK)
+k_count_queue(SceneDev sc, const float4 *__restrict__ O, const float4 *__restrict__ D, const uint32_t *__restrict__ count,
+              uint32_t stride, uint32_t batches, uint32_t flags, unsigned long long *__restrict__ out)
+{
+    const uint32_t n = *count;
+    const uint32_t idx = blockIdx.x * PBLOCK + threadIdx.x;
+    const uint32_t per = (n + PBLOCK - 1) / PBLOCK * PBLOCK;
+    const uint32_t b = per ? idx / per : batches, k = per ? idx % per : 0;
+    unsigned long long rays = 0, nodes = 0, tris = 0;
+    if (b < batches && k < n) {
+        const RayD r = load_ray(O, D, (size_t)b * stride + k);
+        if (r.tmax > r.tmin) {
+            uint32_t cn, ct;
+            (void)trace_canonical(sc, r, flags, cn, ct);
+            rays = 1; nodes = cn; tris = ct;
+        }
+    }
+    wave_add64(rays, &out[0]);
+    wave_add64(nodes, &out[1]);
+    wave_add64(tris, &out[2]);
+}
+
+__global__ void __launch_bounds__(PBLOCK) k_count_primary(PipeDev pd, unsigned long long *__restrict__ out)
+{
+    const uint32_t q = blockIdx.x * PBLOCK + threadIdx.x;
+    unsigned long long rays = 0, nodes = 0, tris = 0;
+    if (q < pd.cap) {
+        const RayD r = primary_ray(pd, pd.x0 + q % pd.tw, pd.y0 + q / pd.tw);
+        uint32_t cn, ct;
+        (void)trace_canonical(pd.sc, r, RT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES, cn, ct);
+        rays = 1; nodes = cn; tris = ct;
+    }
+    wave_add64(rays, &out[0]);
+    wave_add64(nodes, &out[1]);
+    wave_add64(tris, &out[2]);
+}
+
 __global__ void k_f32_to_f16(const float4 *__restrict__ in, ushort4 *__restrict__ out, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -537,9 +592,12 @@ struct rt_pipeline {
     uint32_t cap = 0, sh0_batches = 0;
     DevBuf hit0, inst0, pix_k, klist, counters, secO, secD, hit1, inst1, slot_j, jlist, sh0O, sh0D, vis0, sh1O, sh1D, vis1;
     DevBuf half_out;
-    bool timing = false;
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool ev_valid = false;
+    std::vector<hipEvent_t> ring;      // 8 events per remembered frame
+    int ring_frames = 0;               // 0 = timing off
+    uint64_t ring_pos = 0;             // frames recorded since enable / reset
+    DevBuf totals, work;
+    PipeDev last_pd;
+    uint32_t last_shadow_slots = 2;
     rt_stats stats;
     uint32_t last_tile[4] = {0, 0, 0, 0};
     bool rendered = false;
@@ -569,26 +627,28 @@ template <int STACK>
 void launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
 {
     hipStream_t st = p->ctx->stream;
-    const bool T = p->timing;
+    const bool T = p->ring_frames > 0;
+    hipEvent_t *ev = T ? &p->ring[(size_t)(p->ring_pos % (uint64_t)p->ring_frames) * 8] : nullptr;
     const uint32_t cap = pd.cap;
-    if (T) (void)hipEventRecord(p->ev[0], st);
+    if (T) (void)hipEventRecord(ev[0], st);
     k_primary<STACK><<<blocks(cap), PBLOCK, 0, st>>>(pd);
-    if (T) (void)hipEventRecord(p->ev[1], st);
+    if (T) (void)hipEventRecord(ev[1], st);
     k_shade0_emit<<<blocks(cap), PBLOCK, 0, st>>>(pd, shadow_slots);
-    if (T) (void)hipEventRecord(p->ev[2], st);
+    if (T) (void)hipEventRecord(ev[2], st);
     // one extra block per batch covers the block-boundary padding of each batch
     k_trace_secondary<STACK><<<blocks(cap) * 2 + 2, PBLOCK, 0, st>>>(pd);
-    if (T) (void)hipEventRecord(p->ev[3], st);
+    if (T) (void)hipEventRecord(ev[3], st);
     k_trace_shadow<STACK><<<(blocks(cap) + 1) * shadow_slots, PBLOCK, 0, st>>>(pd.sc, pd.sh0O, pd.sh0D, &pd.counters[C_N0], cap,
                                                                                shadow_slots, pd.vis0);
-    if (T) (void)hipEventRecord(p->ev[4], st);
+    if (T) (void)hipEventRecord(ev[4], st);
     k_shade1_emit<<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd);
-    if (T) (void)hipEventRecord(p->ev[5], st);
+    if (T) (void)hipEventRecord(ev[5], st);
     k_trace_shadow<STACK><<<(blocks((size_t)cap * 2) + 1) * 2, PBLOCK, 0, st>>>(pd.sc, pd.sh1O, pd.sh1D, &pd.counters[C_N1], 2 * cap, 2,
                                                                                 pd.vis1);
-    if (T) (void)hipEventRecord(p->ev[6], st);
+    if (T) (void)hipEventRecord(ev[6], st);
     k_resolve<<<blocks(cap), PBLOCK, 0, st>>>(pd);
-    if (T) (void)hipEventRecord(p->ev[7], st);
+    if (T) { (void)hipEventRecord(ev[7], st); p->ring_pos++; }
+    k_add_totals<<<1, 64, 0, st>>>(pd.counters, p->totals.as<unsigned long long>(), cap);
 }
 
 }  // namespace
@@ -602,6 +662,7 @@ int rt_pipeline_create(rt_context *ctx, uint32_t kind, rt_pipeline **out)
     rt_pipeline *p = new (std::nothrow) rt_pipeline();
     if (!p) { rt_set_error("out of host memory"); return RT_ERR_OOM; }
     p->ctx = ctx;
+    rt_context_retain(ctx);
     memset(&p->pfc, 0, sizeof p->pfc);
     memset(&p->stats, 0, sizeof p->stats);
     *out = p;
@@ -614,10 +675,14 @@ int rt_pipeline_destroy(rt_pipeline *p)
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     DevBuf *all[] = {&p->d_mats, &p->d_env, &p->accum_own, &p->hit0, &p->inst0, &p->pix_k, &p->klist, &p->counters, &p->secO, &p->secD,
-                     &p->hit1, &p->inst1, &p->slot_j, &p->jlist, &p->sh0O, &p->sh0D, &p->vis0, &p->sh1O, &p->sh1D, &p->vis1, &p->half_out};
+                     &p->hit1, &p->inst1, &p->slot_j, &p->jlist, &p->sh0O, &p->sh0D, &p->vis0, &p->sh1O, &p->sh1D, &p->vis1, &p->half_out,
+                     &p->totals, &p->work};
     for (DevBuf *b : all) b->release();
-    for (hipEvent_t e : p->ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->ring) if (e) (void)hipEventDestroy(e);
+    if (p->scene) rt_scene_destroy(p->scene);
+    rt_context *ctx = p->ctx;
     delete p;
+    rt_context_release(ctx);
     return RT_OK;
 }
 
@@ -627,6 +692,8 @@ int rt_pipeline_set_scene(rt_pipeline *p, rt_scene *s)
 {
     RT_REQUIRE(p && s, "null argument");
     RT_REQUIRE(s->ctx == p->ctx, "scene belongs to a different context");
+    rt_scene_retain(s);
+    if (p->scene) rt_scene_destroy(p->scene);
     p->scene = s;
     return RT_OK;
 }
@@ -771,9 +838,9 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
     const uint32_t tw = x1 - x0, th = y1 - y0, cap = tw * th;
     const uint32_t shadow_slots = p->pfc.options.showAmbientOcclusionOnly ? 4u : 2u;
     RT_TRY(ensure_queues(p, cap, shadow_slots));
-    if (p->timing && !p->ev_valid) {
-        for (hipEvent_t &e : p->ev) HIP_TRY(hipEventCreate(&e));
-        p->ev_valid = true;
+    if (!p->totals.p) {
+        RT_TRY(p->totals.reserve(8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(p->totals.p, 0, 8 * sizeof(unsigned long long), st));
     }
     PipeDev pd;
     pd.sc = p->scene->dev();
@@ -800,9 +867,11 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
     const uint32_t need = p->scene->stack_need;
     if (need <= 32) launch_frame<32>(p, pd, shadow_slots);
     else if (need <= 64) launch_frame<64>(p, pd, shadow_slots);
-    else if (need <= 150) launch_frame<150>(p, pd, shadow_slots);
-    else { rt_set_error("traversal stack need %u exceeds 150 entries", need); return RT_ERR_UNSUPPORTED; }
+    else if (need <= 160) launch_frame<160>(p, pd, shadow_slots);
+    else { rt_set_error("traversal stack need %u exceeds 160 entries", need); return RT_ERR_UNSUPPORTED; }
     HIP_TRY(hipGetLastError());
+    p->last_pd = pd;
+    p->last_shadow_slots = shadow_slots;
     p->last_tile[0] = x0; p->last_tile[1] = y0; p->last_tile[2] = x1; p->last_tile[3] = y1;
     p->rendered = true;
     return RT_OK;
@@ -848,11 +917,32 @@ int rt_pipeline_read_output(rt_pipeline *p, void *host, size_t bytes)
     return RT_OK;
 }
 
-int rt_pipeline_enable_timing(rt_pipeline *p, int enable)
+int rt_pipeline_enable_timing(rt_pipeline *p, int frames)
 {
     RT_REQUIRE(p, "null pipeline");
-    p->timing = enable != 0;
+    RT_REQUIRE(frames >= 0 && frames <= 4096, "timing ring holds 0..4096 frames");
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    for (hipEvent_t e : p->ring) if (e) (void)hipEventDestroy(e);
+    p->ring.assign((size_t)frames * 8, nullptr);
+    for (hipEvent_t &e : p->ring) HIP_TRY(hipEventCreate(&e));
+    p->ring_frames = frames;
+    p->ring_pos = 0;
     return RT_OK;
+}
+
+static int stage_times(rt_pipeline *p, uint64_t frame, float ms[8])
+{
+    hipEvent_t *ev = &p->ring[(size_t)(frame % (uint64_t)p->ring_frames) * 8];
+    for (int k = 0; k < 7; k++) HIP_TRY(hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]));
+    HIP_TRY(hipEventElapsedTime(&ms[7], ev[0], ev[7]));
+    return RT_OK;
+}
+
+static void add_times(rt_stats *out, const float ms[8])
+{
+    out->ms_primary += ms[0]; out->ms_shade0 += ms[1]; out->ms_trace_secondary += ms[2]; out->ms_trace_shadow0 += ms[3];
+    out->ms_shade1 += ms[4]; out->ms_trace_shadow1 += ms[5]; out->ms_resolve += ms[6]; out->ms_total += ms[7];
 }
 
 int rt_pipeline_get_stats(rt_pipeline *p, rt_stats *out)
@@ -869,13 +959,74 @@ int rt_pipeline_get_stats(rt_pipeline *p, rt_stats *out)
     out->secondary_hits = c[C_N1];
     out->rays_secondary = c[C_SECONDARY];
     out->rays_shadow = c[C_SHADOW];
-    if (p->timing && p->ev_valid) {
-        float *ms[7] = {&out->ms_primary, &out->ms_shade0, &out->ms_trace_secondary, &out->ms_trace_shadow0,
-                        &out->ms_shade1, &out->ms_trace_shadow1, &out->ms_resolve};
-        for (int k = 0; k < 7; k++) HIP_TRY(hipEventElapsedTime(ms[k], p->ev[k], p->ev[k + 1]));
-        HIP_TRY(hipEventElapsedTime(&out->ms_total, p->ev[0], p->ev[7]));
+    out->frames = 1;
+    if (p->ring_frames > 0 && p->ring_pos > 0) {
+        float ms[8];
+        RT_TRY(stage_times(p, p->ring_pos - 1, ms));
+        add_times(out, ms);
     }
     p->stats = *out;
+    return RT_OK;
+}
+
+int rt_pipeline_get_totals(rt_pipeline *p, rt_stats *out)
+{
+    RT_REQUIRE(p && out, "null argument");
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    memset(out, 0, sizeof *out);
+    if (!p->totals.p) return RT_OK;
+    unsigned long long t[8];
+    HIP_TRY(hipMemcpy(t, p->totals.p, sizeof t, hipMemcpyDeviceToHost));
+    out->rays_primary = t[0]; out->rays_secondary = t[1]; out->rays_shadow = t[2];
+    out->primary_hits = t[3]; out->secondary_hits = t[4];
+    out->frames = t[5];
+    if (p->ring_frames > 0) {
+        const uint64_t have = p->ring_pos < (uint64_t)p->ring_frames ? p->ring_pos : (uint64_t)p->ring_frames;
+        for (uint64_t f = p->ring_pos - have; f < p->ring_pos; f++) {
+            float ms[8];
+            RT_TRY(stage_times(p, f, ms));
+            add_times(out, ms);
+        }
+        if (have < out->frames) out->frames = have;      // times cover only the remembered frames
+    }
+    return RT_OK;
+}
+
+int rt_pipeline_reset_totals(rt_pipeline *p)
+{
+    RT_REQUIRE(p, "null pipeline");
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    if (p->totals.p) HIP_TRY(hipMemsetAsync(p->totals.p, 0, 8 * sizeof(unsigned long long), p->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    p->ring_pos = 0;
+    return RT_OK;
+}
+
+int rt_pipeline_count_work(rt_pipeline *p, rt_stage_work *out)
+{
+    RT_REQUIRE(p && out, "null argument");
+    if (!p->rendered) { rt_set_error("count_work: nothing rendered yet"); return RT_ERR_STATE; }
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    RT_TRY(p->work.reserve(RT_STAGE_COUNT * 3 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(p->work.p, 0, RT_STAGE_COUNT * 3 * sizeof(unsigned long long), st));
+    unsigned long long *w = p->work.as<unsigned long long>();
+    const PipeDev &pd = p->last_pd;
+    const uint32_t cap = pd.cap, ss = p->last_shadow_slots;
+    const uint32_t any = RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH | RT_RAY_FLAG_SKIP_CLOSEST_HIT_SHADER;
+    k_count_primary<<<blocks(cap), PBLOCK, 0, st>>>(pd, w + 3 * RT_STAGE_PRIMARY);
+    k_count_queue<<<blocks(cap) * 2 + 2, PBLOCK, 0, st>>>(pd.sc, pd.secO, pd.secD, &pd.counters[C_N0], cap, 2, RT_RAY_FLAG_NONE,
+                                                          w + 3 * RT_STAGE_SECONDARY);
+    k_count_queue<<<(blocks(cap) + 1) * ss, PBLOCK, 0, st>>>(pd.sc, pd.sh0O, pd.sh0D, &pd.counters[C_N0], cap, ss, any,
+                                                             w + 3 * RT_STAGE_SHADOW0);
+    k_count_queue<<<(blocks((size_t)cap * 2) + 1) * 2, PBLOCK, 0, st>>>(pd.sc, pd.sh1O, pd.sh1D, &pd.counters[C_N1], 2 * cap, 2, any,
+                                                                        w + 3 * RT_STAGE_SHADOW1);
+    HIP_TRY(hipGetLastError());
+    unsigned long long h[RT_STAGE_COUNT * 3];
+    HIP_TRY(hipMemcpyAsync(h, w, sizeof h, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int k = 0; k < RT_STAGE_COUNT; k++) { out[k].rays = h[3 * k]; out[k].nodes = h[3 * k + 1]; out[k].tris = h[3 * k + 2]; }
     return RT_OK;
 }
 

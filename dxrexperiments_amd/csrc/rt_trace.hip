@@ -43,7 +43,7 @@ template <int STACK>
 __global__ void __launch_bounds__(TRACE_BLOCK)
 k_trace_fast(SceneDev sc, const float4 *__restrict__ o, const float4 *__restrict__ d, size_t n, uint32_t flags, TraceOut out)
 {
-    __shared__ int smem[STACK * TRACE_BLOCK];
+    __shared__ int smem[StackShape<STACK>::LDSN * TRACE_BLOCK];
     const size_t i = (size_t)blockIdx.x * TRACE_BLOCK + threadIdx.x;
     if (i >= n) return;
     const RayD r = load_ray(o, d, i);
@@ -67,9 +67,9 @@ int rt_launch_trace(rt_context *ctx, const rt_scene *s, const float4 *o, const f
         const uint32_t need = s->stack_need;
         if (need <= 32) k_trace_fast<32><<<grid, TRACE_BLOCK, 0, st>>>(sc, o, d, n, ray_flags, out);
         else if (need <= 64) k_trace_fast<64><<<grid, TRACE_BLOCK, 0, st>>>(sc, o, d, n, ray_flags, out);
-        else if (need <= 150) k_trace_fast<150><<<grid, TRACE_BLOCK, 0, st>>>(sc, o, d, n, ray_flags, out);
+        else if (need <= 160) k_trace_fast<160><<<grid, TRACE_BLOCK, 0, st>>>(sc, o, d, n, ray_flags, out);
         else {
-            rt_set_error("traversal stack need %u exceeds 150 entries", need);
+            rt_set_error("traversal stack need %u exceeds 160 entries", need);
             return RT_ERR_UNSUPPORTED;
         }
     }

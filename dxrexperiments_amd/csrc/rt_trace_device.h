@@ -256,13 +256,41 @@ RT_DEV HitD trace_canonical(const SceneDev &sc, const RayD &r, uint32_t flags, u
 #define RT_STACK_SENTINEL 0x7FFFFFFF   // pops back out of a BLAS
 #define RT_STACK_EMPTY    0x7FFFFFFE
 
+// Traversal stack of STACK entries per lane: the first RT_LDS_STACK levels live in LDS
+// (smem[level][lane]: one dword per lane per level, conflict free), deeper levels --
+// rarely reached: a level is only used while BOTH children of that many ancestors were
+// hit -- spill to a per-lane private array.  Keeping the LDS part short is what lets
+// 5+ waves per SIMD stay resident (16 levels x 256 lanes x 4 B = 16 KiB per block).
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK 16
+#endif
+
+template <int STACK>
+struct StackShape {
+    static constexpr int LDSN = STACK < RT_LDS_STACK ? STACK : RT_LDS_STACK;
+    static constexpr int SPILL = STACK - LDSN;
+};
+
 template <int STACK, int BLOCK>
 struct LdsStack {
+    static constexpr int LDSN = StackShape<STACK>::LDSN;
+    static constexpr int SPILL = StackShape<STACK>::SPILL;
     int *base;      // &smem[threadIdx.x]
     int sp;
+    int spill[SPILL > 0 ? SPILL : 1];
     RT_DEV void init(int *smem) { base = smem + threadIdx.x; sp = 0; }
-    RT_DEV void push(int v) { base[sp * BLOCK] = v; sp++; }
-    RT_DEV int pop() { sp--; return base[sp * BLOCK]; }
+    RT_DEV void push(int v)
+    {
+        if (SPILL == 0 || sp < LDSN) base[sp * BLOCK] = v;
+        else spill[sp - LDSN] = v;
+        sp++;
+    }
+    RT_DEV int pop()
+    {
+        sp--;
+        if (SPILL == 0 || sp < LDSN) return base[sp * BLOCK];
+        return spill[sp - LDSN];
+    }
 };
 
 template <int STACK, int BLOCK>

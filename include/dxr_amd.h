@@ -150,9 +150,19 @@ int rt_pipeline_get_num_outputs(const rt_pipeline *p, int *n);               /* 
 int rt_pipeline_get_output_device_ptr(rt_pipeline *p, uint32_t id, void **ptr); /* getOutputResource .h:35 */
 /* synchronises; host buffer is w*h*4 floats (RGBA32F) or halfs (RGBA16F) */
 int rt_pipeline_read_output(rt_pipeline *p, void *host, size_t bytes);
-/* synchronises; timings need rt_pipeline_enable_timing(p, 1) */
+/* synchronises; stage timings need rt_pipeline_enable_timing(p, frames > 0): HIP events
+ * are recorded around every stage kernel on the context stream, in a ring that
+ * remembers the last `frames` frames */
 int rt_pipeline_get_stats(rt_pipeline *p, rt_stats *out);
-int rt_pipeline_enable_timing(rt_pipeline *p, int enable);
+int rt_pipeline_enable_timing(rt_pipeline *p, int frames);
+/* sums over every frame since rt_pipeline_reset_totals (ray counts exact; stage times
+ * summed over the frames still in the timing ring, out->frames says how many) */
+int rt_pipeline_get_totals(rt_pipeline *p, rt_stats *out);
+int rt_pipeline_reset_totals(rt_pipeline *p);
+/* Re-traces the ray queues of the LAST rendered frame with the canonical traversal and
+ * returns its node / triangle counters per stage: out[RT_STAGE_COUNT].  These are the
+ * ALGORITHMIC-bytes inputs of the roofline (32 B per node, 36 B per triangle, 48 B per ray). */
+int rt_pipeline_count_work(rt_pipeline *p, rt_stage_work *out);
 /* per-pixel primary-hit records of the last render (tests): w*h each, may be NULL */
 int rt_pipeline_read_primary_hits(rt_pipeline *p, float *t, uint32_t *prim, uint32_t *inst);
 

@@ -117,7 +117,8 @@ typedef struct rt_bvh_node {
 #define RT_ACCUM_RUNNING_MEAN 0u  /* (n*prev+cur)/(n+1), ProgressiveRaytracing.hlsl:36-38 */
 #define RT_ACCUM_SUM          1u  /* prev+cur; caller divides by count (multi-GPU shards) */
 
-/* Per-render statistics (all counts are for the most recent render call). */
+/* Render statistics: rt_pipeline_get_stats = the most recent render call (frames = 1);
+ * rt_pipeline_get_totals = sums since rt_pipeline_reset_totals. */
 typedef struct rt_stats {
     uint64_t rays_primary;
     uint64_t rays_secondary;     /* closest-hit radiance rays beyond primary */
@@ -132,7 +133,21 @@ typedef struct rt_stats {
     float    ms_trace_shadow1;   /* shadow traversal for second hits      */
     float    ms_resolve;         /* final shade + accumulate              */
     float    ms_total;
+    uint64_t frames;             /* frames the counts / times above cover  */
 } rt_stats;
+
+/* Algorithmic work of one traversal stage of the last rendered frame, counted by
+ * the canonical (reference-order) traversal: see SURVEY.md 8(d), DESIGN.md. */
+typedef struct rt_stage_work {
+    uint64_t rays;               /* rays actually traced in the stage        */
+    uint64_t nodes;              /* AABBs slab-tested by the canonical loop  */
+    uint64_t tris;               /* triangles handed to the triangle test    */
+} rt_stage_work;
+#define RT_STAGE_PRIMARY   0
+#define RT_STAGE_SECONDARY 1
+#define RT_STAGE_SHADOW0   2
+#define RT_STAGE_SHADOW1   3
+#define RT_STAGE_COUNT     4
 
 /* Status codes returned by every export. */
 #define RT_OK                 0

@@ -67,8 +67,8 @@ def test_cornell_golden_frames(gpu, capi):
         if f == 0:
             t, prim, inst = p.primary_hits(64 * 64)
             assert np.array_equal(prim, g["prim"]) and np.array_equal(inst, g["inst"]) and np.array_equal(t, g["t"])
-    st = p.stats()
-    assert st["rays_primary"] == 64 * 64 and st["primary_hits"] == int((g["inst"] != T.RT_NO_HIT).sum())
+            st = p.stats()
+            assert st["rays_primary"] == 64 * 64 and st["primary_hits"] == int((g["inst"] != T.RT_NO_HIT).sum())
 
 
 OPTION_CASES = [
