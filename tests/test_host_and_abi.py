@@ -1,0 +1,177 @@
+"""CPU-only: the C-ABI library loads and exports every declared symbol; host-side frame
+logic (camera basis, update()) matches the oracle and the committed fixture; the product
+package never touches the oracle; multi-GPU host logic over gloo (world_size 2)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from dxrexperiments_amd import rtypes as T, scenes
+from util import GOLDEN, cam_array
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dxr_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(capi):
+    names = declared_symbols()
+    assert len(names) > 50
+    lib = capi.lib()
+    for n in names:
+        assert hasattr(lib, n), "libdxrexperiments_amd.so does not export %s" % n
+        assert n in capi.SIGNATURES, "capi.py has no signature for %s" % n
+    assert set(capi.SIGNATURES) == set(names)
+    assert b"gfx950" in lib.rt_version()
+
+
+def test_no_gpu_means_loud_failure_not_fallback(capi):
+    """On a machine without a HIP device the product must refuse to work."""
+    try:
+        n = capi.device_count()
+    except capi.RtError:
+        n = 0
+    if n == 0:
+        with pytest.raises(capi.RtError):
+            capi.Context(0)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "dxrexperiments_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "pyoracle" not in text and "liboracle" not in text and "oracle/" not in text.replace("the oracle/", ""), f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench.count("from oracle import") == 1 and "def cpu_baseline" in bench     # only inside the cpu_baseline leg
+
+
+def test_record_layouts(capi):
+    assert T.PER_FRAME_CONSTANTS.itemsize == 188 and T.MATERIAL_PARAMS.itemsize == 64 and T.VERTEX.itemsize == 24
+    assert T.PER_FRAME_CONSTANTS.fields["options"][1] == 144 and T.DEBUG_OPTIONS.fields["environmentStrength"][1] == 36
+    import ctypes
+    assert ctypes.sizeof(capi.Stats) == 5 * 8 + 8 * 4 + 8
+
+
+def test_camera_basis_matches_oracle_and_definition(capi, oracle):
+    for cam, aspect in ((scenes.cornell_camera(), 1.0), (scenes.sponza_camera(), 1920 / 1080),
+                        (dict(eye=(8, 10, 30), at=(0, 1.5, 0), up=(0, 1, 0), fov=float(np.float32(np.pi / 4))), 1920 / 1080)):
+        f, u = capi.camera_look(cam["eye"], cam["at"], cam["up"])
+        of, ou = oracle.camera_look(cam["eye"], cam["at"], cam["up"])
+        assert np.array_equal(f, of) and np.array_equal(u, ou)
+        U, V, W = capi.camera_basis(f, u, cam["fov"], aspect)
+        oU, oV, oW = oracle.camera_basis(f, u, cam["fov"], aspect)
+        assert np.array_equal(U, oU) and np.array_equal(V, oV) and np.array_equal(W, oW)
+        # calculateCameraVariables: |V| = |W| tan(fov/2), |U| = |V| aspect, mutually orthogonal, .w = 0
+        assert abs(np.linalg.norm(V[:3]) - np.tan(0.5 * cam["fov"])) < 1e-6
+        assert abs(np.linalg.norm(U[:3]) - np.linalg.norm(V[:3]) * aspect) < 1e-6
+        assert abs(U[:3] @ V[:3]) < 1e-6 and abs(U[:3] @ W[:3]) < 1e-6 and U[3] == V[3] == W[3] == 0
+
+
+def test_progressive_update_matches_oracle_and_fixture(capi, oracle):
+    g = np.load(os.path.join(GOLDEN, "host_update_golden.npz"))
+    host = capi.ProgressiveHost(int(g["seed"]))
+    oh = oracle.Progressive(int(g["seed"]))
+    acc = []
+    for i, cam in enumerate(g["cams"]):
+        pfc = host.update(cam, 0.5 * i, 10 + i, 1920, 1080)
+        want = oh.update(cam, 0.5 * i, 10 + i, 1920, 1080)
+        assert pfc.tobytes() == want.tobytes() == g["pfc"][i].tobytes()
+        acc.append(int(pfc["cameraParams"]["accumCount"]))
+        assert int(pfc["cameraParams"]["frameCount"]) == 10 + i
+    assert acc == [0, 1, 2, 0, 1, 0]                 # restarts whenever the camera changed (.cpp:183-186)
+    p0 = np.frombuffer(g["pfc"][0].tobytes(), T.PER_FRAME_CONSTANTS)[0]
+    # paused animation: t = 142 s -> rotY(sin(28.4) * 3.14 / 2) of (0.3, -0.2, -1) (.cpp:179-181,197-201)
+    a = np.sin(np.float32(142.0) * np.float32(0.2)) * 3.14 * 0.5
+    want = np.array([0.3 * np.cos(a) - np.sin(a), -0.2, -0.3 * np.sin(a) - np.cos(a)])
+    assert np.allclose(p0["directionalLight"]["forwardDir"][:3], want, atol=1e-6)
+    assert p0["options"]["maxIterations"] == 1024 and p0["options"]["cosineHemisphereSampling"] == 1
+    assert abs(p0["cameraParams"]["jitters"][0]) <= 0.5 / 1920 and abs(p0["cameraParams"]["jitters"][1]) <= 0.5 / 1080
+    assert p0["pointLight"]["color"].tolist() == pytest.approx([0.2, 0.8, 0.6, 2.0])
+
+
+def test_progressive_flags_and_reset(capi):
+    host = capi.ProgressiveHost(5)
+    cam = cam_array(scenes.cornell_camera(), 1.0)
+    a = [int(host.update(cam, 0.0, i, 64, 64)["cameraParams"]["accumCount"]) for i in range(3)]
+    host.reset()
+    b = int(host.update(cam, 0.0, 3, 64, 64)["cameraParams"]["accumCount"])
+    host.set_flags(accumulation_enabled=False)
+    c = [int(host.update(cam, 0.0, i, 64, 64)["cameraParams"]["accumCount"]) for i in range(2)]
+    assert a == [0, 1, 2] and b == 0 and c == [0, 0]
+    host.set_flags(animation_paused=False)
+    d0 = host.update(cam, 1.0, 1, 64, 64)["directionalLight"]["forwardDir"].copy()
+    d1 = host.update(cam, 2.0, 1, 64, 64)["directionalLight"]["forwardDir"].copy()
+    assert not np.array_equal(d0, d1)
+
+
+def test_scene_generators_are_deterministic():
+    v1, t1 = scenes.sponza_class(detail=0.25)
+    v2, t2 = scenes.sponza_class(detail=0.25)
+    assert np.array_equal(v1, v2) and np.array_equal(t1, t2)
+    assert t1.max() < v1.shape[0]
+    x = scenes.instance_grid(4)
+    assert x.shape == (16, 12) and np.isfinite(x).all()
+    f = scenes.sky_cubemap(8)
+    assert f.shape == (6, 8, 8, 4) and (f[..., :3] >= 0).all()
+
+
+GLOO_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from dxrexperiments_amd import distributed as D, rtypes as T
+from oracle import pyoracle as O          # stand-in renderer for the CPU test (test infrastructure)
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+g = np.load(os.path.join(sys.argv[1], "tests", "golden", "cornell64_golden.npz"))
+v, i = O.obj_load(os.path.join(sys.argv[1], "tests", "golden", "cornell.obj"))
+sc = O.Scene(); sc.add_instance(sc.add_model(v, i)); sc.build()
+N = 4
+mine = D.shard_frames(rank, world, N)
+acc = np.zeros((64, 64, 4), np.float32)
+for f in mine:
+    sc.render(T.default_material(), g["pfc"][f], 64, 64, accum=acc, env_constant=(0.5, 0.5, 0.5), accum_mode=T.ACCUM_SUM)
+mean, total = D.reduce_accumulation(torch.from_numpy(acc), len(mine))
+assert total == N, total
+err = float(np.abs(mean.numpy() - g["images"][N - 1]).max())
+rms = float(np.sqrt(np.mean((mean.numpy().astype(np.float64) - g["images"][N - 1]) ** 2)))
+assert rms <= 1e-5 and err <= 1e-5, (rms, err)
+rows = D.tile_rows(rank, world, 64, band=16)
+own = torch.zeros(64, dtype=torch.int32)
+for y0, y1 in rows: own[y0:y1] += 1
+dist.all_reduce(own)
+assert bool((own == 1).all())             # tile partition covers every row exactly once
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok", mine, rms)
+'''
+
+
+def test_sample_sharding_over_gloo_world2(tmp_path, oracle):
+    """N>1 path on CPU: two processes shard the frames, one all-reduce(sum), mean == single-process result."""
+    script = tmp_path / "worker.py"
+    script.write_text(GLOO_WORKER)
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script), ROOT]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert r.stdout.count(" ok ") == 2
+
+
+def test_shard_helpers():
+    from dxrexperiments_amd import distributed as D
+    for world in (1, 2, 3, 8):
+        fr = [D.shard_frames(r, world, 21) for r in range(world)]
+        assert sorted(sum(fr, [])) == list(range(21))
+        assert [len(x) for x in fr] == D.frames_per_rank(world, 21)
+        rows = sum((D.tile_rows(r, world, 1080) for r in range(world)), [])
+        assert sum(b - a for a, b in rows) == 1080
