@@ -7,10 +7,11 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC = dxrexperiments_amd/csrc
 LIBDIR = dxrexperiments_amd/lib
-LIB = $(LIBDIR)/libdxrexperiments_amd.so
+LIBNAME ?= libdxrexperiments_amd.so
+LIB = $(LIBDIR)/$(LIBNAME)
 HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math \
            -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero \
-           -Wall -Wno-unused-function -Iinclude
+           -Wall -Wno-unused-function -Iinclude $(EXTRA)
 SRCS = $(CSRC)/rt_api.hip $(CSRC)/rt_bvh_build.hip $(CSRC)/rt_trace.hip $(CSRC)/rt_pipeline.hip \
        $(CSRC)/rt_obj.cpp $(CSRC)/rt_host.cpp $(CSRC)/rt_dds.cpp
 HDRS = $(wildcard $(CSRC)/*.h) include/dxr_amd.h include/dxr_amd_types.h

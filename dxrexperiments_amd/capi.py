@@ -12,7 +12,8 @@ import numpy as np
 from . import rtypes as T
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdxrexperiments_amd.so")
+# DXR_AMD_LIB selects an alternative build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("DXR_AMD_LIB") or os.path.join(_HERE, "lib", "libdxrexperiments_amd.so")
 _LIB = None
 
 

@@ -121,6 +121,11 @@ static int context_create(int device, void *stream, bool own, rt_context **out)
         delete c;
         return RT_ERR_HIP;
     }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        c->persistent_blocks = (uint32_t)prop.multiProcessorCount * 6u;
+    const char *pb = getenv("RT_PERSISTENT_BLOCKS_PER_CU");
+    if (pb && atoi(pb) >= 1 && atoi(pb) <= 16) c->persistent_blocks = c->persistent_blocks / 6u * (uint32_t)atoi(pb);
     const char *lm = getenv("RT_LEAF_MAX");
     if (lm) {
         int v = atoi(lm);
@@ -156,6 +161,7 @@ void rt_context_release(rt_context *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf &b : ctx->scratch) b.release();
+    ctx->pool.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -461,7 +461,10 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
         k_decode_bounds<<<1, 64, 0, st>>>(enc.as<uint32_t>(), bounds.as<float>());
         if ((rc = lbvh_from_boxes(ctx, s->tlas, boxes.as<Box6>(), n, bounds.as<float>(), true, tkeys, tsort, tenc, tdepth)) != RT_OK) break;
         s->tlas.root_code = (n == 1) ? ~(int)0 : 0;     // single instance: root is the leaf of instance 0
-        s->stack_need = s->tlas.fast_depth + deepest + 2;
+        // one pending entry per internal node on the current path; two-level walks add the
+        // TLAS path and the sentinel that marks the bottom of a BLAS walk
+        s->two_level = !(n == 1 && (s->h_inst[0].flags & RT_INST_IDENTITY));
+        s->stack_need = s->two_level ? s->tlas.fast_depth + 1 + deepest : deepest;
     } while (0);
     boxes.release(); enc.release(); bounds.release(); tkeys.release(); tsort.release(); tenc.release(); tdepth.release();
     return rc;

@@ -113,6 +113,8 @@ struct rt_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_trace_ms = 0.0f;
     uint32_t leaf_max = 4;       // triangles per collapsed leaf in the traversal layout
+    uint32_t persistent_blocks = 256 * 6;   // grid cap of the persistent traversal kernels (CUs x resident blocks)
+    DevBuf pool;                 // ray-pool counters of rt_trace_batch
     DevBuf scratch[8];           // staging for host-pointer batch calls
 };
 
@@ -156,7 +158,8 @@ struct rt_scene {
     BvhDev tlas;
     bool built = false;
     float build_ms = 0.0f;
-    uint32_t stack_need = 0;     // traversal stack entries needed (TLAS + deepest BLAS + sentinel)
+    uint32_t stack_need = 0;     // traversal stack entries a ray can hold at once
+    bool two_level = true;       // false: one identity instance, rays walk its BLAS directly
     SceneDev dev() const
     {
         SceneDev s;

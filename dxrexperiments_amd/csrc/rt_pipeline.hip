@@ -24,7 +24,7 @@
 
 #include <new>
 
-#include "rt_trace_device.h"
+#include "rt_trace_wave.h"
 
 int rt_dds_load_cube(const char *path, std::vector<float> &faces, uint32_t &size);
 
@@ -41,7 +41,8 @@ constexpr int PBLOCK = 256;
 #define HIT_MISS -1.0f
 #define HIT_UNTRACED -2.0f
 
-enum { C_N0 = 0, C_N1 = 1, C_SECONDARY = 2, C_SHADOW = 3, C_COUNT = 4 };
+enum { C_N0 = 0, C_N1 = 1, C_SECONDARY = 2, C_SHADOW = 3, C_POOL_PRIMARY = 4, C_POOL_SECONDARY = 5, C_POOL_SHADOW0 = 6,
+       C_POOL_SHADOW1 = 7, C_COUNT = 8 };
 
 struct PipeDev {
     SceneDev sc;
@@ -52,7 +53,8 @@ struct PipeDev {
     uint32_t env_size;
     float env_const[3];
     uint32_t width, height;
-    uint32_t x0, y0, tw, th, cap;
+    uint32_t x0, y0, tw, th, cap;       // tile rectangle; cap = tiles_x * tiles_y * 64 pixel slots
+    uint32_t tiles_x;
     uint32_t max_rad, max_shadow;
     uint32_t accum_mode;
     float4 *accum;
@@ -98,6 +100,19 @@ RT_DEV f3 sample_cube(const PipeDev &pd, f3 d)
 RT_DEV f3 sample_environment(const PipeDev &pd, f3 dir)
 {
     return sample_cube(pd, dir) * pd.pfc.options.environmentStrength;
+}
+
+// Pixel slot q -> pixel.  Slots are laid out as 8x8 pixel tiles (64 consecutive slots = one
+// wave = one 8x8 screen tile), so a wave's primary rays -- and, through the order-preserving
+// compaction, the secondary and shadow rays spawned from them -- share BVH nodes.  Slots of
+// partial tiles that fall outside the rectangle are invalid.
+RT_DEV bool pix_xy(const PipeDev &pd, uint32_t q, uint32_t &px, uint32_t &py)
+{
+    const uint32_t t = q >> 6, w = q & 63u;
+    const uint32_t lx = (t % pd.tiles_x) * 8u + (w & 7u), ly = (t / pd.tiles_x) * 8u + (w >> 3);
+    px = pd.x0 + lx;
+    py = pd.y0 + ly;
+    return lx < pd.tw && ly < pd.th;
 }
 
 // ---- RayGen (ProgressiveRaytracing.hlsl:18-32)
@@ -365,20 +380,45 @@ RT_DEV void wave_add(uint32_t v, uint32_t *counter)
 
 // ---- kernels -------------------------------------------------------------------------
 
-template <int STACK>
+// primary stage: raygen is the ray source, hit0/inst0 the sink (pixel-indexed)
+struct PrimarySrc {
+    const PipeDev &pd;
+    RT_DEV uint32_t count() const { return pd.cap; }
+    RT_DEV uint32_t flags() const { return RT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES; }      // ProgressiveRaytracing.hlsl:34
+    RT_DEV bool load(uint32_t q, RayD &r) const
+    {
+        uint32_t px, py;
+        const bool valid = pix_xy(pd, q, px, py);
+        r = primary_ray(pd, px, py);
+        return valid;
+    }
+};
+struct PrimarySink {
+    const PipeDev &pd;
+    RT_DEV void store(uint32_t q, const HitD &h, bool) const
+    {
+        const bool hit = h.inst != RT_NO_HIT;
+        pd.hit0[q] = make_float4(hit ? h.t : HIT_MISS, h.u, h.v, __uint_as_float(h.prim));
+        pd.inst0[q] = h.inst;
+    }
+};
+
+template <int STACK, bool TWO_LEVEL>
 __global__ void __launch_bounds__(PBLOCK) k_primary(PipeDev pd)
 {
-    __shared__ int smem[StackShape<STACK>::LDSN * PBLOCK];
+    __shared__ int smem[STACK * PBLOCK];
+    PrimarySrc src = {pd};
+    PrimarySink sink = {pd};
+    trace_wave<STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, &pd.counters[C_POOL_PRIMARY], smem);   // one 8x8 tile per wave
+}
+
+// compaction of the pixels whose primary ray hit: ballot + popcount prefix sum, one atomic per wave
+__global__ void __launch_bounds__(PBLOCK) k_compact_primary(PipeDev pd)
+{
     const uint32_t q = blockIdx.x * PBLOCK + threadIdx.x;
-    if (q >= pd.cap) return;
-    const uint32_t px = pd.x0 + q % pd.tw, py = pd.y0 + q / pd.tw;
-    const RayD r = primary_ray(pd, px, py);
-    const HitD h = trace_fast<STACK, PBLOCK>(pd.sc, r, RT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES, smem);
-    const bool hit = h.inst != RT_NO_HIT;
-    pd.hit0[q] = make_float4(hit ? h.t : HIT_MISS, h.u, h.v, __uint_as_float(h.prim));
-    pd.inst0[q] = h.inst;
+    const bool hit = q < pd.cap && pd.hit0[q].x != HIT_MISS;
     const uint32_t k = wave_compact(hit, &pd.counters[C_N0]);
-    pd.pix_k[q] = hit ? k : RT_NO_HIT;
+    if (q < pd.cap) pd.pix_k[q] = hit ? k : RT_NO_HIT;
     if (hit) pd.klist[k] = q;
 }
 
@@ -388,7 +428,8 @@ __global__ void __launch_bounds__(PBLOCK) k_shade0_emit(PipeDev pd, uint32_t sha
     uint32_t n_shadow = 0, n_sec = 0;
     if (k < pd.counters[C_N0]) {
         const uint32_t q = pd.klist[k];
-        const uint32_t px = pd.x0 + q % pd.tw, py = pd.y0 + q / pd.tw;
+        uint32_t px, py;
+        (void)pix_xy(pd, q, px, py);
         const RayD r = primary_ray(pd, px, py);
         const float4 h = pd.hit0[q];
         EmitIO0 io(pd, k);
@@ -404,43 +445,70 @@ __global__ void __launch_bounds__(PBLOCK) k_shade0_emit(PipeDev pd, uint32_t sha
     wave_add(n_sec, &pd.counters[C_SECONDARY]);
 }
 
-// any-hit over `batches` batches of *count rays; batch b lives at [b*stride, b*stride + *count)
-template <int STACK>
-__global__ void __launch_bounds__(PBLOCK)
-k_trace_shadow(SceneDev sc, const float4 *__restrict__ O, const float4 *__restrict__ D, const uint32_t *__restrict__ count,
-               uint32_t stride, uint32_t batches, uint32_t *__restrict__ vis)
+// a ray queue of `batches` batches of *count rays; batch b lives at [b*stride, b*stride + *count)
+struct QueueSrc {
+    const float4 *O, *D;
+    const uint32_t *count_ptr;
+    uint32_t stride, batches, fl;
+    RT_DEV uint32_t n() const { return *count_ptr; }
+    RT_DEV uint32_t count() const { return n() * batches; }
+    RT_DEV uint32_t flags() const { return fl; }
+    RT_DEV size_t slot(uint32_t i) const { const uint32_t c = n(); return (size_t)(i / c) * stride + i % c; }
+    RT_DEV bool load(uint32_t i, RayD &r) const
+    {
+        const size_t sl = slot(i);
+        const v4f a = ldg16(O, sl * 16), b = ldg16(D, sl * 16);
+        r.o = mk3(a.x, a.y, a.z); r.tmin = a.w;
+        r.d = mk3(b.x, b.y, b.z); r.tmax = b.w;
+        return r.tmax > r.tmin;
+    }
+};
+
+struct ShadowSink {      // ShadowMiss sets visibility 1 (ProgressiveRaytracing.hlsl:178-182)
+    QueueSrc q;
+    uint32_t *vis;
+    RT_DEV void store(uint32_t i, const HitD &h, bool) const { vis[q.slot(i)] = h.inst == RT_NO_HIT ? 1u : 0u; }
+};
+
+struct SecondarySink {
+    QueueSrc q;
+    float4 *hit1;
+    uint32_t *inst1;
+    RT_DEV void store(uint32_t i, const HitD &h, bool traced) const
+    {
+        const size_t sl = q.slot(i);
+        const bool hit = h.inst != RT_NO_HIT;
+        hit1[sl] = make_float4(hit ? h.t : (traced ? HIT_MISS : HIT_UNTRACED), h.u, h.v, __uint_as_float(h.prim));
+        inst1[sl] = h.inst;
+    }
+};
+
+template <int STACK, bool TWO_LEVEL>
+__global__ void __launch_bounds__(PBLOCK) k_trace_shadow(SceneDev sc, QueueSrc src, uint32_t *vis, uint32_t *pool)
 {
-    __shared__ int smem[StackShape<STACK>::LDSN * PBLOCK];
-    const uint32_t n = *count;
-    const uint32_t idx = blockIdx.x * PBLOCK + threadIdx.x;
-    const uint32_t per = (n + PBLOCK - 1) / PBLOCK * PBLOCK;      // batches start on block boundaries
-    const uint32_t b = per ? idx / per : batches, k = per ? idx % per : 0;
-    if (b >= batches || k >= n) return;
-    const size_t slot = (size_t)b * stride + k;
-    const RayD r = load_ray(O, D, slot);
-    const HitD h = trace_fast<STACK, PBLOCK>(sc, r, RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH | RT_RAY_FLAG_SKIP_CLOSEST_HIT_SHADER, smem);
-    vis[slot] = h.inst == RT_NO_HIT ? 1u : 0u;
+    __shared__ int smem[STACK * PBLOCK];
+    ShadowSink sink = {src, vis};
+    trace_wave<STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem);
 }
 
-template <int STACK>
-__global__ void __launch_bounds__(PBLOCK) k_trace_secondary(PipeDev pd)
+template <int STACK, bool TWO_LEVEL>
+__global__ void __launch_bounds__(PBLOCK) k_trace_secondary(SceneDev sc, QueueSrc src, float4 *hit1, uint32_t *inst1, uint32_t *pool)
 {
-    __shared__ int smem[StackShape<STACK>::LDSN * PBLOCK];
+    __shared__ int smem[STACK * PBLOCK];
+    SecondarySink sink = {src, hit1, inst1};
+    trace_wave<STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem);
+}
+
+// compaction of the secondary rays that hit (they get shaded and emit shadow rays)
+__global__ void __launch_bounds__(PBLOCK) k_compact_secondary(PipeDev pd)
+{
     const uint32_t n = pd.counters[C_N0];
     const uint32_t idx = blockIdx.x * PBLOCK + threadIdx.x;
-    const uint32_t per = (n + PBLOCK - 1) / PBLOCK * PBLOCK;
-    const uint32_t b = per ? idx / per : 2u, k = per ? idx % per : 0;
-    if (b >= 2u || k >= n) return;
-    const size_t slot = (size_t)b * pd.cap + k;
-    const RayD r = load_ray(pd.secO, pd.secD, slot);
-    const bool traced = r.tmax > r.tmin;
-    HitD h = make_miss(r);
-    if (traced) h = trace_fast<STACK, PBLOCK>(pd.sc, r, RT_RAY_FLAG_NONE, smem);
-    const bool hit = h.inst != RT_NO_HIT;
-    pd.hit1[slot] = make_float4(hit ? h.t : (traced ? HIT_MISS : HIT_UNTRACED), h.u, h.v, __uint_as_float(h.prim));
-    pd.inst1[slot] = h.inst;
+    const bool in_range = idx < 2u * n;
+    const size_t slot = in_range ? (size_t)(idx / n) * pd.cap + idx % n : 0;
+    const bool hit = in_range && pd.hit1[slot].x >= 0.0f;
     const uint32_t j = wave_compact(hit, &pd.counters[C_N1]);
-    pd.slot_j[slot] = hit ? j : RT_NO_HIT;
+    if (in_range) pd.slot_j[slot] = hit ? j : RT_NO_HIT;
     if (hit) pd.jlist[j] = (uint32_t)slot;
 }
 
@@ -452,7 +520,8 @@ __global__ void __launch_bounds__(PBLOCK) k_shade1_emit(PipeDev pd)
         const uint32_t slot = pd.jlist[j];
         const uint32_t k = slot % pd.cap;
         const uint32_t q = pd.klist[k];
-        const uint32_t px = pd.x0 + q % pd.tw, py = pd.y0 + q / pd.tw;
+        uint32_t px, py;
+        (void)pix_xy(pd, q, px, py);
         const RayD r = load_ray(pd.secO, pd.secD, slot);
         const float4 h = pd.hit1[slot];
         EmitIO1 io(pd, j);
@@ -468,7 +537,8 @@ __global__ void __launch_bounds__(PBLOCK) k_resolve(PipeDev pd)
 {
     const uint32_t q = blockIdx.x * PBLOCK + threadIdx.x;
     if (q >= pd.cap) return;
-    const uint32_t px = pd.x0 + q % pd.tw, py = pd.y0 + q / pd.tw;
+    uint32_t px, py;
+    if (!pix_xy(pd, q, px, py)) return;
     const RayD r = primary_ray(pd, px, py);
     const float4 h = pd.hit0[q];
     f3 c;
@@ -535,8 +605,9 @@ __global__ void __launch_bounds__(PBLOCK) k_count_primary(PipeDev pd, unsigned l
 {
     const uint32_t q = blockIdx.x * PBLOCK + threadIdx.x;
     unsigned long long rays = 0, nodes = 0, tris = 0;
-    if (q < pd.cap) {
-        const RayD r = primary_ray(pd, pd.x0 + q % pd.tw, pd.y0 + q / pd.tw);
+    uint32_t px, py;
+    if (q < pd.cap && pix_xy(pd, q, px, py)) {
+        const RayD r = primary_ray(pd, px, py);
         uint32_t cn, ct;
         (void)trace_canonical(pd.sc, r, RT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES, cn, ct);
         rays = 1; nodes = cn; tris = ct;
@@ -623,32 +694,45 @@ int ensure_queues(rt_pipeline *p, uint32_t cap, uint32_t sh0_batches)
     return RT_OK;
 }
 
-template <int STACK>
+template <int STACK, bool TWO_LEVEL>
 void launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
 {
     hipStream_t st = p->ctx->stream;
     const bool T = p->ring_frames > 0;
     hipEvent_t *ev = T ? &p->ring[(size_t)(p->ring_pos % (uint64_t)p->ring_frames) * 8] : nullptr;
     const uint32_t cap = pd.cap;
+    const unsigned pmax = p->ctx->persistent_blocks;
+    auto pgrid = [pmax](size_t rays) { const size_t b = (rays + PBLOCK - 1) / PBLOCK; return (unsigned)(b < pmax ? (b ? b : 1) : pmax); };
+    const uint32_t any = RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH | RT_RAY_FLAG_SKIP_CLOSEST_HIT_SHADER;
+    const QueueSrc sec = {pd.secO, pd.secD, &pd.counters[C_N0], cap, 2u, RT_RAY_FLAG_NONE};          // ProgressiveRaytracing.hlsl:53
+    const QueueSrc sh0 = {pd.sh0O, pd.sh0D, &pd.counters[C_N0], cap, shadow_slots, any};              // RaytracingCommon.hlsli:94
+    const QueueSrc sh1 = {pd.sh1O, pd.sh1D, &pd.counters[C_N1], 2u * cap, 2u, any};
     if (T) (void)hipEventRecord(ev[0], st);
-    k_primary<STACK><<<blocks(cap), PBLOCK, 0, st>>>(pd);
+    // primary rays are coherent: one 8x8 tile per wave, scheduled by the hardware dispatcher
+    k_primary<STACK, TWO_LEVEL><<<blocks(cap), PBLOCK, 0, st>>>(pd);
+    k_compact_primary<<<blocks(cap), PBLOCK, 0, st>>>(pd);
     if (T) (void)hipEventRecord(ev[1], st);
     k_shade0_emit<<<blocks(cap), PBLOCK, 0, st>>>(pd, shadow_slots);
     if (T) (void)hipEventRecord(ev[2], st);
-    // one extra block per batch covers the block-boundary padding of each batch
-    k_trace_secondary<STACK><<<blocks(cap) * 2 + 2, PBLOCK, 0, st>>>(pd);
+    k_trace_secondary<STACK, TWO_LEVEL><<<pgrid((size_t)cap * 2), PBLOCK, 0, st>>>(pd.sc, sec, pd.hit1, pd.inst1, &pd.counters[C_POOL_SECONDARY]);
+    k_compact_secondary<<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd);
     if (T) (void)hipEventRecord(ev[3], st);
-    k_trace_shadow<STACK><<<(blocks(cap) + 1) * shadow_slots, PBLOCK, 0, st>>>(pd.sc, pd.sh0O, pd.sh0D, &pd.counters[C_N0], cap,
-                                                                               shadow_slots, pd.vis0);
+    k_trace_shadow<STACK, TWO_LEVEL><<<pgrid((size_t)cap * shadow_slots), PBLOCK, 0, st>>>(pd.sc, sh0, pd.vis0, &pd.counters[C_POOL_SHADOW0]);
     if (T) (void)hipEventRecord(ev[4], st);
     k_shade1_emit<<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd);
     if (T) (void)hipEventRecord(ev[5], st);
-    k_trace_shadow<STACK><<<(blocks((size_t)cap * 2) + 1) * 2, PBLOCK, 0, st>>>(pd.sc, pd.sh1O, pd.sh1D, &pd.counters[C_N1], 2 * cap, 2,
-                                                                                pd.vis1);
+    k_trace_shadow<STACK, TWO_LEVEL><<<pgrid((size_t)cap * 4), PBLOCK, 0, st>>>(pd.sc, sh1, pd.vis1, &pd.counters[C_POOL_SHADOW1]);
     if (T) (void)hipEventRecord(ev[6], st);
     k_resolve<<<blocks(cap), PBLOCK, 0, st>>>(pd);
     if (T) { (void)hipEventRecord(ev[7], st); p->ring_pos++; }
-    k_add_totals<<<1, 64, 0, st>>>(pd.counters, p->totals.as<unsigned long long>(), cap);
+    k_add_totals<<<1, 64, 0, st>>>(pd.counters, p->totals.as<unsigned long long>(), pd.tw * pd.th);
+}
+
+template <int STACK>
+void launch_frame_any(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
+{
+    if (p->scene->two_level) launch_frame<STACK, true>(p, pd, shadow_slots);
+    else launch_frame<STACK, false>(p, pd, shadow_slots);
 }
 
 }  // namespace
@@ -835,7 +919,8 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
         HIP_TRY(hipMemcpyAsync(p->d_mats.p, p->mats.data(), sizeof(rt_material_params) * p->mats.size(), hipMemcpyHostToDevice, st));
         p->mats_dirty = false;
     }
-    const uint32_t tw = x1 - x0, th = y1 - y0, cap = tw * th;
+    const uint32_t tw = x1 - x0, th = y1 - y0;
+    const uint32_t tiles_x = (tw + 7u) / 8u, cap = tiles_x * ((th + 7u) / 8u) * 64u;
     const uint32_t shadow_slots = p->pfc.options.showAmbientOcclusionOnly ? 4u : 2u;
     RT_TRY(ensure_queues(p, cap, shadow_slots));
     if (!p->totals.p) {
@@ -851,7 +936,7 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
     pd.env_size = p->env_size;
     for (int k = 0; k < 3; k++) pd.env_const[k] = p->env_const[k];
     pd.width = width; pd.height = height;
-    pd.x0 = x0; pd.y0 = y0; pd.tw = tw; pd.th = th; pd.cap = cap;
+    pd.x0 = x0; pd.y0 = y0; pd.tw = tw; pd.th = th; pd.cap = cap; pd.tiles_x = tiles_x;
     pd.max_rad = p->max_rad; pd.max_shadow = p->max_shadow;
     pd.accum_mode = p->accum_mode;
     pd.accum = p->accum;
@@ -865,10 +950,10 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
     pd.sh1O = p->sh1O.as<float4>(); pd.sh1D = p->sh1D.as<float4>(); pd.vis1 = p->vis1.as<uint32_t>();
     HIP_TRY(hipMemsetAsync(pd.counters, 0, C_COUNT * 4, st));
     const uint32_t need = p->scene->stack_need;
-    if (need <= 32) launch_frame<32>(p, pd, shadow_slots);
-    else if (need <= 64) launch_frame<64>(p, pd, shadow_slots);
-    else if (need <= 160) launch_frame<160>(p, pd, shadow_slots);
-    else { rt_set_error("traversal stack need %u exceeds 160 entries", need); return RT_ERR_UNSUPPORTED; }
+    if (need < 32) launch_frame_any<32>(p, pd, shadow_slots);
+    else if (need < 64) launch_frame_any<64>(p, pd, shadow_slots);
+    else if (need < 160) launch_frame_any<160>(p, pd, shadow_slots);
+    else { rt_set_error("traversal stack need %u exceeds 159 entries", need); return RT_ERR_UNSUPPORTED; }
     HIP_TRY(hipGetLastError());
     p->last_pd = pd;
     p->last_shadow_slots = shadow_slots;
@@ -1036,14 +1121,21 @@ int rt_pipeline_read_primary_hits(rt_pipeline *p, float *t, uint32_t *prim, uint
     if (!p->rendered) { rt_set_error("nothing rendered yet"); return RT_ERR_STATE; }
     HIP_TRY(hipSetDevice(p->ctx->device));
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-    const size_t cap = (size_t)(p->last_tile[2] - p->last_tile[0]) * (p->last_tile[3] - p->last_tile[1]);
+    const PipeDev &pd = p->last_pd;
+    const size_t cap = pd.cap;
     std::vector<float4> h(cap);
+    std::vector<uint32_t> hi(cap);
     HIP_TRY(hipMemcpy(h.data(), p->hit0.p, cap * 16, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < cap; i++) {
-        if (t) t[i] = h[i].x;
-        if (prim) memcpy(&prim[i], &h[i].w, 4);
+    HIP_TRY(hipMemcpy(hi.data(), p->inst0.p, cap * 4, hipMemcpyDeviceToHost));
+    for (size_t q = 0; q < cap; q++) {          // slots are 8x8-tiled: scatter back to scanline order
+        const uint32_t tl = (uint32_t)(q >> 6), w = (uint32_t)(q & 63u);
+        const uint32_t lx = (tl % pd.tiles_x) * 8u + (w & 7u), ly = (tl / pd.tiles_x) * 8u + (w >> 3);
+        if (lx >= pd.tw || ly >= pd.th) continue;
+        const size_t i = (size_t)ly * pd.tw + lx;
+        if (t) t[i] = h[q].x;
+        if (prim) memcpy(&prim[i], &h[q].w, 4);
+        if (inst) inst[i] = hi[q];
     }
-    if (inst) HIP_TRY(hipMemcpy(inst, p->inst0.p, cap * 4, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -1,20 +1,11 @@
 // rt_trace.hip -- batch TraceRay kernels behind rt_trace_batch().
-#include "rt_trace_device.h"
+#include "rt_trace_wave.h"
 
 using namespace rtd;
 
 namespace {
 
 constexpr int TRACE_BLOCK = 256;
-
-RT_DEV RayD load_ray(const float4 *__restrict__ o, const float4 *__restrict__ d, size_t i)
-{
-    const float4 a = o[i], b = d[i];
-    RayD r;
-    r.o = mk3(a.x, a.y, a.z); r.tmin = a.w;
-    r.d = mk3(b.x, b.y, b.z); r.tmax = b.w;
-    return r;
-}
 
 RT_DEV void store_hit(const TraceOut &out, size_t i, const HitD &h)
 {
@@ -24,6 +15,15 @@ RT_DEV void store_hit(const TraceOut &out, size_t i, const HitD &h)
     if (out.v) out.v[i] = h.v;
     if (out.prim) out.prim[i] = h.prim;
     if (out.inst) out.inst[i] = h.inst;
+}
+
+RT_DEV RayD load_ray(const float4 *__restrict__ o, const float4 *__restrict__ d, size_t i)
+{
+    const v4f a = ldg16(o, i * 16), b = ldg16(d, i * 16);
+    RayD r;
+    r.o = mk3(a.x, a.y, a.z); r.tmin = a.w;
+    r.d = mk3(b.x, b.y, b.z); r.tmax = b.w;
+    return r;
 }
 
 __global__ void __launch_bounds__(TRACE_BLOCK)
@@ -39,16 +39,31 @@ k_trace_canonical(SceneDev sc, const float4 *__restrict__ o, const float4 *__res
     if (out.cnt_tris) out.cnt_tris[i] = ct;
 }
 
-template <int STACK>
-__global__ void __launch_bounds__(TRACE_BLOCK)
-k_trace_fast(SceneDev sc, const float4 *__restrict__ o, const float4 *__restrict__ d, size_t n, uint32_t flags, TraceOut out)
+struct BatchSrc {
+    const float4 *o, *d;
+    uint32_t n, fl;
+    RT_DEV uint32_t count() const { return n; }
+    RT_DEV uint32_t flags() const { return fl; }
+    RT_DEV bool load(uint32_t i, RayD &r) const { r = load_ray(o, d, i); return true; }
+};
+
+struct BatchSink {
+    TraceOut out;
+    RT_DEV void store(uint32_t i, const HitD &h, bool) const { store_hit(out, i, h); }
+};
+
+template <int STACK, bool TWO_LEVEL>
+__global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(SceneDev sc, BatchSrc src, BatchSink sink, uint32_t *pool)
 {
-    __shared__ int smem[StackShape<STACK>::LDSN * TRACE_BLOCK];
-    const size_t i = (size_t)blockIdx.x * TRACE_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const RayD r = load_ray(o, d, i);
-    const HitD h = trace_fast<STACK, TRACE_BLOCK>(sc, r, flags, smem);
-    store_hit(out, i, h);
+    __shared__ int smem[STACK * TRACE_BLOCK];
+    trace_wave<STACK, TRACE_BLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem);
+}
+
+template <int STACK>
+void launch_fast(bool two_level, unsigned grid, hipStream_t st, const SceneDev &sc, const BatchSrc &src, const BatchSink &sink, uint32_t *pool)
+{
+    if (two_level) k_trace_fast<STACK, true><<<grid, TRACE_BLOCK, 0, st>>>(sc, src, sink, pool);
+    else k_trace_fast<STACK, false><<<grid, TRACE_BLOCK, 0, st>>>(sc, src, sink, pool);
 }
 
 }  // namespace
@@ -58,18 +73,26 @@ int rt_launch_trace(rt_context *ctx, const rt_scene *s, const float4 *o, const f
 {
     if (n == 0) return RT_OK;
     const SceneDev sc = s->dev();
-    const unsigned grid = (unsigned)((n + TRACE_BLOCK - 1) / TRACE_BLOCK);
     hipStream_t st = ctx->stream;
-    HIP_TRY(hipEventRecord(ctx->ev0, st));
     if (kernel == RT_TRACE_CANONICAL) {
+        const unsigned grid = (unsigned)((n + TRACE_BLOCK - 1) / TRACE_BLOCK);
+        HIP_TRY(hipEventRecord(ctx->ev0, st));
         k_trace_canonical<<<grid, TRACE_BLOCK, 0, st>>>(sc, o, d, n, ray_flags, out);
     } else {
+        if (n > 0xFFFFFF00ull) { rt_set_error("rt_trace_batch: more than 2^32 rays in one batch"); return RT_ERR_INVALID_ARG; }
+        RT_TRY(ctx->pool.reserve(64));
+        HIP_TRY(hipMemsetAsync(ctx->pool.p, 0, 64, st));
+        BatchSrc src = {o, d, (uint32_t)n, ray_flags};
+        BatchSink sink = {out};
+        const size_t want = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
+        const unsigned grid = (unsigned)(want < ctx->persistent_blocks ? want : ctx->persistent_blocks);
         const uint32_t need = s->stack_need;
-        if (need <= 32) k_trace_fast<32><<<grid, TRACE_BLOCK, 0, st>>>(sc, o, d, n, ray_flags, out);
-        else if (need <= 64) k_trace_fast<64><<<grid, TRACE_BLOCK, 0, st>>>(sc, o, d, n, ray_flags, out);
-        else if (need <= 160) k_trace_fast<160><<<grid, TRACE_BLOCK, 0, st>>>(sc, o, d, n, ray_flags, out);
+        HIP_TRY(hipEventRecord(ctx->ev0, st));
+        if (need < 32) launch_fast<32>(s->two_level, grid, st, sc, src, sink, ctx->pool.as<uint32_t>());
+        else if (need < 64) launch_fast<64>(s->two_level, grid, st, sc, src, sink, ctx->pool.as<uint32_t>());
+        else if (need < 160) launch_fast<160>(s->two_level, grid, st, sc, src, sink, ctx->pool.as<uint32_t>());
         else {
-            rt_set_error("traversal stack need %u exceeds 160 entries", need);
+            rt_set_error("traversal stack need %u exceeds 159 entries", need);
             return RT_ERR_UNSUPPORTED;
         }
     }

@@ -244,138 +244,4 @@ RT_DEV HitD trace_canonical(const SceneDev &sc, const RayD &r, uint32_t flags, u
     return best;
 }
 
-// ---------------------------------------------------------------------------
-// Production traversal.  One ray per lane; the traversal stack lives in LDS as
-// stack[level][lane-in-block] (one dword per lane per level: bank = lane mod 32,
-// conflict free for both halves of the wave).  Internal nodes are 64-B slabs
-// holding both child boxes, fetched as four 16-B loads from one half cache line.
-// A single loop walks the TLAS and, below an instance leaf, that instance's BLAS
-// with the ray transformed to object space; RT_SENTINEL marks the BLAS bottom.
-// ---------------------------------------------------------------------------
-
-#define RT_STACK_SENTINEL 0x7FFFFFFF   // pops back out of a BLAS
-#define RT_STACK_EMPTY    0x7FFFFFFE
-
-// Traversal stack of STACK entries per lane: the first RT_LDS_STACK levels live in LDS
-// (smem[level][lane]: one dword per lane per level, conflict free), deeper levels --
-// rarely reached: a level is only used while BOTH children of that many ancestors were
-// hit -- spill to a per-lane private array.  Keeping the LDS part short is what lets
-// 5+ waves per SIMD stay resident (16 levels x 256 lanes x 4 B = 16 KiB per block).
-#ifndef RT_LDS_STACK
-#define RT_LDS_STACK 16
-#endif
-
-template <int STACK>
-struct StackShape {
-    static constexpr int LDSN = STACK < RT_LDS_STACK ? STACK : RT_LDS_STACK;
-    static constexpr int SPILL = STACK - LDSN;
-};
-
-template <int STACK, int BLOCK>
-struct LdsStack {
-    static constexpr int LDSN = StackShape<STACK>::LDSN;
-    static constexpr int SPILL = StackShape<STACK>::SPILL;
-    int *base;      // &smem[threadIdx.x]
-    int sp;
-    int spill[SPILL > 0 ? SPILL : 1];
-    RT_DEV void init(int *smem) { base = smem + threadIdx.x; sp = 0; }
-    RT_DEV void push(int v)
-    {
-        if (SPILL == 0 || sp < LDSN) base[sp * BLOCK] = v;
-        else spill[sp - LDSN] = v;
-        sp++;
-    }
-    RT_DEV int pop()
-    {
-        sp--;
-        if (SPILL == 0 || sp < LDSN) return base[sp * BLOCK];
-        return spill[sp - LDSN];
-    }
-};
-
-template <int STACK, int BLOCK>
-RT_DEV HitD trace_fast(const SceneDev &sc, const RayD &r, uint32_t flags, int *smem)
-{
-    HitD best = make_miss(r);
-    if (sc.n_inst == 0 || !(r.tmax > r.tmin)) return best;
-    const bool first = (flags & RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH) != 0;
-    const bool cull = (flags & RT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES) != 0;
-
-    LdsStack<STACK, BLOCK> st;
-    st.init(smem);
-    st.push(RT_STACK_EMPTY);
-
-    const RayInv wri = make_inv(r.o, r.d);
-    ObjRay cur_ray;                 // ray in the space of the structure being walked
-    cur_ray.o = r.o; cur_ray.d = r.d; cur_ray.ri = wri;
-    const Slab *slabs = sc.tlas_slabs;
-    const InstanceRec *in = nullptr;
-    uint32_t ii = RT_NO_HIT;
-    bool in_blas = false;
-    int node = sc.tlas_root_code;
-    bool done = false;
-
-    while (!done) {
-        // ---- descend through internal nodes
-        while (node >= 0 && node < RT_STACK_EMPTY) {
-            const Slab *s = slabs + node;
-            const float4 q0 = s->q0, q1 = s->q1, q2 = s->q2, q3 = s->q3;
-            float e0, e1;
-            const bool h0 = slab_hit(cur_ray.ri, q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, r.tmin, best.t, e0);
-            const bool h1 = slab_hit(cur_ray.ri, q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, r.tmin, best.t, e1);
-            const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-            if (h0 && h1) {
-                const bool swap = e1 < e0;
-                st.push(swap ? c0 : c1);
-                node = swap ? c1 : c0;
-            } else if (h0) node = c0;
-            else if (h1) node = c1;
-            else node = st.pop();
-        }
-        if (node == RT_STACK_EMPTY) break;
-        if (node == RT_STACK_SENTINEL) {
-            // leave the BLAS: back to the TLAS in world space
-            in_blas = false;
-            slabs = sc.tlas_slabs;
-            cur_ray.o = r.o; cur_ray.d = r.d; cur_ray.ri = wri;
-            node = st.pop();
-            continue;
-        }
-        // ---- leaf
-        const uint32_t code = (uint32_t)~node;
-        if (!in_blas) {
-            ii = code;
-            in = sc.inst + ii;
-            float e;
-            // the instance box was tested as a child of its TLAS parent, except when
-            // the TLAS is a single leaf: test it here for that case
-            bool enter = true;
-            if (sc.n_inst == 1)
-                enter = slab_hit(wri, in->wlo[0], in->whi[0], in->wlo[1], in->whi[1], in->wlo[2], in->whi[2], r.tmin, best.t, e);
-            if (enter) {
-                cur_ray = to_object(*in, r);
-                slabs = in->slabs;
-                in_blas = true;
-                st.push(RT_STACK_SENTINEL);
-                node = in->root_code;
-            } else node = st.pop();
-            continue;
-        }
-        const uint32_t firstTri = code >> 3, cnt = (code & 7u) + 1u;
-        for (uint32_t k = 0; k < cnt; k++) {
-            const TriRec *tp = in->tris + firstTri + k;
-            const float4 a = tp->a, b = tp->b, c = tp->c;
-            const uint32_t prim = __float_as_uint(c.y);
-            if (accept_candidate(*in, ii, prim, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), r, wri, cur_ray, cull,
-                                 best) && first) {
-                done = true;
-                break;
-            }
-        }
-        if (done) break;
-        node = st.pop();
-    }
-    return best;
-}
-
 }  // namespace rtd

@@ -1,0 +1,229 @@
+// rt_trace_wave.h -- production TraceRay for gfx950: a persistent, wave64-wide
+// traversal engine.
+//
+// Design (MI355X-first; nothing here comes from the Fallback Layer, whose source is
+// not in the reference checkout):
+//   * one ray per lane, 4 waves per workgroup, as many workgroups as stay resident;
+//     each wave keeps pulling rays from a global pool: when at least REFILL lanes
+//     of the wave are idle (their ray finished) one lane does ONE atomicAdd for the
+//     whole wave (ballot + popcount prefix sum hands out the indices) and the idle
+//     lanes load the next rays -- on wave64 incoherent rays otherwise leave most of
+//     a wave's 64 lanes parked while the longest ray finishes;
+//   * "while-while" order: all lanes walk internal nodes until every live lane
+//     stands on a leaf, then all leaves are processed together, so the (short)
+//     triangle code is not serialised against the (long) node code;
+//   * internal nodes are 64-B slabs holding BOTH child boxes: four 16-B loads from
+//     one half cache line through explicitly global (address-space 1) pointers;
+//   * the step is branch free: both children are slab-tested, the nearer hit child
+//     is entered, the farther one is written to the stack slot above the top
+//     unconditionally (it only counts if the top moves), the slot below the top is
+//     read speculatively (it only counts if both children miss);
+//   * the stack is LDS resident, stack[level][lane-in-block]: one dword per lane per
+//     level, bank = lane mod 32, conflict free for both halves of a wave.
+//
+// Exactness: culling uses the same monotone slab test as the oracle and candidates
+// are validated exactly as the canonical definition prescribes (rt_trace_device.h),
+// so the visiting order, leaf collapsing and ray-to-lane assignment used here cannot
+// change any result bit.
+#pragma once
+
+#include "rt_trace_device.h"
+
+namespace rtd {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) v4f *gptr4;
+
+// 16-B load through a global (not flat) pointer
+RT_DEV v4f ldg16(const void *base, size_t byte_off)
+{
+    return *(gptr4)((const char *)base + byte_off);
+}
+
+#define RT_NODE_EMPTY    0x7FFFFFFE     // popped from an empty stack: the ray is finished
+#define RT_NODE_SENTINEL 0x7FFFFFFF     // bottom of a BLAS walk: return to the TLAS
+
+#ifndef RT_REFILL_LANES
+#define RT_REFILL_LANES 16              // refill a wave once this many of its 64 lanes are idle
+#endif
+#ifndef RT_POOL_CHUNK
+#define RT_POOL_CHUNK 128u              // rays per chunk of the queue a wave takes at a time
+#endif
+
+RT_DEV bool node_is_internal(int node) { return node >= 0 && node < RT_NODE_EMPTY; }
+
+RT_DEV unsigned long long lanemask_lt()
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    return (1ull << lane) - 1ull;
+}
+
+// Ray sources / hit sinks are small functor structs:
+//   struct Src  { uint32_t count() const; bool load(uint32_t i, RayD &r) const;   // false: not to be traced
+//                 uint32_t flags() const; };
+//   struct Sink { void store(uint32_t i, const HitD &h, bool traced) const; };
+
+template <int STACK, int BLOCK, bool TWO_LEVEL, uint32_t CHUNK, class Src, class Sink>
+RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uint32_t *pool, int *smem)
+{
+    const uint32_t total = src.count();
+    const uint32_t flags = src.flags();
+    const bool first = (flags & RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH) != 0;
+    const bool cull = (flags & RT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES) != 0;
+    int *stk = smem + threadIdx.x;                 // stk[level * BLOCK]
+
+    // single-level scenes (one identity instance) walk the BLAS directly in world space
+    const InstanceRec *in0 = sc.inst;
+    const Slab *blas_slabs0 = TWO_LEVEL ? nullptr : in0->slabs;
+    const TriRec *tris0 = TWO_LEVEL ? nullptr : in0->tris;
+    const int root0 = TWO_LEVEL ? sc.tlas_root_code : in0->root_code;
+
+    bool alive = false;
+    bool exhausted = false;          // wave-uniform: the global pool has nothing left
+    uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the chunk of the queue being handed out
+    const uint32_t n_waves = gridDim.x * (BLOCK / 64);
+    uint32_t next_chunk = blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;   // wave-uniform
+    uint32_t idx = 0;
+    RayD r;
+    RayInv wri;
+    HitD best;
+    int node = RT_NODE_EMPTY;
+    int sp = 0;
+    // two-level state
+    ObjRay cur;                       // ray in the space of the structure being walked
+    const Slab *slabs = TWO_LEVEL ? sc.tlas_slabs : blas_slabs0;
+    const InstanceRec *in = in0;
+    const TriRec *tris = tris0;
+    uint32_t ii = 0;
+    bool in_blas = !TWO_LEVEL;
+    r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1); r.tmin = 0; r.tmax = 0;
+    wri = make_inv(r.o, r.d);
+    cur.o = r.o; cur.d = r.d; cur.ri = wri;
+    best = make_miss(r);
+
+    for (;;) {
+        // ---- refill idle lanes: the wave owns a chunk [chunk_next, chunk_end) of the ray pool and
+        //      only goes to the global counter (one atomic, lane 0) when the chunk is used up ----
+        const unsigned long long idle = __ballot(!alive);
+        const int n_idle = __popcll(idle);
+        if (!exhausted && n_idle >= RT_REFILL_LANES) {
+            if (chunk_next >= chunk_end) {
+#ifdef RT_POOL_ATOMIC
+                uint32_t base = 0;
+                if ((threadIdx.x & 63u) == 0u) base = atomicAdd(pool, CHUNK);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+#else
+                // static interleaving: wave w of W owns chunks w, w+W, w+2W, ... of the queue; no
+                // atomics (same-address returning atomics cost ~60 ns each here and serialise)
+                const uint32_t base = next_chunk * CHUNK;
+                next_chunk += n_waves;
+#endif
+                chunk_next = base;
+                chunk_end = base + CHUNK < total ? base + CHUNK : total;
+                if (base >= total) { exhausted = true; chunk_end = chunk_next; }
+            }
+            const uint32_t avail = chunk_end - chunk_next;
+            const uint32_t rank = (uint32_t)__popcll(idle & lanemask_lt());
+            if (!alive && rank < avail) {
+                const uint32_t my = chunk_next + rank;
+                idx = my;
+                const bool traced = src.load(my, r);
+                best = make_miss(r);
+                if (traced && r.tmax > r.tmin && sc.n_inst != 0) {
+                    wri = make_inv(r.o, r.d);
+                    cur.o = r.o; cur.d = r.d; cur.ri = wri;
+                    node = root0;
+                    sp = 0;
+                    if (TWO_LEVEL) { slabs = sc.tlas_slabs; in_blas = false; }
+                    alive = true;
+                } else {
+                    sink.store(my, best, traced);
+                }
+            }
+            chunk_next += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
+        }
+        if (__ballot(alive) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- walk internal nodes until this lane stands on a leaf (or runs dry) ----------
+        while (alive && node_is_internal(node)) {
+            const char *sl = (const char *)(slabs + node);
+            const v4f q0 = ldg16(sl, 0), q1 = ldg16(sl, 16), q2 = ldg16(sl, 32), q3 = ldg16(sl, 48);
+#ifdef RT_EXPERIMENT_EXTRA_LOADS      /* timing experiment: re-load the same half line, fold into a dummy */
+            {
+                const char *sx = (const char *)((uintptr_t)sl ^ 64u);      // the other half of the same 128-B line
+                const v4f x0 = ldg16(sx, 0), x1 = ldg16(sx, 16), x2 = ldg16(sx, 32), x3 = ldg16(sx, 48);
+                asm volatile("" :: "v"(x0.x), "v"(x1.y), "v"(x2.z), "v"(x3.w));
+            }
+#endif
+            float e0, e1;
+            const bool h0 = slab_hit(cur.ri, q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, r.tmin, best.t, e0);
+            const bool h1 = slab_hit(cur.ri, q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, r.tmin, best.t, e1);
+            const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            const bool both = h0 && h1, none = !(h0 || h1);
+            const bool swap = e1 < e0;
+            const int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+            const int one = h0 ? c0 : c1;
+            const int below = sp > 0 ? sp - 1 : 0;
+            const int popped = sp > 0 ? stk[below * BLOCK] : RT_NODE_EMPTY;   // speculative pop
+            stk[sp * BLOCK] = farc;                                           // speculative push
+            node = both ? nearc : (none ? popped : one);
+            sp = both ? sp + 1 : ((none && sp > 0) ? sp - 1 : sp);
+        }
+
+        // ---- leaves, instance entry / exit, termination -----------------------------------
+        if (alive) {
+            bool pop = true;
+            if (node == RT_NODE_EMPTY) {
+                sink.store(idx, best, true);
+                alive = false;
+                pop = false;
+            } else if (TWO_LEVEL && node == RT_NODE_SENTINEL) {
+                in_blas = false;
+                slabs = sc.tlas_slabs;
+                cur.o = r.o; cur.d = r.d; cur.ri = wri;
+            } else if (TWO_LEVEL && !in_blas) {
+                ii = (uint32_t)~node;
+                in = sc.inst + ii;
+                bool enter = true;
+                if (sc.n_inst == 1) {      // the lone instance box was never tested as somebody's child
+                    float e;
+                    enter = slab_hit(wri, in->wlo[0], in->whi[0], in->wlo[1], in->whi[1], in->wlo[2], in->whi[2], r.tmin, best.t, e);
+                }
+                if (enter) {
+                    cur = to_object(*in, r);
+                    slabs = in->slabs;
+                    tris = in->tris;
+                    in_blas = true;
+                    stk[sp * BLOCK] = RT_NODE_SENTINEL;
+                    sp++;
+                    node = in->root_code;
+                    pop = false;
+                }
+            } else {
+                const uint32_t code = (uint32_t)~node;
+                const uint32_t first_tri = code >> 3, cnt = (code & 7u) + 1u;
+                for (uint32_t k = 0; k < cnt; k++) {
+                    const char *tp = (const char *)(tris + first_tri + k);
+                    const v4f a = ldg16(tp, 0), b = ldg16(tp, 16), c = ldg16(tp, 32);
+                    const uint32_t prim = __float_as_uint(c.y);
+                    if (accept_candidate(*in, ii, prim, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), r, wri, cur, cull,
+                                         best) && first) {
+                        sink.store(idx, best, true);
+                        alive = false;
+                        pop = false;
+                        break;
+                    }
+                }
+            }
+            if (pop) {
+                if (sp > 0) { sp--; node = stk[sp * BLOCK]; }
+                else node = RT_NODE_EMPTY;
+            }
+        }
+    }
+}
+
+}  // namespace rtd
