@@ -17,7 +17,19 @@ SRCS = $(CSRC)/rt_api.hip $(CSRC)/rt_bvh_build.hip $(CSRC)/rt_trace.hip $(CSRC)/
 HDRS = $(wildcard $(CSRC)/*.h) include/dxr_amd.h include/dxr_amd_types.h
 OBJS = $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
 
-all: $(LIB)
+BIN = $(LIBDIR)/progressive $(LIBDIR)/test_wrapper
+CXX ?= g++
+HOSTFLAGS = -O2 -std=c++17 -Wall -Iinclude -Idxrexperiments_amd/include
+HOSTLINK = -L$(LIBDIR) -ldxrexperiments_amd -L/opt/rocm/lib -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib
+
+all: $(LIB) $(BIN)
+
+# host programs written against the reference-shaped C++ API (no HIP needed to compile them)
+$(LIBDIR)/progressive: examples/progressive.cpp $(LIB) $(wildcard dxrexperiments_amd/include/*.h)
+	$(CXX) $(HOSTFLAGS) $< -o $@ $(HOSTLINK)
+
+$(LIBDIR)/test_wrapper: tests/cpp/test_wrapper.cpp $(LIB) $(wildcard dxrexperiments_amd/include/*.h)
+	$(CXX) $(HOSTFLAGS) $< -o $@ $(HOSTLINK)
 
 build/%.hip.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build
@@ -35,7 +47,7 @@ oracle:
 	$(MAKE) -C oracle liboracle.so
 
 clean:
-	rm -rf build $(LIB)
+	rm -rf build $(LIB) $(BIN)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

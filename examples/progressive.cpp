@@ -1,0 +1,74 @@
+// Headless stand-in for DXRExperimentsApp (src/DXRExperimentsApp.cpp:78-229): builds the scene and the
+// material the reference app hard-codes, drives update()/render() for N frames and writes the
+// accumulation image as a PFM.  Uses only the reference-shaped C++ API (dxrexperiments_amd/include).
+//
+//   progressive <model.obj> <width> <height> <frames> <out.pfm> [eye.x eye.y eye.z at.x at.y at.z]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "ProgressiveRaytracingPipeline.h"
+
+using namespace DXRFramework;
+
+int main(int argc, char **argv)
+{
+    if (argc < 6) {
+        std::fprintf(stderr, "usage: %s model.obj width height frames out.pfm [eye xyz at xyz]\n", argv[0]);
+        return 2;
+    }
+    const UINT width = std::atoi(argv[2]), height = std::atoi(argv[3]), frames = std::atoi(argv[4]);
+    try {
+        auto context = RtContext::create(0);
+        auto scene = RtScene::create();
+        scene->addModel(RtModel::create(context, argv[1]), Matrix::identity());
+
+        RaytracingPipeline::Material material{};                       // DXRExperimentsApp.cpp:95-104
+        material.params.albedo = {0.95f, 0.05f, 0.0f, 1.0f};
+        material.params.specular = {0.58f, 0.58f, 0.58f, 1.0f};
+        material.params.roughness = 0.5f;
+        material.params.reflectivity = 0.7f;
+        material.params.type = 1;
+
+        auto camera = std::make_shared<Math::Camera>();
+        camera->SetAspectRatio(float(width) / float(height));
+        if (argc >= 12)
+            camera->SetEyeAtUp({(float)std::atof(argv[6]), (float)std::atof(argv[7]), (float)std::atof(argv[8])},
+                               {(float)std::atof(argv[9]), (float)std::atof(argv[10]), (float)std::atof(argv[11])}, {0, 1, 0});
+        else
+            camera->SetEyeAtUp({0.0f, 0.0f, 3.2f}, {0.0f, 0.0f, 0.0f}, {0, 1, 0});
+
+        auto pipeline = ProgressiveRaytracingPipeline::create(context);
+        pipeline->setScene(scene);
+        pipeline->addMaterial(material);
+        pipeline->setCamera(camera);
+        pipeline->loadResources(3);
+        pipeline->setEnvironmentConstant(0.5f, 0.5f, 0.5f);
+        pipeline->createOutputResource(RT_FORMAT_R32G32B32A32_FLOAT, width, height);
+        pipeline->buildAccelerationStructures();
+
+        const auto t0 = std::chrono::steady_clock::now();
+        for (UINT frame = 1; frame <= frames; ++frame) {               // the first rendered frame has frameCount 1
+            pipeline->update(0.0f, frame, (frame + 2) % 3, frame % 3, width, height);
+            pipeline->render(frame % 3, width, height);
+        }
+        std::vector<float> image(size_t(width) * height * 4);
+        pipeline->readOutput(image.data(), image.size() * sizeof(float));
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        // window-title metric of the reference (src/utils/DXSample.cpp:114)
+        std::printf("%s: %u frames, %.2f fps, ~%.2f Million Primary Rays/s, BVH build %.2f ms\n", pipeline->getName(), frames, frames / s,
+                    double(width) * height * frames / s / 1e6, scene->getBuildMilliseconds());
+
+        FILE *f = std::fopen(argv[5], "wb");
+        if (!f) { std::perror(argv[5]); return 1; }
+        std::fprintf(f, "PF\n%u %u\n-1.0\n", width, height);
+        for (int y = int(height) - 1; y >= 0; --y)                        // PFM rows run bottom to top
+            for (UINT x = 0; x < width; ++x) std::fwrite(&image[(size_t(y) * width + x) * 4], sizeof(float), 3, f);
+        std::fclose(f);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,58 @@
+// Drives the reference-shaped C++ API end to end and dumps the raw fp32 accumulation image so that the
+// Python test can compare it with the committed golden frames (tests/golden/cornell64_golden.npz).
+//   test_wrapper <cornell.obj> <out.f32>
+#include <cstdio>
+#include <vector>
+
+#include "ProgressiveRaytracingPipeline.h"
+
+using namespace DXRFramework;
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) return 2;
+    try {
+        const UINT W = 64, H = 64;
+        auto context = RtContext::create(0);
+        auto scene = RtScene::create();
+        scene->addModel(RtModel::create(context, argv[1]), Matrix::identity());
+        RaytracingPipeline::Material material{};
+        material.params.albedo = {0.95f, 0.05f, 0.0f, 1.0f};
+        material.params.specular = {0.58f, 0.58f, 0.58f, 1.0f};
+        material.params.roughness = 0.5f;
+        material.params.reflectivity = 0.7f;
+        material.params.type = 1;
+        auto camera = std::make_shared<Math::Camera>();
+        camera->SetAspectRatio(1.0f);
+        camera->SetEyeAtUp({0.0f, 0.0f, 3.2f}, {0.0f, 0.0f, 0.0f}, {0, 1, 0});
+        RaytracingPipeline::SharedPtr pipeline = ProgressiveRaytracingPipeline::create(context, 1234);
+        pipeline->setScene(scene);
+        pipeline->addMaterial(material);
+        pipeline->setCamera(camera);
+        pipeline->loadResources(3);
+        pipeline->createOutputResource(RT_FORMAT_R32G32B32A32_FLOAT, W, H);
+        pipeline->buildAccelerationStructures();
+        if (pipeline->getNumOutputs() != 1 || std::string(pipeline->getName()) != "Progressive Ray Tracing Pipeline") return 3;
+        for (UINT frame = 1; frame <= 4; ++frame) {
+            pipeline->update(0.0f, frame, 0, 0, W, H);
+            pipeline->render(0, W, H);
+        }
+        std::vector<float> image(size_t(W) * H * 4);
+        static_cast<ProgressiveRaytracingPipeline *>(pipeline.get())->readOutput(image.data(), image.size() * 4);
+        FILE *f = std::fopen(argv[2], "wb");
+        if (!f) return 4;
+        std::fwrite(image.data(), 4, image.size(), f);
+        std::fclose(f);
+        // error behaviour: a missing model falls back to the reference's single triangle, bad programs throw
+        auto fallback = RtModel::create(context, "/nonexistent.obj");
+        if (fallback->getNumTriangles() != 1) return 5;
+        bool threw = false;
+        try { RtProgram::Desc d; d.setRayGen("NoSuchShader"); RtProgram::create(context, d); } catch (const std::logic_error &) { threw = true; }
+        if (!threw) return 6;
+        std::printf("wrapper ok\n");
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
