@@ -361,15 +361,25 @@ struct ResolveIO0 {
 };
 
 // ---- wave compaction ---------------------------------------------------------------
-RT_DEV uint32_t wave_compact(bool keep, uint32_t *counter)
+// Order-preserving compaction inside a block of CBLOCK threads: ballot + popcount give the rank inside
+// the wave, wave totals meet in LDS, and ONE atomic per block reserves the output range (same-address
+// returning atomics cost ~11 ns each on this chip, so one per wave would dominate these tiny kernels).
+constexpr int CBLOCK = 1024;
+RT_DEV uint32_t block_compact(bool keep, uint32_t *counter)
 {
+    __shared__ uint32_t wave_total[CBLOCK / 64];
+    __shared__ uint32_t block_base;
     const unsigned long long mask = __ballot(keep);
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t base = 0;
-    const int leader = __ffsll((long long)__ballot(true)) - 1;
-    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = (uint32_t)__shfl((int)base, leader, 64);
-    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_total[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sum = 0;
+        for (int w = 0; w < CBLOCK / 64; w++) { const uint32_t c = wave_total[w]; wave_total[w] = sum; sum += c; }
+        block_base = sum ? atomicAdd(counter, sum) : 0u;
+    }
+    __syncthreads();
+    return block_base + wave_total[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 // every lane of the wave must call this (no early exits before it)
 RT_DEV void wave_add(uint32_t v, uint32_t *counter)
@@ -409,15 +419,15 @@ __global__ void __launch_bounds__(PBLOCK) k_primary(PipeDev pd)
     __shared__ int smem[STACK * PBLOCK];
     PrimarySrc src = {pd};
     PrimarySink sink = {pd};
-    trace_wave<STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, &pd.counters[C_POOL_PRIMARY], smem);   // one 8x8 tile per wave
+    trace_wave<STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, &pd.counters[C_POOL_PRIMARY], smem, nullptr);   // one 8x8 tile per wave
 }
 
 // compaction of the pixels whose primary ray hit: ballot + popcount prefix sum, one atomic per wave
-__global__ void __launch_bounds__(PBLOCK) k_compact_primary(PipeDev pd)
+__global__ void __launch_bounds__(CBLOCK) k_compact_primary(PipeDev pd)
 {
-    const uint32_t q = blockIdx.x * PBLOCK + threadIdx.x;
+    const uint32_t q = blockIdx.x * CBLOCK + threadIdx.x;
     const bool hit = q < pd.cap && pd.hit0[q].x != HIT_MISS;
-    const uint32_t k = wave_compact(hit, &pd.counters[C_N0]);
+    const uint32_t k = block_compact(hit, &pd.counters[C_N0]);
     if (q < pd.cap) pd.pix_k[q] = hit ? k : RT_NO_HIT;
     if (hit) pd.klist[k] = q;
 }
@@ -441,8 +451,7 @@ __global__ void __launch_bounds__(PBLOCK) k_shade0_emit(PipeDev pd, uint32_t sha
         n_shadow = (uint32_t)__popc(io.shadow_mask);
         n_sec = (uint32_t)__popc(io.sec_mask);
     }
-    wave_add(n_shadow, &pd.counters[C_SHADOW]);
-    wave_add(n_sec, &pd.counters[C_SECONDARY]);
+    (void)n_shadow; (void)n_sec;       // rays are counted by the traversal waves (one atomic per persistent wave)
 }
 
 // a ray queue of `batches` batches of *count rays; batch b lives at [b*stride, b*stride + *count)
@@ -484,30 +493,30 @@ struct SecondarySink {
 };
 
 template <int STACK, bool TWO_LEVEL>
-__global__ void __launch_bounds__(PBLOCK) k_trace_shadow(SceneDev sc, QueueSrc src, uint32_t *vis, uint32_t *pool)
+__global__ void __launch_bounds__(PBLOCK) k_trace_shadow(SceneDev sc, QueueSrc src, uint32_t *vis, uint32_t *pool, uint32_t *stat)
 {
     __shared__ int smem[STACK * PBLOCK];
     ShadowSink sink = {src, vis};
-    trace_wave<STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem);
+    trace_wave<STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem, stat);
 }
 
 template <int STACK, bool TWO_LEVEL>
-__global__ void __launch_bounds__(PBLOCK) k_trace_secondary(SceneDev sc, QueueSrc src, float4 *hit1, uint32_t *inst1, uint32_t *pool)
+__global__ void __launch_bounds__(PBLOCK) k_trace_secondary(SceneDev sc, QueueSrc src, float4 *hit1, uint32_t *inst1, uint32_t *pool, uint32_t *stat)
 {
     __shared__ int smem[STACK * PBLOCK];
     SecondarySink sink = {src, hit1, inst1};
-    trace_wave<STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem);
+    trace_wave<STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem, stat);
 }
 
 // compaction of the secondary rays that hit (they get shaded and emit shadow rays)
-__global__ void __launch_bounds__(PBLOCK) k_compact_secondary(PipeDev pd)
+__global__ void __launch_bounds__(CBLOCK) k_compact_secondary(PipeDev pd)
 {
     const uint32_t n = pd.counters[C_N0];
-    const uint32_t idx = blockIdx.x * PBLOCK + threadIdx.x;
+    const uint32_t idx = blockIdx.x * CBLOCK + threadIdx.x;
     const bool in_range = idx < 2u * n;
     const size_t slot = in_range ? (size_t)(idx / n) * pd.cap + idx % n : 0;
     const bool hit = in_range && pd.hit1[slot].x >= 0.0f;
-    const uint32_t j = wave_compact(hit, &pd.counters[C_N1]);
+    const uint32_t j = block_compact(hit, &pd.counters[C_N1]);
     if (in_range) pd.slot_j[slot] = hit ? j : RT_NO_HIT;
     if (hit) pd.jlist[j] = (uint32_t)slot;
 }
@@ -530,7 +539,7 @@ __global__ void __launch_bounds__(PBLOCK) k_shade1_emit(PipeDev pd)
             if (!(io.shadow_mask & (1u << s))) store_invalid(pd.sh1O, pd.sh1D, (size_t)s * 2u * pd.cap + j);
         n_shadow = (uint32_t)__popc(io.shadow_mask);
     }
-    wave_add(n_shadow, &pd.counters[C_SHADOW]);
+    (void)n_shadow;
 }
 
 __global__ void __launch_bounds__(PBLOCK) k_resolve(PipeDev pd)
@@ -710,18 +719,21 @@ void launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
     if (T) (void)hipEventRecord(ev[0], st);
     // primary rays are coherent: one 8x8 tile per wave, scheduled by the hardware dispatcher
     k_primary<STACK, TWO_LEVEL><<<blocks(cap), PBLOCK, 0, st>>>(pd);
-    k_compact_primary<<<blocks(cap), PBLOCK, 0, st>>>(pd);
+    k_compact_primary<<<(cap + CBLOCK - 1) / CBLOCK, CBLOCK, 0, st>>>(pd);
     if (T) (void)hipEventRecord(ev[1], st);
     k_shade0_emit<<<blocks(cap), PBLOCK, 0, st>>>(pd, shadow_slots);
     if (T) (void)hipEventRecord(ev[2], st);
-    k_trace_secondary<STACK, TWO_LEVEL><<<pgrid((size_t)cap * 2), PBLOCK, 0, st>>>(pd.sc, sec, pd.hit1, pd.inst1, &pd.counters[C_POOL_SECONDARY]);
-    k_compact_secondary<<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd);
+    k_trace_secondary<STACK, TWO_LEVEL><<<pgrid((size_t)cap * 2), PBLOCK, 0, st>>>(pd.sc, sec, pd.hit1, pd.inst1, &pd.counters[C_POOL_SECONDARY],
+                                                                                      &pd.counters[C_SECONDARY]);
+    k_compact_secondary<<<(2 * cap + CBLOCK - 1) / CBLOCK, CBLOCK, 0, st>>>(pd);
     if (T) (void)hipEventRecord(ev[3], st);
-    k_trace_shadow<STACK, TWO_LEVEL><<<pgrid((size_t)cap * shadow_slots), PBLOCK, 0, st>>>(pd.sc, sh0, pd.vis0, &pd.counters[C_POOL_SHADOW0]);
+    k_trace_shadow<STACK, TWO_LEVEL><<<pgrid((size_t)cap * shadow_slots), PBLOCK, 0, st>>>(pd.sc, sh0, pd.vis0, &pd.counters[C_POOL_SHADOW0],
+                                                                                               &pd.counters[C_SHADOW]);
     if (T) (void)hipEventRecord(ev[4], st);
     k_shade1_emit<<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd);
     if (T) (void)hipEventRecord(ev[5], st);
-    k_trace_shadow<STACK, TWO_LEVEL><<<pgrid((size_t)cap * 4), PBLOCK, 0, st>>>(pd.sc, sh1, pd.vis1, &pd.counters[C_POOL_SHADOW1]);
+    k_trace_shadow<STACK, TWO_LEVEL><<<pgrid((size_t)cap * 4), PBLOCK, 0, st>>>(pd.sc, sh1, pd.vis1, &pd.counters[C_POOL_SHADOW1],
+                                                                                    &pd.counters[C_SHADOW]);
     if (T) (void)hipEventRecord(ev[6], st);
     k_resolve<<<blocks(cap), PBLOCK, 0, st>>>(pd);
     if (T) { (void)hipEventRecord(ev[7], st); p->ring_pos++; }

@@ -64,8 +64,9 @@ RT_DEV unsigned long long lanemask_lt()
 //   struct Sink { void store(uint32_t i, const HitD &h, bool traced) const; };
 
 template <int STACK, int BLOCK, bool TWO_LEVEL, uint32_t CHUNK, class Src, class Sink>
-RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uint32_t *pool, int *smem)
+RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uint32_t *pool, int *smem, uint32_t *traced_counter)
 {
+    uint32_t n_traced = 0;           // rays this lane actually traversed (statistics)
     const uint32_t total = src.count();
     const uint32_t flags = src.flags();
     const bool first = (flags & RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH) != 0;
@@ -136,6 +137,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     sp = 0;
                     if (TWO_LEVEL) { slabs = sc.tlas_slabs; in_blas = false; }
                     alive = true;
+                    n_traced++;
                 } else {
                     sink.store(my, best, traced);
                 }
@@ -146,6 +148,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
             if (exhausted) break;
             continue;
         }
+
 
         // ---- walk internal nodes until this lane stands on a leaf (or runs dry) ----------
         while (alive && node_is_internal(node)) {
@@ -223,6 +226,10 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 else node = RT_NODE_EMPTY;
             }
         }
+    }
+    if (traced_counter) {            // one no-return atomic per persistent wave
+        for (int o = 32; o > 0; o >>= 1) n_traced += (uint32_t)__shfl_xor((int)n_traced, o, 64);
+        if ((threadIdx.x & 63u) == 0u && n_traced) atomicAdd(traced_counter, n_traced);
     }
 }
 
