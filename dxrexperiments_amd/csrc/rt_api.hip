@@ -123,9 +123,9 @@ static int context_create(int device, void *stream, bool own, rt_context **out)
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-        c->persistent_blocks = (uint32_t)prop.multiProcessorCount * 6u;
+        c->cu_count = (uint32_t)prop.multiProcessorCount;
     const char *pb = getenv("RT_PERSISTENT_BLOCKS_PER_CU");
-    if (pb && atoi(pb) >= 1 && atoi(pb) <= 16) c->persistent_blocks = c->persistent_blocks / 6u * (uint32_t)atoi(pb);
+    if (pb && atoi(pb) >= 1 && atoi(pb) <= 16) c->blocks_per_cu_override = (uint32_t)atoi(pb);
     const char *lm = getenv("RT_LEAF_MAX");
     if (lm) {
         int v = atoi(lm);

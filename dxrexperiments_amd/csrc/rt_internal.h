@@ -113,7 +113,8 @@ struct rt_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_trace_ms = 0.0f;
     uint32_t leaf_max = 4;       // triangles per collapsed leaf in the traversal layout
-    uint32_t persistent_blocks = 256 * 6;   // grid cap of the persistent traversal kernels (CUs x resident blocks)
+    uint32_t cu_count = 256;     // compute units of the device
+    uint32_t blocks_per_cu_override = 0;    // RT_PERSISTENT_BLOCKS_PER_CU: 0 = ask the occupancy API per kernel
     DevBuf pool;                 // ray-pool counters of rt_trace_batch
     DevBuf scratch[8];           // staging for host-pointer batch calls
 };
@@ -185,6 +186,20 @@ struct TraceOut {
 };
 int rt_launch_trace(rt_context *ctx, const rt_scene *s, const float4 *origin_tmin, const float4 *dir_tmax, size_t n,
                     uint32_t ray_flags, uint32_t kernel, const TraceOut &out);
+
+// Grid of a persistent traversal kernel: exactly the blocks that are resident at once (the static
+// chunk interleaving gives every launched wave its share of the queue, so a block that has to wait
+// for a slot would run its share as a serial tail).
+template <class K>
+static inline unsigned rt_persistent_grid(const rt_context *ctx, K kernel, int block, size_t rays)
+{
+    int per_cu = (int)ctx->blocks_per_cu_override;
+    if (per_cu <= 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    const size_t want = (rays + (size_t)block - 1) / (size_t)block;
+    const size_t cap = (size_t)ctx->cu_count * (size_t)per_cu;
+    return (unsigned)(want < cap ? (want ? want : 1) : cap);
+}
 
 // rt_api.hip
 void rt_context_retain(rt_context *ctx);

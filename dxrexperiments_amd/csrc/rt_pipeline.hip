@@ -710,8 +710,7 @@ void launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
     const bool T = p->ring_frames > 0;
     hipEvent_t *ev = T ? &p->ring[(size_t)(p->ring_pos % (uint64_t)p->ring_frames) * 8] : nullptr;
     const uint32_t cap = pd.cap;
-    const unsigned pmax = p->ctx->persistent_blocks;
-    auto pgrid = [pmax](size_t rays) { const size_t b = (rays + PBLOCK - 1) / PBLOCK; return (unsigned)(b < pmax ? (b ? b : 1) : pmax); };
+    const rt_context *ctx = p->ctx;
     const uint32_t any = RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH | RT_RAY_FLAG_SKIP_CLOSEST_HIT_SHADER;
     const QueueSrc sec = {pd.secO, pd.secD, &pd.counters[C_N0], cap, 2u, RT_RAY_FLAG_NONE};          // ProgressiveRaytracing.hlsl:53
     const QueueSrc sh0 = {pd.sh0O, pd.sh0D, &pd.counters[C_N0], cap, shadow_slots, any};              // RaytracingCommon.hlsli:94
@@ -723,16 +722,16 @@ void launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
     if (T) (void)hipEventRecord(ev[1], st);
     k_shade0_emit<<<blocks(cap), PBLOCK, 0, st>>>(pd, shadow_slots);
     if (T) (void)hipEventRecord(ev[2], st);
-    k_trace_secondary<STACK, TWO_LEVEL><<<pgrid((size_t)cap * 2), PBLOCK, 0, st>>>(pd.sc, sec, pd.hit1, pd.inst1, &pd.counters[C_POOL_SECONDARY],
+    k_trace_secondary<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_secondary<STACK, TWO_LEVEL>, PBLOCK, (size_t)cap * 2), PBLOCK, 0, st>>>(pd.sc, sec, pd.hit1, pd.inst1, &pd.counters[C_POOL_SECONDARY],
                                                                                       &pd.counters[C_SECONDARY]);
     k_compact_secondary<<<(2 * cap + CBLOCK - 1) / CBLOCK, CBLOCK, 0, st>>>(pd);
     if (T) (void)hipEventRecord(ev[3], st);
-    k_trace_shadow<STACK, TWO_LEVEL><<<pgrid((size_t)cap * shadow_slots), PBLOCK, 0, st>>>(pd.sc, sh0, pd.vis0, &pd.counters[C_POOL_SHADOW0],
+    k_trace_shadow<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL>, PBLOCK, (size_t)cap * shadow_slots), PBLOCK, 0, st>>>(pd.sc, sh0, pd.vis0, &pd.counters[C_POOL_SHADOW0],
                                                                                                &pd.counters[C_SHADOW]);
     if (T) (void)hipEventRecord(ev[4], st);
     k_shade1_emit<<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd);
     if (T) (void)hipEventRecord(ev[5], st);
-    k_trace_shadow<STACK, TWO_LEVEL><<<pgrid((size_t)cap * 4), PBLOCK, 0, st>>>(pd.sc, sh1, pd.vis1, &pd.counters[C_POOL_SHADOW1],
+    k_trace_shadow<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL>, PBLOCK, (size_t)cap * 4), PBLOCK, 0, st>>>(pd.sc, sh1, pd.vis1, &pd.counters[C_POOL_SHADOW1],
                                                                                     &pd.counters[C_SHADOW]);
     if (T) (void)hipEventRecord(ev[6], st);
     k_resolve<<<blocks(cap), PBLOCK, 0, st>>>(pd);
@@ -962,7 +961,8 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
     pd.sh1O = p->sh1O.as<float4>(); pd.sh1D = p->sh1D.as<float4>(); pd.vis1 = p->vis1.as<uint32_t>();
     HIP_TRY(hipMemsetAsync(pd.counters, 0, C_COUNT * 4, st));
     const uint32_t need = p->scene->stack_need;
-    if (need < 32) launch_frame_any<32>(p, pd, shadow_slots);
+    if (need < 24) launch_frame_any<24>(p, pd, shadow_slots);
+    else if (need < 31) launch_frame_any<31>(p, pd, shadow_slots);
     else if (need < 64) launch_frame_any<64>(p, pd, shadow_slots);
     else if (need < 160) launch_frame_any<160>(p, pd, shadow_slots);
     else { rt_set_error("traversal stack need %u exceeds 159 entries", need); return RT_ERR_UNSUPPORTED; }

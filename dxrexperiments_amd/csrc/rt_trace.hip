@@ -60,10 +60,12 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(SceneDev sc, BatchSr
 }
 
 template <int STACK>
-void launch_fast(bool two_level, unsigned grid, hipStream_t st, const SceneDev &sc, const BatchSrc &src, const BatchSink &sink, uint32_t *pool)
+void launch_fast(const rt_context *ctx, bool two_level, hipStream_t st, const SceneDev &sc, const BatchSrc &src, const BatchSink &sink, uint32_t *pool)
 {
-    if (two_level) k_trace_fast<STACK, true><<<grid, TRACE_BLOCK, 0, st>>>(sc, src, sink, pool);
-    else k_trace_fast<STACK, false><<<grid, TRACE_BLOCK, 0, st>>>(sc, src, sink, pool);
+    if (two_level)
+        k_trace_fast<STACK, true><<<rt_persistent_grid(ctx, k_trace_fast<STACK, true>, TRACE_BLOCK, src.n), TRACE_BLOCK, 0, st>>>(sc, src, sink, pool);
+    else
+        k_trace_fast<STACK, false><<<rt_persistent_grid(ctx, k_trace_fast<STACK, false>, TRACE_BLOCK, src.n), TRACE_BLOCK, 0, st>>>(sc, src, sink, pool);
 }
 
 }  // namespace
@@ -84,13 +86,12 @@ int rt_launch_trace(rt_context *ctx, const rt_scene *s, const float4 *o, const f
         HIP_TRY(hipMemsetAsync(ctx->pool.p, 0, 64, st));
         BatchSrc src = {o, d, (uint32_t)n, ray_flags};
         BatchSink sink = {out};
-        const size_t want = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
-        const unsigned grid = (unsigned)(want < ctx->persistent_blocks ? want : ctx->persistent_blocks);
         const uint32_t need = s->stack_need;
         HIP_TRY(hipEventRecord(ctx->ev0, st));
-        if (need < 32) launch_fast<32>(s->two_level, grid, st, sc, src, sink, ctx->pool.as<uint32_t>());
-        else if (need < 64) launch_fast<64>(s->two_level, grid, st, sc, src, sink, ctx->pool.as<uint32_t>());
-        else if (need < 160) launch_fast<160>(s->two_level, grid, st, sc, src, sink, ctx->pool.as<uint32_t>());
+        if (need < 24) launch_fast<24>(ctx, s->two_level, st, sc, src, sink, ctx->pool.as<uint32_t>());
+        else if (need < 31) launch_fast<31>(ctx, s->two_level, st, sc, src, sink, ctx->pool.as<uint32_t>());
+        else if (need < 64) launch_fast<64>(ctx, s->two_level, st, sc, src, sink, ctx->pool.as<uint32_t>());
+        else if (need < 160) launch_fast<160>(ctx, s->two_level, st, sc, src, sink, ctx->pool.as<uint32_t>());
         else {
             rt_set_error("traversal stack need %u exceeds 159 entries", need);
             return RT_ERR_UNSUPPORTED;
