@@ -29,8 +29,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 RAY_BYTES, NODE_BYTES, TRI_BYTES = 48, 32, 36   # 32 B ray in + 16 B hit out; node; triangle
-TRACE_STAGES = {"primary": ("ms_primary", "k_primary"), "secondary": ("ms_trace_secondary", "k_trace_secondary"),
-                "shadow0": ("ms_trace_shadow0", "k_trace_shadow"), "shadow1": ("ms_trace_shadow1", "k_trace_shadow")}
+# stage -> (rt_stats time fields, kernel, rt_pipeline_count_work stages whose rays the launch traces)
+TRACE_STAGES = {"primary": (("ms_primary",), "k_primary", ("primary",)),
+                "secondary": (("ms_trace_secondary",), "k_trace_secondary", ("secondary",)),
+                "shadow": (("ms_trace_shadow0", "ms_trace_shadow1"), "k_trace_shadow", ("shadow0", "shadow1"))}
 
 
 def parse():
@@ -192,10 +194,10 @@ def main():
             work = pipe.count_work()                       # canonical counters of the last frame's queues
             n_t = max(int(tot["frames"]), 1)
             stages = {}
-            for name, (key, kernel) in TRACE_STAGES.items():
-                w = work[name]
+            for name, (keys, kernel, parts) in TRACE_STAGES.items():
+                w = {k: sum(work[p][k] for p in parts) for k in ("rays", "nodes", "tris")}
                 b = RAY_BYTES * w["rays"] + NODE_BYTES * w["nodes"] + TRI_BYTES * w["tris"]
-                ms = tot[key] / n_t
+                ms = sum(tot[k] for k in keys) / n_t
                 stages[name] = {"kernel": kernel, "avg_ms": ms, "rays": w["rays"], "algorithmic_bytes": b,
                                 "nodes_per_ray": w["nodes"] / max(w["rays"], 1), "tris_per_ray": w["tris"] / max(w["rays"], 1),
                                 "GBps": b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,

@@ -492,11 +492,30 @@ struct SecondarySink {
     }
 };
 
+// every shadow ray of the frame in ONE launch: queue 0 (rays from first hits) then queue 1 (from second hits)
+struct ShadowSrc2 {
+    QueueSrc a, b;
+    RT_DEV uint32_t count() const { return a.count() + b.count(); }
+    RT_DEV uint32_t flags() const { return a.fl; }
+    RT_DEV bool load(uint32_t i, RayD &r) const { const uint32_t ca = a.count(); return i < ca ? a.load(i, r) : b.load(i - ca, r); }
+};
+struct ShadowSink2 {
+    ShadowSrc2 q;
+    uint32_t *vis_a, *vis_b;
+    RT_DEV void store(uint32_t i, const HitD &h, bool) const
+    {
+        const uint32_t ca = q.a.count();
+        const uint32_t v = h.inst == RT_NO_HIT ? 1u : 0u;
+        if (i < ca) vis_a[q.a.slot(i)] = v;
+        else vis_b[q.b.slot(i - ca)] = v;
+    }
+};
+
 template <int STACK, bool TWO_LEVEL>
-__global__ void __launch_bounds__(PBLOCK) k_trace_shadow(SceneDev sc, QueueSrc src, uint32_t *vis, uint32_t *pool, uint32_t *stat)
+__global__ void __launch_bounds__(PBLOCK) k_trace_shadow(SceneDev sc, ShadowSrc2 src, uint32_t *vis_a, uint32_t *vis_b, uint32_t *pool, uint32_t *stat)
 {
     __shared__ int smem[STACK * PBLOCK];
-    ShadowSink sink = {src, vis};
+    ShadowSink2 sink = {src, vis_a, vis_b};
     trace_wave<STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem, stat);
 }
 
@@ -725,14 +744,12 @@ void launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
     k_trace_secondary<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_secondary<STACK, TWO_LEVEL>, PBLOCK, (size_t)cap * 2), PBLOCK, 0, st>>>(pd.sc, sec, pd.hit1, pd.inst1, &pd.counters[C_POOL_SECONDARY],
                                                                                       &pd.counters[C_SECONDARY]);
     k_compact_secondary<<<(2 * cap + CBLOCK - 1) / CBLOCK, CBLOCK, 0, st>>>(pd);
-    if (T) (void)hipEventRecord(ev[3], st);
-    k_trace_shadow<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL>, PBLOCK, (size_t)cap * shadow_slots), PBLOCK, 0, st>>>(pd.sc, sh0, pd.vis0, &pd.counters[C_POOL_SHADOW0],
-                                                                                               &pd.counters[C_SHADOW]);
-    if (T) (void)hipEventRecord(ev[4], st);
+    if (T) { (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }      // (shadow stage 0 is merged into the launch below)
     k_shade1_emit<<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd);
     if (T) (void)hipEventRecord(ev[5], st);
-    k_trace_shadow<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL>, PBLOCK, (size_t)cap * 4), PBLOCK, 0, st>>>(pd.sc, sh1, pd.vis1, &pd.counters[C_POOL_SHADOW1],
-                                                                                    &pd.counters[C_SHADOW]);
+    const ShadowSrc2 shadows = {sh0, sh1};
+    k_trace_shadow<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL>, PBLOCK, (size_t)cap * (shadow_slots + 4)), PBLOCK, 0, st>>>(
+        pd.sc, shadows, pd.vis0, pd.vis1, &pd.counters[C_POOL_SHADOW0], &pd.counters[C_SHADOW]);
     if (T) (void)hipEventRecord(ev[6], st);
     k_resolve<<<blocks(cap), PBLOCK, 0, st>>>(pd);
     if (T) { (void)hipEventRecord(ev[7], st); p->ring_pos++; }
