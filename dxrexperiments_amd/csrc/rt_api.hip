@@ -126,6 +126,8 @@ static int context_create(int device, void *stream, bool own, rt_context **out)
         c->cu_count = (uint32_t)prop.multiProcessorCount;
     const char *pb = getenv("RT_PERSISTENT_BLOCKS_PER_CU");
     if (pb && atoi(pb) >= 1 && atoi(pb) <= 16) c->blocks_per_cu_override = (uint32_t)atoi(pb);
+    const char *fb = getenv("RT_FAST_BVH");
+    if (fb && strcmp(fb, "lbvh") == 0) c->use_ploc = false;
     const char *lm = getenv("RT_LEAF_MAX");
     if (lm) {
         int v = atoi(lm);

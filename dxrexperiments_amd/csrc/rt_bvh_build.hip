@@ -364,6 +364,8 @@ int rt_build_blas(rt_context *ctx, rt_model *m)
         if (n == 1) m->blas.root_code = ~(int)0;                                   // leaf(first 0, count 1)
         else if (n <= ctx->leaf_max) m->blas.root_code = ~(int)(n - 1);            // leaf(first 0, count n)
         else m->blas.root_code = 0;
+        // production traversal layout: re-cluster the same leaves with PLOC (rt_bvh_ploc.hip)
+        if (ctx->use_ploc && (rc = rt_build_ploc_layout(ctx, m)) != RT_OK) break;
         m->built = true;
     } while (0);
     boxes.release(); enc.release(); bounds.release(); tkeys.release(); tsort.release(); tenc.release(); tdepth.release();
@@ -465,6 +467,9 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
         // TLAS path and the sentinel that marks the bottom of a BLAS walk
         s->two_level = !(n == 1 && (s->h_inst[0].flags & RT_INST_IDENTITY));
         s->stack_need = s->two_level ? s->tlas.fast_depth + 1 + deepest : deepest;
+        if (getenv("RT_VERBOSE"))
+            fprintf(stderr, "[dxr_amd] TLAS %u instances depth %u; deepest BLAS layout depth %u (%s); stack need %u; %s walk\n", n,
+                    s->tlas.max_depth, deepest, ctx->use_ploc ? "PLOC" : "LBVH", s->stack_need, s->two_level ? "two-level" : "single-level");
     } while (0);
     boxes.release(); enc.release(); bounds.release(); tkeys.release(); tsort.release(); tenc.release(); tdepth.release();
     return rc;

@@ -1,0 +1,299 @@
+// rt_bvh_ploc.hip -- traversal-layout optimiser for a BLAS.
+//
+// The canonical acceleration structure (rt_bvh_build.hip) is an LBVH: fully determined,
+// index-exact against the oracle, but only spatial-median quality (~95 box tests per primary
+// ray on the Sponza-class scene).  Results do not depend on the tree that is walked (DESIGN.md
+// "Exactness rule"), so the PRODUCTION traversal is free to use a better hierarchy over the
+// same triangles.  This file builds one with PLOC (parallel locally-ordered clustering,
+// Meister & Bittner 2018): clusters start as the Morton-sorted leaves of the canonical tree;
+// every round each cluster finds, inside a window of +-RADIUS neighbours, the partner that
+// minimises the surface area of the merged box; mutual pairs merge; the cluster array is
+// compacted in order (scans, no atomics), until one cluster is left.  Node ids come from
+// prefix sums, so the build is run-to-run deterministic.
+//
+// Output: the same 64-B slab / 48-B triangle layout the traversal engine already walks
+// (rt_internal.h): triangles re-gathered in the depth-first order of the new tree so that every
+// subtree is a contiguous triangle range and subtrees of <= leaf_max triangles collapse to leaves.
+#include "rt_internal.h"
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+namespace {
+
+#ifndef RT_PLOC_RADIUS
+#define RT_PLOC_RADIUS 8
+#endif
+constexpr int PLOC_RADIUS = RT_PLOC_RADIUS;
+constexpr unsigned PB = 256;
+
+struct Box6 { float lo[3]; float hi[3]; };
+
+__device__ __forceinline__ float merged_area(const Box6 &a, const Box6 &b)
+{
+    const float dx = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]);
+    const float dy = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]);
+    const float dz = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// clusters start as the canonical leaves, in key order
+__global__ void k_ploc_init(const rt_bvh_node *__restrict__ nodes, uint32_t n, uint32_t *__restrict__ cl_node, Box6 *__restrict__ cl_box,
+                            uint32_t *__restrict__ size, uint32_t *__restrict__ parent)
+{
+    const uint32_t k = blockIdx.x * PB + threadIdx.x;
+    if (k >= n) return;
+    const rt_bvh_node nd = nodes[n - 1 + k];
+    Box6 b;
+    for (int c = 0; c < 3; c++) { b.lo[c] = nd.bmin[c]; b.hi[c] = nd.bmax[c]; }
+    cl_node[k] = k;                 // node ids: leaves 0..n-1 (key order), internal n..2n-2 (creation order)
+    cl_box[k] = b;
+    size[k] = 1;
+    parent[k] = 0xFFFFFFFFu;
+}
+
+// nearest neighbour inside the window, smallest merged area, ties -> lower index
+__global__ void __launch_bounds__(PB) k_ploc_nn(const Box6 *__restrict__ cl_box, uint32_t c, uint32_t *__restrict__ nn)
+{
+    __shared__ Box6 tile[PB + 2 * PLOC_RADIUS];
+    const int base = (int)(blockIdx.x * PB) - PLOC_RADIUS;
+    for (int t = threadIdx.x; t < (int)PB + 2 * PLOC_RADIUS; t += PB) {
+        const int g = base + t;
+        if (g >= 0 && g < (int)c) tile[t] = cl_box[g];
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * PB + threadIdx.x;
+    if (i >= c) return;
+    const Box6 me = tile[threadIdx.x + PLOC_RADIUS];
+    float best = __uint_as_float(0x7f800000u);
+    uint32_t arg = i;
+    for (int d = -PLOC_RADIUS; d <= PLOC_RADIUS; d++) {
+        const int j = (int)i + d;
+        if (d == 0 || j < 0 || j >= (int)c) continue;
+        const float a = merged_area(me, tile[threadIdx.x + PLOC_RADIUS + d]);
+        if (a < best) { best = a; arg = (uint32_t)j; }
+    }
+    nn[i] = arg;
+}
+
+__global__ void k_ploc_flags(const uint32_t *__restrict__ nn, uint32_t c, uint32_t *__restrict__ keep, uint32_t *__restrict__ merge)
+{
+    const uint32_t i = blockIdx.x * PB + threadIdx.x;
+    if (i >= c) return;
+    const uint32_t j = nn[i];
+    const bool mutual = j != i && nn[j] == i;
+    merge[i] = (mutual && i < j) ? 1u : 0u;        // the lower index of a mutual pair creates the node
+    keep[i] = (mutual && i > j) ? 0u : 1u;         // the higher index disappears
+}
+
+__global__ void k_ploc_apply(const uint32_t *__restrict__ nn, const uint32_t *__restrict__ keep, const uint32_t *__restrict__ merge,
+                             const uint32_t *__restrict__ keep_pos, const uint32_t *__restrict__ merge_pos, uint32_t c, uint32_t n,
+                             uint32_t next_node, const uint32_t *__restrict__ cl_node, const Box6 *__restrict__ cl_box,
+                             uint32_t *__restrict__ out_node, Box6 *__restrict__ out_box, uint32_t *__restrict__ left,
+                             uint32_t *__restrict__ right, Box6 *__restrict__ node_box, uint32_t *__restrict__ size,
+                             uint32_t *__restrict__ parent)
+{
+    const uint32_t i = blockIdx.x * PB + threadIdx.x;
+    if (i >= c || !keep[i]) return;
+    const uint32_t pos = keep_pos[i];
+    if (merge[i]) {
+        const uint32_t j = nn[i];
+        const uint32_t m = next_node + merge_pos[i];
+        const uint32_t a = cl_node[i], b = cl_node[j];
+        const Box6 ba = cl_box[i], bb = cl_box[j];
+        Box6 u;
+        for (int k = 0; k < 3; k++) { u.lo[k] = fminf(ba.lo[k], bb.lo[k]); u.hi[k] = fmaxf(ba.hi[k], bb.hi[k]); }
+        left[m - n] = a;
+        right[m - n] = b;
+        node_box[m] = u;
+        size[m] = size[a] + size[b];
+        parent[a] = m;
+        parent[b] = m;
+        parent[m] = 0xFFFFFFFFu;
+        out_node[pos] = m;
+        out_box[pos] = u;
+    } else {
+        out_node[pos] = cl_node[i];
+        out_box[pos] = cl_box[i];
+    }
+}
+
+// leaf boxes into node_box[0..n-1] so every node id indexes one box array
+__global__ void k_ploc_leaf_boxes(const Box6 *__restrict__ cl_box, uint32_t n, Box6 *__restrict__ node_box)
+{
+    const uint32_t k = blockIdx.x * PB + threadIdx.x;
+    if (k < n) node_box[k] = cl_box[k];
+}
+
+// depth-first offset of every node = number of leaves before it; depth of every leaf; and the
+// depth-first PRE-ORDER rank of every internal node among the internal nodes (a subtree of s leaves
+// holds s-1 of them), which becomes its slab index: a node's left child sits in the next slab, so
+// the two halves of a 128-B line are parent and child half of the time and subtrees are contiguous.
+__global__ void k_ploc_offsets(const uint32_t *__restrict__ left, const uint32_t *__restrict__ right, const uint32_t *__restrict__ size,
+                               const uint32_t *__restrict__ parent, uint32_t n, uint32_t *__restrict__ offset, uint32_t *__restrict__ slot,
+                               uint32_t *__restrict__ max_depth)
+{
+    const uint32_t id = blockIdx.x * PB + threadIdx.x;
+    uint32_t depth = 0;
+    if (id < 2 * n - 1) {
+        uint32_t off = 0, rank = 0, cur = id;
+        for (uint32_t p = parent[cur]; p != 0xFFFFFFFFu; p = parent[cur]) {
+            rank++;                                            // the ancestor itself precedes this node
+            if (right[p - n] == cur) {
+                const uint32_t sl = size[left[p - n]];
+                off += sl;
+                rank += sl - 1;                                // internal nodes of the left sibling subtree
+            }
+            cur = p;
+            depth++;
+        }
+        offset[id] = off;
+        if (id >= n) { slot[id - n] = rank; depth = 0; }      // only leaves vote for the depth
+    }
+    for (int o = 32; o > 0; o >>= 1) depth = max(depth, (uint32_t)__shfl_xor((int)depth, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(max_depth, depth);
+}
+
+__global__ void k_ploc_tris(const uint64_t *__restrict__ keys, const rt_vertex *__restrict__ verts, const uint32_t *__restrict__ idx,
+                            const uint32_t *__restrict__ offset, uint32_t n, TriRec *__restrict__ tris)
+{
+    const uint32_t k = blockIdx.x * PB + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t prim = (uint32_t)(keys[k] & 0xFFFFFFFFull);
+    const rt_float3 p0 = verts[idx[3 * prim + 0]].position;
+    const rt_float3 p1 = verts[idx[3 * prim + 1]].position;
+    const rt_float3 p2 = verts[idx[3 * prim + 2]].position;
+    TriRec t;
+    t.a = make_float4(p0.x, p0.y, p0.z, p1.x);
+    t.b = make_float4(p1.y, p1.z, p2.x, p2.y);
+    t.c = make_float4(p2.z, __uint_as_float(prim), 0.0f, 0.0f);
+    tris[offset[k]] = t;
+}
+
+__device__ __forceinline__ int ploc_code(uint32_t c, uint32_t n, const uint32_t *__restrict__ size, const uint32_t *__restrict__ offset,
+                                         const uint32_t *__restrict__ slot, uint32_t leaf_max)
+{
+    const uint32_t s = size[c];
+    if (c < n || s <= leaf_max) return ~(int)((offset[c] << 3) | (s - 1));
+    return (int)slot[c - n];
+}
+
+__global__ void k_ploc_slabs(const uint32_t *__restrict__ left, const uint32_t *__restrict__ right, const Box6 *__restrict__ node_box,
+                             const uint32_t *__restrict__ size, const uint32_t *__restrict__ offset, const uint32_t *__restrict__ slot,
+                             uint32_t n, uint32_t leaf_max, Slab *__restrict__ slabs)
+{
+    const uint32_t i = blockIdx.x * PB + threadIdx.x;
+    if (i >= n - 1) return;
+    const uint32_t l = left[i], r = right[i];
+    const Box6 a = node_box[l], b = node_box[r];
+    Slab s;
+    s.q0 = make_float4(a.lo[0], a.hi[0], a.lo[1], a.hi[1]);
+    s.q1 = make_float4(b.lo[0], b.hi[0], b.lo[1], b.hi[1]);
+    s.q2 = make_float4(a.lo[2], a.hi[2], b.lo[2], b.hi[2]);
+    s.q3 = make_float4(__int_as_float(ploc_code(l, n, size, offset, slot, leaf_max)),
+                       __int_as_float(ploc_code(r, n, size, offset, slot, leaf_max)), 0.0f, 0.0f);
+    slabs[slot[i]] = s;
+}
+
+inline unsigned gr(size_t n) { return (unsigned)((n + PB - 1) / PB); }
+
+}  // namespace
+
+// Rebuilds m->blas.slabs / m->tris / root_code / fast_depth from a PLOC tree.  The canonical arrays
+// (nodes, keys, parents) are left untouched.
+int rt_build_ploc_layout(rt_context *ctx, rt_model *m)
+{
+    const uint32_t n = m->n_tris;
+    if (n < 2 * ctx->leaf_max + 2) return RT_OK;          // tiny meshes: the LBVH layout is as good as any
+    hipStream_t st = ctx->stream;
+    DevBuf cl_node[2], cl_box[2], nn, keep, merge, keep_pos, merge_pos, left, right, node_box, size, parent, offset, slot, scan_tmp, depth;
+    int rc = RT_OK;
+    do {
+        const size_t nn2 = 2 * (size_t)n - 1;
+        for (int k = 0; k < 2 && rc == RT_OK; k++) {
+            rc = cl_node[k].reserve(4 * (size_t)n);
+            if (rc == RT_OK) rc = cl_box[k].reserve(sizeof(Box6) * (size_t)n);
+        }
+        DevBuf *u32s[] = {&nn, &keep, &merge, &keep_pos, &merge_pos};
+        for (DevBuf *b : u32s) if (rc == RT_OK) rc = b->reserve(4 * ((size_t)n + 1));
+        if (rc == RT_OK) rc = left.reserve(4 * (size_t)(n - 1));
+        if (rc == RT_OK) rc = right.reserve(4 * (size_t)(n - 1));
+        if (rc == RT_OK) rc = node_box.reserve(sizeof(Box6) * nn2);
+        if (rc == RT_OK) rc = size.reserve(4 * nn2);
+        if (rc == RT_OK) rc = parent.reserve(4 * nn2);
+        if (rc == RT_OK) rc = offset.reserve(4 * nn2);
+        if (rc == RT_OK) rc = slot.reserve(4 * (size_t)(n - 1));
+        if (rc == RT_OK) rc = depth.reserve(4);
+        if (rc != RT_OK) break;
+        size_t tmp_bytes = 0;
+        if (rocprim::exclusive_scan(nullptr, tmp_bytes, keep.as<uint32_t>(), keep_pos.as<uint32_t>(), 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st) != hipSuccess) {
+            rt_set_error("rocprim::exclusive_scan sizing failed");
+            rc = RT_ERR_HIP;
+            break;
+        }
+        if ((rc = scan_tmp.reserve(tmp_bytes)) != RT_OK) break;
+
+        k_ploc_init<<<gr(n), PB, 0, st>>>(m->blas.nodes.as<rt_bvh_node>(), n, cl_node[0].as<uint32_t>(), cl_box[0].as<Box6>(),
+                                         size.as<uint32_t>(), parent.as<uint32_t>());
+        k_ploc_leaf_boxes<<<gr(n), PB, 0, st>>>(cl_box[0].as<Box6>(), n, node_box.as<Box6>());
+        uint32_t c = n, next_node = n;
+        int cur = 0;
+        for (int round = 0; c > 1 && round < 4096; round++) {
+            k_ploc_nn<<<gr(c), PB, 0, st>>>(cl_box[cur].as<Box6>(), c, nn.as<uint32_t>());
+            k_ploc_flags<<<gr(c), PB, 0, st>>>(nn.as<uint32_t>(), c, keep.as<uint32_t>(), merge.as<uint32_t>());
+            // scans run over c+1 elements so that element c holds the totals (its input flag is garbage-free: set to 0)
+            (void)hipMemsetAsync(keep.as<uint32_t>() + c, 0, 4, st);
+            (void)hipMemsetAsync(merge.as<uint32_t>() + c, 0, 4, st);
+            size_t tb = tmp_bytes;
+            (void)rocprim::exclusive_scan(scan_tmp.p, tb, keep.as<uint32_t>(), keep_pos.as<uint32_t>(), 0u, (size_t)c + 1, rocprim::plus<uint32_t>(), st);
+            tb = tmp_bytes;
+            (void)rocprim::exclusive_scan(scan_tmp.p, tb, merge.as<uint32_t>(), merge_pos.as<uint32_t>(), 0u, (size_t)c + 1, rocprim::plus<uint32_t>(), st);
+            k_ploc_apply<<<gr(c), PB, 0, st>>>(nn.as<uint32_t>(), keep.as<uint32_t>(), merge.as<uint32_t>(), keep_pos.as<uint32_t>(),
+                                              merge_pos.as<uint32_t>(), c, n, next_node, cl_node[cur].as<uint32_t>(), cl_box[cur].as<Box6>(),
+                                              cl_node[cur ^ 1].as<uint32_t>(), cl_box[cur ^ 1].as<Box6>(), left.as<uint32_t>(),
+                                              right.as<uint32_t>(), node_box.as<Box6>(), size.as<uint32_t>(), parent.as<uint32_t>());
+            uint32_t totals[2];
+            if (hipMemcpyAsync(&totals[0], keep_pos.as<uint32_t>() + c, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(&totals[1], merge_pos.as<uint32_t>() + c, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) {
+                rt_set_error("PLOC round %d failed: %s", round, hipGetErrorString(hipGetLastError()));
+                rc = RT_ERR_HIP;
+                break;
+            }
+            if (totals[1] == 0 || totals[0] != c - totals[1]) {
+                rt_set_error("PLOC round %d made no progress (%u clusters, %u merges)", round, c, totals[1]);
+                rc = RT_ERR_STATE;
+                break;
+            }
+            c = totals[0];
+            next_node += totals[1];
+            cur ^= 1;
+        }
+        if (rc != RT_OK) break;
+        if (c != 1 || next_node != 2 * n - 1) {
+            rt_set_error("PLOC did not converge (%u clusters, %u nodes)", c, next_node);
+            rc = RT_ERR_STATE;
+            break;
+        }
+        (void)hipMemsetAsync(depth.p, 0, 4, st);
+        k_ploc_offsets<<<gr(nn2), PB, 0, st>>>(left.as<uint32_t>(), right.as<uint32_t>(), size.as<uint32_t>(), parent.as<uint32_t>(), n,
+                                              offset.as<uint32_t>(), slot.as<uint32_t>(), depth.as<uint32_t>());
+        k_ploc_tris<<<gr(n), PB, 0, st>>>(m->blas.keys.as<uint64_t>(), m->d_verts.as<rt_vertex>(), m->d_idx.as<uint32_t>(),
+                                         offset.as<uint32_t>(), n, m->tris.as<TriRec>());
+        k_ploc_slabs<<<gr(n - 1), PB, 0, st>>>(left.as<uint32_t>(), right.as<uint32_t>(), node_box.as<Box6>(), size.as<uint32_t>(),
+                                              offset.as<uint32_t>(), slot.as<uint32_t>(), n, ctx->leaf_max, m->blas.slabs.as<Slab>());
+        uint32_t d = 0;
+        if (hipMemcpyAsync(&d, depth.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
+            hipGetLastError() != hipSuccess) {
+            rt_set_error("PLOC layout kernels failed");
+            rc = RT_ERR_HIP;
+            break;
+        }
+        m->blas.fast_depth = d;
+        m->blas.root_code = 0;                             // pre-order: the root is slab 0
+    } while (0);
+    DevBuf *all[] = {&cl_node[0], &cl_node[1], &cl_box[0], &cl_box[1], &nn, &keep, &merge, &keep_pos, &merge_pos, &left, &right,
+                     &node_box, &size, &parent, &offset, &slot, &scan_tmp, &depth};
+    for (DevBuf *b : all) b->release();
+    return rc;
+}

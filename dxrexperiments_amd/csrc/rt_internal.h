@@ -113,6 +113,7 @@ struct rt_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_trace_ms = 0.0f;
     uint32_t leaf_max = 4;       // triangles per collapsed leaf in the traversal layout
+    bool use_ploc = true;        // RT_FAST_BVH=lbvh keeps the canonical LBVH as the traversal layout
     uint32_t cu_count = 256;     // compute units of the device
     uint32_t blocks_per_cu_override = 0;    // RT_PERSISTENT_BLOCKS_PER_CU: 0 = ask the occupancy API per kernel
     DevBuf pool;                 // ray-pool counters of rt_trace_batch
@@ -178,6 +179,9 @@ struct rt_scene {
 // rt_bvh_build.hip
 int rt_build_blas(rt_context *ctx, rt_model *m);
 int rt_build_tlas(rt_context *ctx, rt_scene *s);
+
+// rt_bvh_ploc.hip
+int rt_build_ploc_layout(rt_context *ctx, rt_model *m);
 
 // rt_trace.hip
 struct TraceOut {
