@@ -38,6 +38,10 @@ class StageWork(C.Structure):
 
 STAGES = ("primary", "secondary", "shadow0", "shadow1")
 
+PIPELINE_PROGRESSIVE, PIPELINE_REALTIME = 0, 1
+DENOISER_PARAMS = np.dtype([("exposure", "<f4"), ("gamma", "<f4"), ("tonemap", "<u4"), ("gammaCorrect", "<u4"),
+                            ("maxKernelSize", "<i4"), ("debugVisualize", "<u4")])
+
 # name -> (restype, argtypes); every symbol include/dxr_amd.h declares
 _p, _u32, _i, _f, _sz = C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_size_t
 _pp = C.POINTER(C.c_void_p)
@@ -52,6 +56,10 @@ SIGNATURES = {
     "rt_context_synchronize": (_i, [_p]),
     "rt_context_get_stream": (_i, [_p, _pp]),
     "rt_context_get_device": (_i, [_p, C.POINTER(_i)]),
+    "rt_device_alloc": (_i, [_p, _sz, _pp]),
+    "rt_device_free": (_i, [_p, _p]),
+    "rt_device_upload": (_i, [_p, _p, _p, _sz]),
+    "rt_device_download": (_i, [_p, _p, _p, _sz]),
     "rt_model_create_from_obj": (_i, [_p, C.c_char_p, _pp]),
     "rt_model_create_from_arrays": (_i, [_p, _p, _u32, _p, _u32, _pp]),
     "rt_model_get_counts": (_i, [_p, _pu, _pu]),
@@ -90,6 +98,17 @@ SIGNATURES = {
     "rt_pipeline_get_num_outputs": (_i, [_p, C.POINTER(_i)]),
     "rt_pipeline_get_output_device_ptr": (_i, [_p, _u32, _pp]),
     "rt_pipeline_read_output": (_i, [_p, _p, _sz]),
+    "rt_pipeline_read_output_n": (_i, [_p, _u32, _p, _sz]),
+    "rt_realtime_host_update": (_i, [_p, _p, _f, _u32, _u32, _u32, _p]),
+    "rt_denoiser_create": (_i, [_p, _pp]),
+    "rt_denoiser_destroy": (_i, [_p]),
+    "rt_denoiser_get_params": (_i, [_p, _pp]),
+    "rt_denoiser_create_output": (_i, [_p, _u32, _u32, _u32]),
+    "rt_denoiser_dispatch": (_i, [_p, _p, _p, _u32, _u32]),
+    "rt_denoiser_get_output_device_ptr": (_i, [_p, _pp]),
+    "rt_denoiser_read_output": (_i, [_p, _p, _sz]),
+    "rt_denoiser_read_intermediate": (_i, [_p, _p, _sz]),
+    "rt_denoiser_last_ms": (_i, [_p, C.POINTER(_f)]),
     "rt_pipeline_get_stats": (_i, [_p, C.POINTER(Stats)]),
     "rt_pipeline_enable_timing": (_i, [_p, _i]),
     "rt_pipeline_read_primary_hits": (_i, [_p, _p, _p, _p]),
@@ -174,6 +193,14 @@ class Context:
         _check(lib().rt_context_get_stream(self.h, C.byref(s)))
         return s.value or 0
 
+    def upload(self, array):
+        """Copy a numpy array into a fresh device buffer; returns a DeviceBuffer (freed on close / GC)."""
+        a = np.ascontiguousarray(array)
+        p = C.c_void_p()
+        _check(lib().rt_device_alloc(self.h, a.nbytes, C.byref(p)))
+        _check(lib().rt_device_upload(self.h, p, _ptr(a), a.nbytes))
+        return DeviceBuffer(self, p.value, a.nbytes)
+
     # device math probes (tests)
     def math(self, fn, x, y=None):
         x = _f32(x)
@@ -198,6 +225,23 @@ class Context:
         out = np.empty_like(dirs)
         _check(lib().rt_debug_sample_cube(self.h, _ptr(faces), faces.shape[1], _ptr(dirs), _ptr(out), dirs.shape[0]))
         return out
+
+
+class DeviceBuffer:
+    def __init__(self, ctx, ptr, nbytes):
+        self.ctx, self.ptr, self.nbytes = ctx, ptr, nbytes
+
+    def download(self, dtype=np.float32):
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype)
+        _check(lib().rt_device_download(self.ctx.h, _ptr(out), C.c_void_p(self.ptr), self.nbytes))
+        return out
+
+    def close(self):
+        if getattr(self, "ptr", None) and getattr(self.ctx, "h", None):
+            lib().rt_device_free(self.ctx.h, C.c_void_p(self.ptr))
+        self.ptr = None
+
+    __del__ = close
 
 
 class Model:
@@ -309,12 +353,14 @@ class Scene:
 
 
 class Pipeline:
-    """ProgressiveRaytracingPipeline (include/ProgressiveRaytracingPipeline.h:15-78)."""
+    """ProgressiveRaytracingPipeline (include/ProgressiveRaytracingPipeline.h:15-78) or, with
+    kind=PIPELINE_REALTIME, RealtimeRaytracingPipeline (include/RealtimeRaytracingPipeline.h:15-74)."""
 
-    def __init__(self, ctx):
+    def __init__(self, ctx, kind=PIPELINE_PROGRESSIVE):
         self.ctx = ctx
+        self.kind = kind
         h = C.c_void_p()
-        _check(lib().rt_pipeline_create(ctx.h, 0, C.byref(h)))
+        _check(lib().rt_pipeline_create(ctx.h, kind, C.byref(h)))
         self.h = h
         self.width = self.height = 0
         self.format = T.FORMAT_R32G32B32A32_FLOAT
@@ -386,17 +432,23 @@ class Pipeline:
         else:
             _check(lib().rt_pipeline_render_tile(self.h, self.width, self.height, *tile))
 
-    def output_device_ptr(self):
+    @property
+    def num_outputs(self):
+        n = C.c_int()
+        _check(lib().rt_pipeline_get_num_outputs(self.h, C.byref(n)))
+        return n.value
+
+    def output_device_ptr(self, output=0):
         p = C.c_void_p()
-        _check(lib().rt_pipeline_get_output_device_ptr(self.h, 0, C.byref(p)))
+        _check(lib().rt_pipeline_get_output_device_ptr(self.h, output, C.byref(p)))
         return p.value
 
-    def read_output(self):
+    def read_output(self, output=0):
         if self.format == T.FORMAT_R16G16B16A16_FLOAT:
             out = np.empty((self.height, self.width, 4), np.float16)
         else:
             out = np.empty((self.height, self.width, 4), np.float32)
-        _check(lib().rt_pipeline_read_output(self.h, _ptr(out), out.nbytes))
+        _check(lib().rt_pipeline_read_output_n(self.h, output, _ptr(out), out.nbytes))
         return out
 
     def enable_timing(self, frames=1):
@@ -481,3 +533,66 @@ class ProgressiveHost:
         out = np.zeros((), T.PER_FRAME_CONSTANTS)
         _check(lib().rt_progressive_host_update(self.h, _ptr(cam), elapsed_time, elapsed_frames, width, height, _ptr(out)))
         return out
+
+    def update_realtime(self, camera11, elapsed_time, elapsed_frames, width, height):
+        """RealtimeRaytracingPipeline::update (src/RealtimeRaytracingPipeline.cpp:168-199)."""
+        cam = _f32(camera11, 11)
+        out = np.zeros((), T.PER_FRAME_CONSTANTS)
+        _check(lib().rt_realtime_host_update(self.h, _ptr(cam), elapsed_time, elapsed_frames, width, height, _ptr(out)))
+        return out
+
+
+class Denoiser:
+    """DenoiseCompositor (include/DenoiseCompositor.h:5-59)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        _check(lib().rt_denoiser_create(ctx.h, C.byref(h)))
+        self.h = h
+        self.width = self.height = 0
+        self.format = T.FORMAT_R32G32B32A32_FLOAT
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rt_denoiser_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    @property
+    def params(self):
+        """Live numpy view (DENOISER_PARAMS record) of the constant buffer."""
+        p = C.c_void_p()
+        _check(lib().rt_denoiser_get_params(self.h, C.byref(p)))
+        buf = (C.c_uint8 * DENOISER_PARAMS.itemsize).from_address(p.value)
+        return np.frombuffer(buf, dtype=DENOISER_PARAMS, count=1)
+
+    def create_output(self, width, height, fmt=T.FORMAT_R32G32B32A32_FLOAT):
+        _check(lib().rt_denoiser_create_output(self.h, fmt, width, height))
+        self.width, self.height, self.format = width, height, fmt
+
+    def dispatch(self, direct_ptr, indirect_ptr):
+        _check(lib().rt_denoiser_dispatch(self.h, C.c_void_p(direct_ptr), C.c_void_p(indirect_ptr), self.width, self.height))
+
+    def _read(self, fn):
+        dt = np.float16 if self.format == T.FORMAT_R16G16B16A16_FLOAT else np.float32
+        out = np.empty((self.height, self.width, 4), dt)
+        _check(fn(self.h, _ptr(out), out.nbytes))
+        return out
+
+    def read_output(self):
+        return self._read(lib().rt_denoiser_read_output)
+
+    def read_intermediate(self):
+        return self._read(lib().rt_denoiser_read_intermediate)
+
+    def output_device_ptr(self):
+        p = C.c_void_p()
+        _check(lib().rt_denoiser_get_output_device_ptr(self.h, C.byref(p)))
+        return p.value
+
+    def last_ms(self):
+        ms = C.c_float()
+        _check(lib().rt_denoiser_last_ms(self.h, C.byref(ms)))
+        return ms.value

@@ -194,6 +194,45 @@ int rt_context_get_device(rt_context *ctx, int *device_out)
     return RT_OK;
 }
 
+int rt_device_alloc(rt_context *ctx, size_t bytes, void **device_ptr)
+{
+    RT_REQUIRE(ctx && device_ptr, "null argument");
+    RT_TRY(use_device(ctx));
+    hipError_t e = hipMalloc(device_ptr, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        rt_set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP;
+    }
+    return RT_OK;
+}
+
+int rt_device_free(rt_context *ctx, void *device_ptr)
+{
+    RT_REQUIRE(ctx, "null context");
+    RT_TRY(use_device(ctx));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (device_ptr) HIP_TRY(hipFree(device_ptr));
+    return RT_OK;
+}
+
+int rt_device_upload(rt_context *ctx, void *device_dst, const void *host_src, size_t bytes)
+{
+    RT_REQUIRE(ctx && (bytes == 0 || (device_dst && host_src)), "null argument");
+    RT_TRY(use_device(ctx));
+    if (bytes) HIP_TRY(hipMemcpyAsync(device_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_device_download(rt_context *ctx, void *host_dst, const void *device_src, size_t bytes)
+{
+    RT_REQUIRE(ctx && (bytes == 0 || (host_dst && device_src)), "null argument");
+    RT_TRY(use_device(ctx));
+    if (bytes) HIP_TRY(hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
 // ---- model -----------------------------------------------------------------------
 
 static int model_finish(rt_context *ctx, rt_model *m, rt_model **out)

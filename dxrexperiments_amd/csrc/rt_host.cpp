@@ -166,4 +166,15 @@ int rt_progressive_host_update(rt_progressive_host *h, const float camera[11], f
     return RT_OK;
 }
 
+int rt_realtime_host_update(rt_progressive_host *h, const float camera[11], float elapsed_time, uint32_t elapsed_frames,
+                            uint32_t width, uint32_t height, rt_per_frame_constants *out)
+{
+    RT_TRY(rt_progressive_host_update(h, camera, elapsed_time, elapsed_frames, width, height, out));
+    h->accum_count = 0;
+    out->cameraParams.accumCount = 0;                         // RealtimeRaytracingPipeline.cpp:182
+    memset(&out->options, 0, sizeof out->options);
+    out->options.environmentStrength = 1.0f;                  // :197
+    return RT_OK;
+}
+
 }  // extern "C"

@@ -57,7 +57,9 @@ struct PipeDev {
     uint32_t tiles_x;
     uint32_t max_rad, max_shadow;
     uint32_t accum_mode;
+    uint32_t kind;                      // RT_PIPELINE_PROGRESSIVE / RT_PIPELINE_REALTIME
     float4 *accum;
+    float4 *aov_direct, *aov_indirect;  // realtime pipeline outputs (RealtimeRaytracing.hlsl:3-4)
     float4 *hit0; uint32_t *inst0;
     uint32_t *pix_k, *klist;
     uint32_t *counters;
@@ -121,7 +123,8 @@ RT_DEV RayD primary_ray(const PipeDev &pd, uint32_t px, uint32_t py)
     const rt_camera_params &cp = pd.pfc.cameraParams;
     const float dx = ((float)px + 0.5f) / (float)pd.width * 2.0f - 1.0f;
     const float dy = ((float)py + 0.5f) / (float)pd.height * 2.0f - 1.0f;
-    const float jx = cp.jitters.x * 30.0f, jy = cp.jitters.y * 30.0f;
+    const float js = pd.kind == RT_PIPELINE_REALTIME ? 10.0f : 30.0f;   // ProgressiveRaytracing.hlsl:26 / RealtimeRaytracing.hlsl:33
+    const float jx = cp.jitters.x * js, jy = cp.jitters.y * js;
     RayD r;
     r.o = mk3(cp.worldEyePos.x + jx, cp.worldEyePos.y + jy, cp.worldEyePos.z + 0.0f);
     f3 dir = mk3(cp.U.x, cp.U.y, cp.U.z) * dx;
@@ -255,16 +258,60 @@ RT_DEV f3 shade(const PipeDev &pd, IO &io, const rt_material_params &mp, f3 P, f
     return r;
 }
 
-// PrimaryClosestHit (ProgressiveRaytracing.hlsl:150-158) for a stored hit
+// shadeAOV of the realtime pipeline (RealtimeRaytracing.hlsl:65-103): direct light + one Phong-lobe
+// bounce, split into the two AOVs the denoiser consumes (written at depth 0 only)
 template <class IO>
-RT_DEV f3 closest_hit(const PipeDev &pd, IO &io, const RayD &r, float t, float u, float v, uint32_t prim, uint32_t inst,
-                      uint32_t depth, uint32_t pix)
+RT_DEV f3 shade_aov(const PipeDev &pd, IO &io, const rt_material_params &mp, f3 P, f3 N, f3 D, uint32_t depth, uint32_t pix,
+                    f3 &aov_direct, f3 &aov_indirect)
+{
+    uint32_t seed = init_rand(pix, pd.pfc.cameraParams.frameCount);
+    f3 direct = mk3(0.0f, 0.0f, 0.0f);
+    direct = direct + directional_light(pd, io, P, N, depth);
+    direct = direct + point_light(pd, io, P, N, depth);
+    f3 fresnel = mk3(0.0f, 0.0f, 0.0f);
+    f3 specular = mk3(0.0f, 0.0f, 0.0f);
+    if (mp.type == 1u || mp.type == 2u) {
+        if (mp.reflectivity > 0.001f) {
+            const float exponent = exp_det((1.0f - mp.roughness) * 12.0f);
+            float pdf, brdf;
+            const f3 mirror = reflect(D, N);
+            const f3 dir = phong_lobe(seed, mirror, exponent, pdf, brdf);
+            const f3 refl = io.secondary(1, P, dir, RAY_EPSILON, depth);
+            specular = specular + refl * brdf / pdf;
+            fresnel = fresnel_schlick(D, N, mk3(mp.specular.x, mp.specular.y, mp.specular.z));
+        }
+    }
+    const f3 albedo = mk3(mp.albedo.x, mp.albedo.y, mp.albedo.z);
+    const f3 dl = albedo * direct / HLSL_PI;
+    const f3 is = specular * mp.reflectivity * fresnel;
+    if (depth == 0) { aov_direct = dl; aov_indirect = is; }
+    return dl + is;
+}
+
+struct Shaded { f3 color, aov_direct, aov_indirect; };
+
+// PrimaryClosestHit (ProgressiveRaytracing.hlsl:150-158, RealtimeRaytracing.hlsl:105-117) for a stored hit
+template <class IO>
+RT_DEV Shaded closest_hit_aov(const PipeDev &pd, IO &io, const RayD &r, float t, float u, float v, uint32_t prim, uint32_t inst,
+                              uint32_t depth, uint32_t pix)
 {
     const InstanceRec &in = pd.sc.inst[inst];
     const f3 N = normalize(hit_normal(in, prim, u, v));
     const f3 P = r.o + r.d * t;
     const rt_material_params mp = pd.mats[min(inst, pd.nmats - 1u)];
-    return shade(pd, io, mp, P, N, r.d, depth, pix);
+    Shaded s;
+    s.aov_direct = mk3(0.0f, 0.0f, 0.0f);
+    s.aov_indirect = mk3(0.0f, 0.0f, 0.0f);
+    if (pd.kind == RT_PIPELINE_REALTIME) s.color = shade_aov(pd, io, mp, P, N, r.d, depth, pix, s.aov_direct, s.aov_indirect);
+    else s.color = shade(pd, io, mp, P, N, r.d, depth, pix);
+    return s;
+}
+
+template <class IO>
+RT_DEV f3 closest_hit(const PipeDev &pd, IO &io, const RayD &r, float t, float u, float v, uint32_t prim, uint32_t inst,
+                      uint32_t depth, uint32_t pix)
+{
+    return closest_hit_aov(pd, io, r, t, u, v, prim, inst, depth, pix).color;
 }
 
 RT_DEV void store_ray(float4 *O, float4 *D, size_t slot, f3 o, float tmin, f3 d, float tmax)
@@ -569,14 +616,24 @@ __global__ void __launch_bounds__(PBLOCK) k_resolve(PipeDev pd)
     if (!pix_xy(pd, q, px, py)) return;
     const RayD r = primary_ray(pd, px, py);
     const float4 h = pd.hit0[q];
-    f3 c;
-    if (h.x == HIT_MISS) c = sample_environment(pd, r.d);
-    else {
+    Shaded sh;
+    if (h.x == HIT_MISS) {
+        sh.color = sample_environment(pd, r.d);             // PrimaryMiss
+        sh.aov_direct = sh.color;                           // RealtimeRaytracing.hlsl:119-126
+        sh.aov_indirect = mk3(0.0f, 0.0f, 0.0f);
+    } else {
         ResolveIO0 io(pd, pd.pix_k[q], px + py * pd.width);
-        c = closest_hit(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.inst0[q], 0u, px + py * pd.width);
+        sh = closest_hit_aov(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.inst0[q], 0u, px + py * pd.width);
     }
+    const size_t pixel = (size_t)py * pd.width + px;
+    if (pd.kind == RT_PIPELINE_REALTIME) {                  // RealtimeRaytracing.hlsl:44-45: two AOVs, no accumulation
+        pd.aov_direct[pixel] = make_float4(fmax2(sh.aov_direct.x, 0.0f), fmax2(sh.aov_direct.y, 0.0f), fmax2(sh.aov_direct.z, 0.0f), 1.0f);
+        pd.aov_indirect[pixel] = make_float4(fmax2(sh.aov_indirect.x, 0.0f), fmax2(sh.aov_indirect.y, 0.0f), fmax2(sh.aov_indirect.z, 0.0f), 1.0f);
+        return;
+    }
+    const f3 c = sh.color;
     const float4 cur = make_float4(fmax2(c.x, 0.0f), fmax2(c.y, 0.0f), fmax2(c.z, 0.0f), 1.0f);
-    float4 *dst = pd.accum + (size_t)py * pd.width + px;
+    float4 *dst = pd.accum + pixel;
     const float4 prev = *dst;
     float4 o;
     if (pd.accum_mode == RT_ACCUM_SUM) {
@@ -674,6 +731,8 @@ inline unsigned blocks(size_t n) { return (unsigned)((n + PBLOCK - 1) / PBLOCK);
 
 struct rt_pipeline {
     rt_context *ctx = nullptr;
+    uint32_t kind = RT_PIPELINE_PROGRESSIVE;
+    DevBuf aov_own;                    // realtime: second output (indirect specular); the first lives in accum_own
     rt_scene *scene = nullptr;
     std::vector<rt_material_params> mats;
     DevBuf d_mats;
@@ -770,10 +829,11 @@ extern "C" {
 int rt_pipeline_create(rt_context *ctx, uint32_t kind, rt_pipeline **out)
 {
     RT_REQUIRE(ctx && out, "null argument");
-    RT_REQUIRE(kind == RT_PIPELINE_PROGRESSIVE, "only RT_PIPELINE_PROGRESSIVE exists");
+    RT_REQUIRE(kind == RT_PIPELINE_PROGRESSIVE || kind == RT_PIPELINE_REALTIME, "unknown pipeline kind");
     rt_pipeline *p = new (std::nothrow) rt_pipeline();
     if (!p) { rt_set_error("out of host memory"); return RT_ERR_OOM; }
     p->ctx = ctx;
+    p->kind = kind;
     rt_context_retain(ctx);
     memset(&p->pfc, 0, sizeof p->pfc);
     memset(&p->stats, 0, sizeof p->stats);
@@ -786,7 +846,7 @@ int rt_pipeline_destroy(rt_pipeline *p)
     if (!p) return RT_OK;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    DevBuf *all[] = {&p->d_mats, &p->d_env, &p->accum_own, &p->hit0, &p->inst0, &p->pix_k, &p->klist, &p->counters, &p->secO, &p->secD,
+    DevBuf *all[] = {&p->d_mats, &p->d_env, &p->accum_own, &p->aov_own, &p->hit0, &p->inst0, &p->pix_k, &p->klist, &p->counters, &p->secO, &p->secD,
                      &p->hit1, &p->inst1, &p->slot_j, &p->jlist, &p->sh0O, &p->sh0D, &p->vis0, &p->sh1O, &p->sh1D, &p->vis1, &p->half_out,
                      &p->totals, &p->work};
     for (DevBuf *b : all) b->release();
@@ -798,7 +858,11 @@ int rt_pipeline_destroy(rt_pipeline *p)
     return RT_OK;
 }
 
-const char *rt_pipeline_get_name(const rt_pipeline *) { return "Progressive Ray Tracing Pipeline"; }
+const char *rt_pipeline_get_name(const rt_pipeline *p)
+{
+    // include/ProgressiveRaytracingPipeline.h:40, include/RealtimeRaytracingPipeline.h:40
+    return p && p->kind == RT_PIPELINE_REALTIME ? "Realtime Ray Tracing Pipeline" : "Progressive Ray Tracing Pipeline";
+}
 
 int rt_pipeline_set_scene(rt_pipeline *p, rt_scene *s)
 {
@@ -863,6 +927,7 @@ int rt_pipeline_create_output(rt_pipeline *p, uint32_t format, uint32_t width, u
     RT_REQUIRE(format == RT_FORMAT_R32G32B32A32_FLOAT || format == RT_FORMAT_R16G16B16A16_FLOAT, "unsupported output format");
     HIP_TRY(hipSetDevice(p->ctx->device));
     RT_TRY(p->accum_own.reserve((size_t)width * height * 16));
+    if (p->kind == RT_PIPELINE_REALTIME) RT_TRY(p->aov_own.reserve((size_t)width * height * 16));     // kNumOutputResources = 2
     p->accum = p->accum_own.as<float4>();
     p->width = width; p->height = height; p->format = format;
     return rt_pipeline_clear_output(p);
@@ -872,6 +937,7 @@ int rt_pipeline_bind_output(rt_pipeline *p, void *device_rgba32f, uint32_t width
 {
     RT_REQUIRE(p && device_rgba32f, "null argument");
     RT_REQUIRE(width > 0 && height > 0, "empty output");
+    RT_REQUIRE(p->kind == RT_PIPELINE_PROGRESSIVE, "bind_output: only the progressive pipeline renders into caller memory");
     p->accum = (float4 *)device_rgba32f;
     p->width = width; p->height = height; p->format = RT_FORMAT_R32G32B32A32_FLOAT;
     return RT_OK;
@@ -911,6 +977,7 @@ int rt_pipeline_clear_output(rt_pipeline *p)
     if (!p->accum) { rt_set_error("no output resource"); return RT_ERR_STATE; }
     HIP_TRY(hipSetDevice(p->ctx->device));
     HIP_TRY(hipMemsetAsync(p->accum, 0, (size_t)p->width * p->height * 16, p->ctx->stream));
+    if (p->aov_own.p) HIP_TRY(hipMemsetAsync(p->aov_own.p, 0, (size_t)p->width * p->height * 16, p->ctx->stream));
     return RT_OK;
 }
 
@@ -938,7 +1005,7 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
     hipStream_t st = ctx->stream;
     p->rendered = false;
     // RayGen early-out (ProgressiveRaytracing.hlsl:14-16): nothing is traced or written
-    if (p->pfc.cameraParams.accumCount >= p->pfc.options.maxIterations) {
+    if (p->kind == RT_PIPELINE_PROGRESSIVE && p->pfc.cameraParams.accumCount >= p->pfc.options.maxIterations) {
         memset(&p->stats, 0, sizeof p->stats);
         return RT_OK;
     }
@@ -949,7 +1016,7 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
     }
     const uint32_t tw = x1 - x0, th = y1 - y0;
     const uint32_t tiles_x = (tw + 7u) / 8u, cap = tiles_x * ((th + 7u) / 8u) * 64u;
-    const uint32_t shadow_slots = p->pfc.options.showAmbientOcclusionOnly ? 4u : 2u;
+    const uint32_t shadow_slots = (p->kind == RT_PIPELINE_PROGRESSIVE && p->pfc.options.showAmbientOcclusionOnly) ? 4u : 2u;
     RT_TRY(ensure_queues(p, cap, shadow_slots));
     if (!p->totals.p) {
         RT_TRY(p->totals.reserve(8 * sizeof(unsigned long long)));
@@ -967,7 +1034,10 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
     pd.x0 = x0; pd.y0 = y0; pd.tw = tw; pd.th = th; pd.cap = cap; pd.tiles_x = tiles_x;
     pd.max_rad = p->max_rad; pd.max_shadow = p->max_shadow;
     pd.accum_mode = p->accum_mode;
+    pd.kind = p->kind;
     pd.accum = p->accum;
+    pd.aov_direct = p->accum;                       // realtime: output 0 = direct lighting, output 1 = indirect specular
+    pd.aov_indirect = p->aov_own.as<float4>();
     pd.hit0 = p->hit0.as<float4>(); pd.inst0 = p->inst0.as<uint32_t>();
     pd.pix_k = p->pix_k.as<uint32_t>(); pd.klist = p->klist.as<uint32_t>();
     pd.counters = p->counters.as<uint32_t>();
@@ -999,37 +1069,41 @@ int rt_pipeline_render(rt_pipeline *p, uint32_t width, uint32_t height)
 int rt_pipeline_get_num_outputs(const rt_pipeline *p, int *n)
 {
     RT_REQUIRE(p && n, "null argument");
-    *n = 1;
+    *n = p->kind == RT_PIPELINE_REALTIME ? 2 : 1;
     return RT_OK;
 }
 
 int rt_pipeline_get_output_device_ptr(rt_pipeline *p, uint32_t id, void **ptr)
 {
     RT_REQUIRE(p && ptr, "null argument");
-    RT_REQUIRE(id == 0, "the progressive pipeline has one output");
-    *ptr = p->accum;
+    RT_REQUIRE(id < (p->kind == RT_PIPELINE_REALTIME ? 2u : 1u), "output index out of range");
+    *ptr = id == 0 ? (void *)p->accum : p->aov_own.p;
     return RT_OK;
 }
 
-int rt_pipeline_read_output(rt_pipeline *p, void *host, size_t bytes)
+int rt_pipeline_read_output_n(rt_pipeline *p, uint32_t id, void *host, size_t bytes)
 {
     RT_REQUIRE(p && host, "null argument");
-    if (!p->accum) { rt_set_error("no output resource"); return RT_ERR_STATE; }
+    RT_REQUIRE(id < (p->kind == RT_PIPELINE_REALTIME ? 2u : 1u), "output index out of range");
+    const float4 *src = id == 0 ? p->accum : p->aov_own.as<float4>();
+    if (!src) { rt_set_error("no output resource"); return RT_ERR_STATE; }
     HIP_TRY(hipSetDevice(p->ctx->device));
     const size_t npix = (size_t)p->width * p->height;
     hipStream_t st = p->ctx->stream;
     if (p->format == RT_FORMAT_R16G16B16A16_FLOAT) {
         RT_REQUIRE(bytes == npix * 8, "host buffer must be width*height*8 bytes for RGBA16F");
         RT_TRY(p->half_out.reserve(npix * 8));
-        k_f32_to_f16<<<blocks(npix), PBLOCK, 0, st>>>(p->accum, p->half_out.as<ushort4>(), npix);
+        k_f32_to_f16<<<blocks(npix), PBLOCK, 0, st>>>(src, p->half_out.as<ushort4>(), npix);
         HIP_TRY(hipMemcpyAsync(host, p->half_out.p, bytes, hipMemcpyDeviceToHost, st));
     } else {
         RT_REQUIRE(bytes == npix * 16, "host buffer must be width*height*16 bytes for RGBA32F");
-        HIP_TRY(hipMemcpyAsync(host, p->accum, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
     return RT_OK;
 }
+
+int rt_pipeline_read_output(rt_pipeline *p, void *host, size_t bytes) { return rt_pipeline_read_output_n(p, 0, host, bytes); }
 
 int rt_pipeline_enable_timing(rt_pipeline *p, int frames)
 {

@@ -57,6 +57,14 @@ int rt_context_synchronize(rt_context *ctx);
 int rt_context_get_stream(rt_context *ctx, void **hip_stream_out);
 int rt_context_get_device(rt_context *ctx, int *device_out);
 
+/* Plain device buffers on the context's GPU (CreateBuffer / AllocateUploadBuffer of
+ * Helpers/DirectXRaytracingHelper.h:187-208): for callers that feed device pointers to
+ * rt_trace_batch(RT_MEM_DEVICE) or rt_denoiser_dispatch without another runtime. */
+int rt_device_alloc(rt_context *ctx, size_t bytes, void **device_ptr);
+int rt_device_free(rt_context *ctx, void *device_ptr);
+int rt_device_upload(rt_context *ctx, void *device_dst, const void *host_src, size_t bytes);     /* synchronous */
+int rt_device_download(rt_context *ctx, void *host_dst, const void *device_src, size_t bytes);   /* synchronous */
+
 /* ---- RtModel (libs/DXRFramework/RtModel.h:13, RtModel.cpp:24-118) ---------- */
 
 /* RtModel::create(ctx, filePath) (RtModel.h:13).  Wavefront OBJ only; see
@@ -116,6 +124,10 @@ int rt_trace_last_ms(rt_context *ctx, float *ms);
  *       src/ProgressiveRaytracingPipeline.cpp) ------------------------------- */
 
 #define RT_PIPELINE_PROGRESSIVE 0u
+/* RealtimeRaytracingPipeline (include/RealtimeRaytracingPipeline.h:15-74, src/RealtimeRaytracingPipeline.cpp,
+ * assets/shaders/RealtimeRaytracing.hlsl): same traversal and lights, one Phong-lobe bounce, no accumulation,
+ * two outputs: 0 = direct lighting, 1 = indirect specular (the DenoiseCompositor's inputs) */
+#define RT_PIPELINE_REALTIME    1u
 
 int rt_pipeline_create(rt_context *ctx, uint32_t kind, rt_pipeline **out);   /* ::create  ProgressiveRaytracingPipeline.h:19 */
 int rt_pipeline_destroy(rt_pipeline *p);
@@ -150,6 +162,7 @@ int rt_pipeline_get_num_outputs(const rt_pipeline *p, int *n);               /* 
 int rt_pipeline_get_output_device_ptr(rt_pipeline *p, uint32_t id, void **ptr); /* getOutputResource .h:35 */
 /* synchronises; host buffer is w*h*4 floats (RGBA32F) or halfs (RGBA16F) */
 int rt_pipeline_read_output(rt_pipeline *p, void *host, size_t bytes);
+int rt_pipeline_read_output_n(rt_pipeline *p, uint32_t id, void *host, size_t bytes);   /* output id < getNumOutputs() */
 /* synchronises; stage timings need rt_pipeline_enable_timing(p, frames > 0): HIP events
  * are recorded around every stage kernel on the context stream, in a ring that
  * remembers the last `frames` frames */
@@ -181,6 +194,35 @@ int rt_progressive_host_reset(rt_progressive_host *h);                      /* f
 int rt_progressive_host_update(rt_progressive_host *h, const float camera[11], float elapsed_time,
                                uint32_t elapsed_frames, uint32_t width, uint32_t height,
                                rt_per_frame_constants *out);                /* update :177-213 */
+
+/* RealtimeRaytracingPipeline::update (src/RealtimeRaytracingPipeline.cpp:168-199): as above but accumCount = 0 and
+ * options = { environmentStrength 1, rest 0 } */
+int rt_realtime_host_update(rt_progressive_host *h, const float camera[11], float elapsed_time,
+                            uint32_t elapsed_frames, uint32_t width, uint32_t height, rt_per_frame_constants *out);
+
+/* ---- DenoiseCompositor (include/DenoiseCompositor.h:5-59, src/DenoiseCompositor.cpp,
+ *      assets/shaders/BilateralFilter.hlsli, DenoiseCommon.hlsli): separable joint-bilateral filter of the
+ *      indirect-specular AOV guided by the direct-lighting AOV, then composite + exposure + Reinhard + gamma ---- */
+typedef struct rt_denoiser rt_denoiser;
+typedef struct rt_denoiser_params {       /* cbuffer Params, DenoiseCommon.hlsli:18-26 */
+    float    exposure;                    /* defaults src/DenoiseCompositor.cpp:44-49: 1.0 */
+    float    gamma;                       /* 2.2 */
+    uint32_t tonemap;                     /* 1 */
+    uint32_t gammaCorrect;                /* 0 */
+    int32_t  maxKernelSize;               /* 12; taps on each side, <= 20 (the reference's LDS cache extent) */
+    uint32_t debugVisualize;              /* 0 composite, 1 denoised only, 2 input, 3 joint */
+} rt_denoiser_params;
+int rt_denoiser_create(rt_context *ctx, rt_denoiser **out);                                    /* ::create  DenoiseCompositor.h:10 */
+int rt_denoiser_destroy(rt_denoiser *d);
+int rt_denoiser_get_params(rt_denoiser *d, rt_denoiser_params **params);                       /* mConstantBuffer */
+int rt_denoiser_create_output(rt_denoiser *d, uint32_t format, uint32_t width, uint32_t height); /* createOutputResource .cpp:70-93 */
+/* dispatch(cmdList, {directLightingSrv, indirectSpecularSrv}, frameIndex, w, h) (.cpp:109-148): inputs are device
+ * RGBA32F images, e.g. outputs 0 and 1 of the realtime pipeline */
+int rt_denoiser_dispatch(rt_denoiser *d, const void *direct_lighting, const void *indirect_specular, uint32_t width, uint32_t height);
+int rt_denoiser_get_output_device_ptr(rt_denoiser *d, void **ptr);                             /* getOutputResource .h:23 */
+int rt_denoiser_read_output(rt_denoiser *d, void *host, size_t bytes);                         /* final (pass V) image */
+int rt_denoiser_read_intermediate(rt_denoiser *d, void *host, size_t bytes);                   /* pass H image (tests) */
+int rt_denoiser_last_ms(rt_denoiser *d, float *ms);
 
 /* ---- device math probes (tests): evaluate the kernels' deterministic
  *      sin/cos/exp/log/pow/sqrt/div and samplers on the GPU ------------------- */

@@ -363,6 +363,79 @@ int orc_render(const orc_scene *sc, const rt_material_params *mats, uint32_t nma
     return 0;
 }
 
+/* ---- N2: one RealtimeRaytracingPipeline frame (two AOV images, no accumulation) -------- */
+
+int orc_render_realtime(const orc_scene *sc, const rt_material_params *mats, uint32_t nmats,
+                        const float *env_faces, int env_size, const float env_constant[3],
+                        const rt_per_frame_constants *pfc, uint32_t width, uint32_t height,
+                        uint32_t max_radiance_depth, uint32_t max_shadow_depth,
+                        float *direct, float *indirect, int nthreads, orc_render_stats *stats_out)
+{
+    if (!sc->s.built || nmats == 0) return -1;
+    RenderCtx rc;
+    rc.scene = &sc->s;
+    rc.mats = mats; rc.nmats = nmats;
+    rc.env.faces = env_faces; rc.env.size = env_size;
+    for (int k = 0; k < 3; k++) rc.env.constant[k] = env_constant ? env_constant[k] : 0.0f;
+    rc.pfc = *pfc;
+    rc.width = width; rc.height = height;
+    rc.max_radiance_depth = max_radiance_depth;
+    rc.max_shadow_depth = max_shadow_depth;
+    rc.use_brute = false;
+    if (nthreads < 1) nthreads = 1;
+    std::vector<PixelStats> st(nthreads);
+    auto work = [&](int k) {
+        PixelStats &ps = st[k];
+        memset(&ps, 0, sizeof ps);
+        uint32_t ya = (uint32_t)((uint64_t)height * k / nthreads), yb = (uint32_t)((uint64_t)height * (k + 1) / nthreads);
+        for (uint32_t y = ya; y < yb; y++)
+            for (uint32_t x = 0; x < width; x++) {
+                PixelCtx pc = { &rc, x, y, &ps };
+                rayGenRealtime(pc, direct + ((size_t)y * width + x) * 4, indirect + ((size_t)y * width + x) * 4);
+            }
+    };
+    if (nthreads == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int k = 0; k < nthreads; k++) th.emplace_back(work, k);
+        for (std::thread &x : th) x.join();
+    }
+    if (stats_out) {
+        memset(stats_out, 0, sizeof *stats_out);
+        for (const PixelStats &p : st) {
+            stats_out->rays_primary += p.rays_primary; stats_out->rays_secondary += p.rays_secondary;
+            stats_out->rays_shadow += p.rays_shadow; stats_out->primary_hits += p.primary_hits;
+            stats_out->secondary_hits += p.secondary_hits; stats_out->nodes += p.nodes; stats_out->tris += p.tris;
+            stats_out->shaded_hits += p.shaded_hits;
+        }
+    }
+    return 0;
+}
+
+/* ---- N3: DenoiseCompositor::dispatch (src/DenoiseCompositor.cpp:109-148): H pass then V pass ---- */
+
+int orc_denoise(const float *direct, const float *indirect, uint32_t width, uint32_t height, const void *params24,
+                float *out_h, float *out_v, int nthreads)
+{
+    DenoiseParams P;
+    memcpy(&P, params24, sizeof P);
+    if (P.maxKernelSize < 0 || P.maxKernelSize > 20) return -1;
+    Img D = { direct, (int)width, (int)height }, I = { indirect, (int)width, (int)height }, H = { out_h, (int)width, (int)height };
+    if (nthreads < 1) nthreads = 1;
+    for (int pass = 0; pass < 2; pass++) {
+        auto work = [&](int k) {
+            int ya = (int)((uint64_t)height * k / nthreads), yb = (int)((uint64_t)height * (k + 1) / nthreads);
+            for (int y = ya; y < yb; y++)
+                for (int x = 0; x < (int)width; x++)
+                    denoisePixel(pass, P, x, y, D, pass == 0 ? I : H, (pass == 0 ? out_h : out_v) + ((size_t)y * width + x) * 4);
+        };
+        std::vector<std::thread> th;
+        for (int k = 0; k < nthreads; k++) th.emplace_back(work, k);
+        for (std::thread &x : th) x.join();
+    }
+    return 0;
+}
+
 /* ---- host logic ----------------------------------------------------------- */
 
 static inline V3 host_normalize(V3 v)      /* XMVector3Normalize: v / length */

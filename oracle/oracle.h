@@ -57,6 +57,14 @@ int  orc_render(const orc_scene *s, const rt_material_params *mats, uint32_t nma
                 uint32_t accum_mode, uint32_t max_radiance_depth, uint32_t max_shadow_depth, int use_brute,
                 float *accum, int nthreads, orc_render_stats *stats);
 
+int  orc_render_realtime(const orc_scene *s, const rt_material_params *mats, uint32_t nmats,
+                         const float *env_faces, int env_size, const float env_constant[3],
+                         const rt_per_frame_constants *pfc, uint32_t width, uint32_t height,
+                         uint32_t max_radiance_depth, uint32_t max_shadow_depth,
+                         float *direct, float *indirect, int nthreads, orc_render_stats *stats);
+int  orc_denoise(const float *direct, const float *indirect, uint32_t width, uint32_t height, const void *params24,
+                 float *out_h, float *out_v, int nthreads);
+
 void orc_camera_look(const float eye[3], const float at[3], const float up_in[3], float fwd_out[3], float up_out[3]);
 void orc_camera_basis(const float forward[3], const float up[3], float fov, float aspect,
                       float U[4], float V[4], float W[4]);

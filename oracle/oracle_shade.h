@@ -357,4 +357,192 @@ static inline void accumulate(float *px, const float cur[4], uint32_t accumCount
 
 }  // namespace orc
 
+
+/* ---------------------------------------------------------------------------
+ * "Next" rows N2 / N3: RealtimeRaytracingPipeline and DenoiseCompositor.
+ * ------------------------------------------------------------------------- */
+namespace orc {
+
+/* assets/shaders/RealtimeRaytracing.hlsl:7-13 */
+struct ShadingAOV { V3 albedo; float roughness; V3 directLighting; V3 indirectSpecular; };
+
+static V3 traceRealtime(const PixelCtx &pc, const Ray &r, uint32_t flags, uint32_t depth, ShadingAOV *aov);
+
+/* RealtimeRaytracing.hlsl:48-63 */
+static inline V3 shootSecondaryRayRT(const PixelCtx &pc, V3 orig, V3 dir, float minT, uint32_t currentDepth)
+{
+    if (currentDepth >= pc.rc->max_radiance_depth) return v3(0, 0, 0);
+    Ray r = { orig, minT, dir, ORC_RAY_MAX_T };
+    pc.st->rays_secondary++;
+    ShadingAOV unused;
+    return traceRealtime(pc, r, RT_RAY_FLAG_NONE, currentDepth + 1, &unused);
+}
+
+/* RealtimeRaytracing.hlsl:65-103 */
+static inline V3 shadeAOV(const PixelCtx &pc, const rt_material_params &mp, V3 position, V3 normal, V3 rayDir, uint32_t currentDepth, ShadingAOV *aov)
+{
+    uint32_t randSeed = initRand(pc.px + pc.py * pc.rc->width, pc.rc->pfc.cameraParams.frameCount);
+    V3 directContrib = v3(0, 0, 0);
+    directContrib = vadd(directContrib, evaluateDirectionalLight(pc, position, normal, currentDepth));
+    directContrib = vadd(directContrib, evaluatePointLight(pc, position, normal, currentDepth));
+    V3 fresnel = v3(0, 0, 0);
+    V3 specularComponent = v3(0, 0, 0);
+    if (mp.type == 1 || mp.type == 2) {
+        if (mp.reflectivity > 0.001f) {
+            float exponent = exp_((1.0f - mp.roughness) * 12.0f);
+            float pdf, brdf;
+            V3 mirrorDir = reflect3(rayDir, normal);
+            V3 sampleDir = samplePhongLobe(&randSeed, mirrorDir, exponent, &pdf, &brdf);
+            V3 reflectionColor = shootSecondaryRayRT(pc, position, sampleDir, ORC_RAY_EPSILON, currentDepth);
+            V3 s = vscale(reflectionColor, brdf);
+            s = vdivs(s, pdf);
+            specularComponent = vadd(specularComponent, s);
+            fresnel = FresnelReflectanceSchlick(rayDir, normal, v3(mp.specular.x, mp.specular.y, mp.specular.z));
+        }
+    }
+    V3 albedo = v3(mp.albedo.x, mp.albedo.y, mp.albedo.z);
+    V3 direct = vdivs(vmul(albedo, directContrib), ORC_M_PI);
+    V3 spec = vmul(vscale(specularComponent, mp.reflectivity), fresnel);
+    if (currentDepth == 0) {
+        aov->albedo = albedo;
+        aov->roughness = mp.roughness;
+        aov->directLighting = direct;
+        aov->indirectSpecular = spec;
+    }
+    return vadd(direct, spec);
+}
+
+/* PrimaryClosestHit / PrimaryMiss, RealtimeRaytracing.hlsl:105-126 */
+static V3 traceRealtime(const PixelCtx &pc, const Ray &r, uint32_t flags, uint32_t depth, ShadingAOV *aov)
+{
+    Hit h = trace(pc, r, flags);
+    if (h.inst == RT_NO_HIT) {
+        V3 c = sampleEnvironment(pc, r.d);
+        aov->directLighting = c;
+        aov->indirectSpecular = v3(0, 0, 0);
+        return c;
+    }
+    if (depth == 0) pc.st->primary_hits++; else pc.st->secondary_hits++;
+    pc.st->shaded_hits++;
+    const Scene &s = *pc.rc->scene;
+    const Model &m = s.models[s.inst[h.inst].model];
+    V3 n = normalize3(interpolateNormal(m, h.prim, h.u, h.v));
+    V3 position = vadd(r.o, vscale(r.d, h.t));
+    uint32_t mi = h.inst < pc.rc->nmats ? h.inst : pc.rc->nmats - 1;
+    return shadeAOV(pc, pc.rc->mats[mi], position, n, r.d, depth, aov);
+}
+
+/* RayGen, RealtimeRaytracing.hlsl:22-46 (jitter scaled by 10, two AOV outputs, no accumulation) */
+static inline void rayGenRealtime(const PixelCtx &pc, float direct[4], float indirect[4])
+{
+    const rt_camera_params &cp = pc.rc->pfc.cameraParams;
+    float dimx = (float)pc.rc->width, dimy = (float)pc.rc->height;
+    float dx = ((float)pc.px + 0.5f) / dimx; dx = dx * 2.0f; dx = dx - 1.0f;
+    float dy = ((float)pc.py + 0.5f) / dimy; dy = dy * 2.0f; dy = dy - 1.0f;
+    float jx = cp.jitters.x * 10.0f, jy = cp.jitters.y * 10.0f;
+    Ray r;
+    r.o = v3(cp.worldEyePos.x + jx, cp.worldEyePos.y + jy, cp.worldEyePos.z + 0.0f);
+    float ndy = -dy;
+    V3 dir = vscale(v3(cp.U.x, cp.U.y, cp.U.z), dx);
+    dir = vadd(dir, vscale(v3(cp.V.x, cp.V.y, cp.V.z), ndy));
+    dir = vadd(dir, v3(cp.W.x, cp.W.y, cp.W.z));
+    r.d = normalize3(dir);
+    r.tmin = 0.0f;
+    r.tmax = ORC_RAY_MAX_T;
+    pc.st->rays_primary++;
+    ShadingAOV aov;
+    aov.directLighting = v3(0, 0, 0); aov.indirectSpecular = v3(0, 0, 0);
+    (void)traceRealtime(pc, r, RT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES, 0, &aov);
+    direct[0] = fmax_(aov.directLighting.x, 0.0f); direct[1] = fmax_(aov.directLighting.y, 0.0f);
+    direct[2] = fmax_(aov.directLighting.z, 0.0f); direct[3] = 1.0f;
+    indirect[0] = fmax_(aov.indirectSpecular.x, 0.0f); indirect[1] = fmax_(aov.indirectSpecular.y, 0.0f);
+    indirect[2] = fmax_(aov.indirectSpecular.z, 0.0f); indirect[3] = 1.0f;
+}
+
+/* ---- DenoiseCompositor: assets/shaders/BilateralFilter.hlsli:14-118, DenoiseCommon.hlsli:18-77 ---- */
+
+struct DenoiseParams {          /* cbuffer Params, DenoiseCommon.hlsli:18-26; defaults src/DenoiseCompositor.cpp:44-49 */
+    float exposure, gamma;
+    uint32_t tonemap, gammaCorrect;
+    int32_t maxKernelSize;
+    uint32_t debugVisualize;
+};
+
+struct Img { const float *p; int w, h; };
+
+/* Texture2D load: out-of-bounds reads return 0 (D3D) */
+static inline void texel(const Img &t, int x, int y, float out[4])
+{
+    if (x < 0 || y < 0 || x >= t.w || y >= t.h) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
+    const float *s = t.p + ((size_t)y * t.w + x) * 4;
+    out[0] = s[0]; out[1] = s[1]; out[2] = s[2]; out[3] = s[3];
+}
+
+static inline float denoiseTapWeight(int i, float kernelRadius)
+{
+    /* BilateralFilter.hlsli:82-90: index into {1,1,.9,.75,.6,.5,0} */
+    int a = i < 0 ? -i : i;
+    int idx = (int)((float)(a * 5) / (0.001f + fabsf(kernelRadius * 0.8f)));
+    idx = idx < 0 ? 0 : (idx > 6 ? 6 : idx);
+    return idx < 2 ? 1.0f : (idx < 3 ? 0.9f : (idx < 4 ? 0.75f : (idx < 5 ? 0.6f : (idx < 6 ? 0.5f : 0.0f))));
+}
+
+/* filterKernel (BilateralFilter.hlsli:75-118).  The reference reads its taps from a 64+2*20 texel LDS
+ * cache whose halo fill has an index-clamp race at cache slot 0; the cache is meant to equal the texture
+ * with a zero border, which is what this computes.  |maxKernelSize| <= 20 (the cache's MAX_EXTENT). */
+static inline void filterKernel(int pass, int kernelMaxSize, int x, int y, const Img &input, const Img &joint, float out[4])
+{
+    const int dx = pass == 0 ? 1 : 0, dy = pass == 0 ? 0 : 1;
+    const float kernelRadius = (float)kernelMaxSize;
+    float color[4] = {0, 0, 0, 0};
+    float weight = 0.0f;
+    float centerJoint[4];
+    texel(joint, x, y, centerJoint);
+    for (int i = -kernelMaxSize; i <= kernelMaxSize; ++i) {
+        float s[4], sj[4];
+        texel(input, x + dx * i, y + dy * i, s);
+        texel(joint, x + dx * i, y + dy * i, sj);
+        float gaussianWeight = denoiseTapWeight(i, kernelRadius);
+        float dist = fabsf(sj[0] - centerJoint[0]);
+        dist = dist + fabsf(sj[1] - centerJoint[1]);
+        dist = dist + fabsf(sj[2] - centerJoint[2]);
+        dist = dist * 10.0f;
+        float colorWeight = 1.0f - fmin_(fmax_(dist, 0.0f), 1.0f);
+        float bw = gaussianWeight * colorWeight;
+        for (int k = 0; k < 4; k++) color[k] = color[k] + s[k] * bw;
+        weight = weight + bw;
+    }
+    for (int k = 0; k < 4; k++) out[k] = color[k] / weight;
+}
+
+/* main() of pass 0 (H) and pass 1 (V), DenoiseCommon.hlsli:46-77 */
+static inline void denoisePixel(int pass, const DenoiseParams &P, int x, int y, const Img &direct, const Img &input, float out[4])
+{
+    float c[4];
+    if (P.debugVisualize == 2) texel(input, x, y, c);
+    else filterKernel(pass, P.maxKernelSize, x, y, input, direct, c);
+    if (pass == 1) {
+        float d[4];
+        texel(direct, x, y, d);
+        if (P.debugVisualize == 0) { c[0] = c[0] + d[0]; c[1] = c[1] + d[1]; c[2] = c[2] + d[2]; }
+        else if (P.debugVisualize == 3) { c[0] = d[0]; c[1] = d[1]; c[2] = d[2]; }
+        c[0] = c[0] * P.exposure; c[1] = c[1] * P.exposure; c[2] = c[2] * P.exposure;
+        if (P.tonemap) {
+            float lum = c[0] * 0.299f;
+            lum = lum + c[1] * 0.587f;
+            lum = lum + c[2] * 0.114f;
+            float reinhard = lum / (lum + 1.0f);
+            float k = reinhard / lum;
+            c[0] = fmax_(c[0] * k, 0.0f); c[1] = fmax_(c[1] * k, 0.0f); c[2] = fmax_(c[2] * k, 0.0f);
+        }
+        if (P.gammaCorrect) {
+            float e = 1.0f / P.gamma;
+            c[0] = saturate(pow_(c[0], e)); c[1] = saturate(pow_(c[1], e)); c[2] = saturate(pow_(c[2], e));
+        }
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = 1.0f;
+}
+
+}  // namespace orc
+
 #endif

@@ -68,6 +68,8 @@ def lib():
         L.orc_scene_instance_info.argtypes = [p, C.c_uint32, p, p]
         L.orc_trace.argtypes = [p, p, p, C.c_size_t, C.c_uint32, C.c_int] + [p] * 7 + [C.c_int]
         L.orc_render.argtypes = [p, p, C.c_uint32, p, C.c_int, p, p] + [C.c_uint32] * 9 + [C.c_int, p, C.c_int, p]
+        L.orc_render_realtime.argtypes = [p, p, C.c_uint32, p, C.c_int, p, p] + [C.c_uint32] * 4 + [p, p, C.c_int, p]
+        L.orc_denoise.argtypes = [p, p, C.c_uint32, C.c_uint32, p, p, p, C.c_int]
         L.orc_camera_look.argtypes = [p] * 5
         L.orc_camera_basis.argtypes = [p, p, C.c_float, C.c_float, p, p, p]
         L.orc_progressive_create.restype = p
@@ -211,6 +213,23 @@ class Scene:
             raise RuntimeError("orc_trace -> %d" % rc)
         return dict(t=t, u=u, v=v, prim=prim, inst=inst, nodes=cn, tris=ct)
 
+    def render_realtime(self, materials, pfc, width, height, env_faces=None, env_constant=(0.5, 0.5, 0.5),
+                        max_radiance_depth=1, max_shadow_depth=2, nthreads=1):
+        mats = np.ascontiguousarray(materials)
+        pfc = np.ascontiguousarray(pfc)
+        assert pfc.nbytes == PFC_BYTES
+        ef = _f32(env_faces) if env_faces is not None else None
+        ec = _f32(env_constant)
+        direct = np.zeros((height, width, 4), np.float32)
+        indirect = np.zeros((height, width, 4), np.float32)
+        st = RenderStats()
+        rc = lib().orc_render_realtime(self.h, _ptr(mats), mats.nbytes // MATERIAL_BYTES, _ptr(ef), 0 if ef is None else ef.shape[1],
+                                       _ptr(ec), _ptr(pfc), width, height, max_radiance_depth, max_shadow_depth,
+                                       _ptr(direct), _ptr(indirect), nthreads, C.byref(st))
+        if rc != 0:
+            raise RuntimeError("orc_render_realtime -> %d" % rc)
+        return direct, indirect, st.as_dict()
+
     def render(self, materials, pfc, width, height, accum=None, env_faces=None, env_constant=(0.5, 0.5, 0.5),
                tile=None, accum_mode=0, max_radiance_depth=1, max_shadow_depth=2, use_brute=False, nthreads=1):
         mats = np.ascontiguousarray(materials)
@@ -231,6 +250,22 @@ class Scene:
         if rc != 0:
             raise RuntimeError("orc_render -> %d" % rc)
         return accum, st.as_dict()
+
+
+DENOISE_PARAMS = np.dtype([("exposure", "<f4"), ("gamma", "<f4"), ("tonemap", "<u4"), ("gammaCorrect", "<u4"),
+                           ("maxKernelSize", "<i4"), ("debugVisualize", "<u4")])
+
+
+def denoise(direct, indirect, params, nthreads=8):
+    """DenoiseCompositor: returns (H-pass image, final V-pass image)."""
+    d = _f32(direct); i = _f32(indirect)
+    h, w = d.shape[0], d.shape[1]
+    prm = np.ascontiguousarray(params, dtype=DENOISE_PARAMS)
+    oh = np.empty((h, w, 4), np.float32); ov = np.empty((h, w, 4), np.float32)
+    rc = lib().orc_denoise(_ptr(d), _ptr(i), w, h, _ptr(prm), _ptr(oh), _ptr(ov), nthreads)
+    if rc != 0:
+        raise RuntimeError("orc_denoise -> %d" % rc)
+    return oh, ov
 
 
 def camera_look(eye, at, up):

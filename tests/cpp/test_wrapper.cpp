@@ -4,7 +4,9 @@
 #include <cstdio>
 #include <vector>
 
+#include "DenoiseCompositor.h"
 #include "ProgressiveRaytracingPipeline.h"
+#include "RealtimeRaytracingPipeline.h"
 
 using namespace DXRFramework;
 
@@ -49,6 +51,32 @@ int main(int argc, char **argv)
         bool threw = false;
         try { RtProgram::Desc d; d.setRayGen("NoSuchShader"); RtProgram::create(context, d); } catch (const std::logic_error &) { threw = true; }
         if (!threw) return 6;
+        // the app's second pipeline + post chain (src/DXRExperimentsApp.cpp:196-211): realtime AOVs -> denoiser
+        if (argc >= 4) {
+            auto realtime = RealtimeRaytracingPipeline::create(context, 77);
+            realtime->setScene(scene);
+            realtime->addMaterial(material);
+            realtime->setCamera(camera);
+            realtime->loadResources(3);
+            realtime->createOutputResource(RT_FORMAT_R32G32B32A32_FLOAT, W, H);
+            realtime->buildAccelerationStructures();
+            if (realtime->getNumOutputs() != 2 || std::string(realtime->getName()) != "Realtime Ray Tracing Pipeline") return 7;
+            realtime->update(0.0f, 5, 0, 0, W, H);
+            realtime->render(0, W, H);
+            auto denoiser = DenoiseCompositor::create(context);
+            denoiser->loadResources(3, false);
+            denoiser->createOutputResource(RT_FORMAT_R32G32B32A32_FLOAT, W, H);
+            DenoiseCompositor::InputComponents inputs = {realtime->getOutputResource(0), realtime->getOutputResource(1)};
+            denoiser->dispatch(inputs, 0, W, H);
+            std::vector<float> three(size_t(W) * H * 4 * 3);
+            realtime->readOutput(0, three.data(), image.size() * 4);
+            realtime->readOutput(1, three.data() + image.size(), image.size() * 4);
+            denoiser->readOutput(three.data() + 2 * image.size(), image.size() * 4);
+            FILE *g = std::fopen(argv[3], "wb");
+            if (!g) return 8;
+            std::fwrite(three.data(), 4, three.size(), g);
+            std::fclose(g);
+        }
         std::printf("wrapper ok\n");
     } catch (const std::exception &e) {
         std::fprintf(stderr, "error: %s\n", e.what());

@@ -15,6 +15,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIBDIR = os.path.join(ROOT, "dxrexperiments_amd", "lib")
 
 
+def test_cpp_wrapper_realtime_and_denoiser(tmp_path, oracle):
+    """RealtimeRaytracingPipeline + DenoiseCompositor through the C++ mirror == oracle (same host seed 77, frame 5)."""
+    exe = os.path.join(LIBDIR, "test_wrapper")
+    out, out3 = tmp_path / "img.f32", tmp_path / "three.f32"
+    r = subprocess.run([exe, CORNELL_OBJ, str(out), str(out3)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    three = np.fromfile(out3, np.float32).reshape(3, 64, 64, 4)
+    v, i = oracle.obj_load(CORNELL_OBJ)
+    sc = oracle.Scene()
+    sc.add_instance(sc.add_model(v, i))
+    sc.build()
+    host = oracle.Progressive(77)
+    cam = np.array([0, 0, 3.2, 0, 0, 0, 0, 1, 0, np.float32(3.14159265358979 / 4.0), 1.0], np.float32)
+    pfc = np.frombuffer(host.update(cam, 0.0, 5, 64, 64).tobytes(), T.PER_FRAME_CONSTANTS).copy()
+    pfc["cameraParams"]["accumCount"] = 0
+    pfc["options"] = np.zeros((), T.DEBUG_OPTIONS)
+    pfc["options"]["environmentStrength"] = 1.0
+    d, ind, _ = sc.render_realtime(T.default_material(), pfc, 64, 64, env_constant=(0.5, 0.5, 0.5), nthreads=4)
+    prm = np.zeros((), oracle.DENOISE_PARAMS)
+    prm["exposure"], prm["gamma"], prm["tonemap"], prm["maxKernelSize"] = 1.0, 2.2, 1, 12
+    _, ov = oracle.denoise(d, ind, prm)
+    assert np.array_equal(three[0], d) and np.array_equal(three[1], ind)
+    assert np.array_equal(np.nan_to_num(three[2], nan=-1), np.nan_to_num(ov, nan=-1))
+
+
 def test_cpp_wrapper_reproduces_golden_frames(tmp_path):
     """ProgressiveRaytracingPipeline::create/setScene/addMaterial/setCamera/update/render through the C++ mirror,
     4 frames of Cornell 64x64 with host seed 1234 == the committed oracle image."""
