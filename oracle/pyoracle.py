@@ -159,8 +159,8 @@ class Scene:
         self.n_instances = 0
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().orc_scene_destroy(self.h)
+        if getattr(self, "h", None) and _LIB is not None and lib is not None:
+            _LIB.orc_scene_destroy(self.h)
             self.h = None
 
     def add_model(self, verts, idx):
@@ -289,8 +289,8 @@ class Progressive:
         self.h = C.c_void_p(lib().orc_progressive_create(rng_seed))
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().orc_progressive_destroy(self.h)
+        if getattr(self, "h", None) and _LIB is not None and lib is not None:
+            _LIB.orc_progressive_destroy(self.h)
             self.h = None
 
     def options_buffer(self):

@@ -151,7 +151,7 @@ for y0, y1 in rows: own[y0:y1] += 1
 dist.all_reduce(own)
 assert bool((own == 1).all())             # tile partition covers every row exactly once
 dist.barrier(); dist.destroy_process_group()
-print("rank", rank, "ok", mine, rms)
+open(os.path.join(sys.argv[2], "ok_%d" % rank), "w").write("%s %g" % (mine, rms))
 '''
 
 
@@ -161,10 +161,10 @@ def test_sample_sharding_over_gloo_world2(tmp_path, oracle):
     script.write_text(GLOO_WORKER)
     port = 29600 + os.getpid() % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(script), ROOT]
+           "--master-port", str(port), str(script), ROOT, str(tmp_path)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
-    assert r.stdout.count(" ok ") == 2
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists(), r.stdout[-2000:]
 
 
 def test_shard_helpers():
