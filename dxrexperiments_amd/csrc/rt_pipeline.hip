@@ -1048,9 +1048,12 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
     pd.sh1O = p->sh1O.as<float4>(); pd.sh1D = p->sh1D.as<float4>(); pd.vis1 = p->vis1.as<uint32_t>();
     HIP_TRY(hipMemsetAsync(pd.counters, 0, C_COUNT * 4, st));
     const uint32_t need = p->scene->stack_need;
+    // LDS stack rows -> resident 256-thread blocks per CU: 24 -> 6, 31 -> 5, 39 -> 4, 52 -> 3, 78 -> 2, 160 -> 1
     if (need < 24) launch_frame_any<24>(p, pd, shadow_slots);
     else if (need < 31) launch_frame_any<31>(p, pd, shadow_slots);
-    else if (need < 64) launch_frame_any<64>(p, pd, shadow_slots);
+    else if (need < 39) launch_frame_any<39>(p, pd, shadow_slots);
+    else if (need < 52) launch_frame_any<52>(p, pd, shadow_slots);
+    else if (need < 78) launch_frame_any<78>(p, pd, shadow_slots);
     else if (need < 160) launch_frame_any<160>(p, pd, shadow_slots);
     else { rt_set_error("traversal stack need %u exceeds 159 entries", need); return RT_ERR_UNSUPPORTED; }
     HIP_TRY(hipGetLastError());

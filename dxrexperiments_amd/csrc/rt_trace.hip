@@ -88,10 +88,13 @@ int rt_launch_trace(rt_context *ctx, const rt_scene *s, const float4 *o, const f
         BatchSink sink = {out};
         const uint32_t need = s->stack_need;
         HIP_TRY(hipEventRecord(ctx->ev0, st));
-        if (need < 24) launch_fast<24>(ctx, s->two_level, st, sc, src, sink, ctx->pool.as<uint32_t>());
-        else if (need < 31) launch_fast<31>(ctx, s->two_level, st, sc, src, sink, ctx->pool.as<uint32_t>());
-        else if (need < 64) launch_fast<64>(ctx, s->two_level, st, sc, src, sink, ctx->pool.as<uint32_t>());
-        else if (need < 160) launch_fast<160>(ctx, s->two_level, st, sc, src, sink, ctx->pool.as<uint32_t>());
+        uint32_t *pool = ctx->pool.as<uint32_t>();
+        if (need < 24) launch_fast<24>(ctx, s->two_level, st, sc, src, sink, pool);
+        else if (need < 31) launch_fast<31>(ctx, s->two_level, st, sc, src, sink, pool);
+        else if (need < 39) launch_fast<39>(ctx, s->two_level, st, sc, src, sink, pool);
+        else if (need < 52) launch_fast<52>(ctx, s->two_level, st, sc, src, sink, pool);
+        else if (need < 78) launch_fast<78>(ctx, s->two_level, st, sc, src, sink, pool);
+        else if (need < 160) launch_fast<160>(ctx, s->two_level, st, sc, src, sink, pool);
         else {
             rt_set_error("traversal stack need %u exceeds 159 entries", need);
             return RT_ERR_UNSUPPORTED;

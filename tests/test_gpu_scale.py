@@ -1,0 +1,94 @@
+"""BASELINE configs 4 and 5 at their full sizes (parity-test cases, not bench lines):
+C5  synthetic 10 M-triangle mesh, 3840x2160   -> BVH index-exact, hits bit-exact on a ray sample, a 4K frame renders
+C4  4096 instances of one mesh (TLAS over many BLAS instances), 3840x2160, realtime pipeline + denoiser."""
+import time
+
+import numpy as np
+import pytest
+
+from dxrexperiments_amd import rtypes as T, scenes
+from util import ANY, CULL, Pair, assert_hits_equal, cam_array, nodes_equal, random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c5_ten_million_triangles(gpu, oracle, capi):
+    t0 = time.time()
+    v, tri = scenes.displaced_grid(2236, seed=7)                 # 9,999,392 triangles
+    assert tri.shape[0] > 9_900_000
+    t1 = time.time()
+    p = Pair(oracle, capi, gpu, [(v, tri)], [(0, None)])
+    t2 = time.time()
+    gn, gk, gp, gd = p.g.bvh(0)
+    on, ok, op, od = p.o.bvh(0)
+    assert np.array_equal(gk, ok) and nodes_equal(gn, on) and np.array_equal(gp, op) and gd == od
+    del gn, gk, gp, on, ok, op
+    O, D = random_rays(200000, 21, [-20, -12, -20], [20, 4, 20])
+    for flags in (0, CULL):
+        assert_hits_equal(p.g.trace(O, D, flags=flags), p.o.trace(O, D, flags=flags, mode=1, nthreads=8), "10M fast vs oracle flags=%d" % flags)
+    assert_hits_equal(p.g.trace(O, D, flags=ANY), p.o.trace(O, D, flags=ANY, mode=1, nthreads=8), "10M any-hit", closest=False)
+    gc = p.g.trace(O[:20000], D[:20000], flags=0, canonical=True)
+    ob = p.o.trace(O[:20000], D[:20000], flags=0, mode=1, nthreads=8)
+    assert np.array_equal(gc["nodes"], ob["nodes"]) and np.array_equal(gc["tris"], ob["tris"])
+    # one 4K progressive frame
+    W, H = 3840, 2160
+    pipe = capi.Pipeline(gpu)
+    pipe.set_scene(p.g)
+    pipe.add_material(T.default_material())
+    pipe.set_environment_cube(scenes.sky_cubemap(32))
+    pipe.create_output(W, H)
+    pipe.build_acceleration_structures()
+    host = capi.ProgressiveHost(3)
+    cam = cam_array(dict(eye=(0.0, 6.0, 19.0), at=(0.0, -4.0, 0.0), up=(0, 1, 0), fov=0.8), W / H)
+    pipe.enable_timing(2)
+    for f in range(2):
+        pipe.update(host.update(cam, 0.0, f + 1, W, H))
+        pipe.render()
+    img = pipe.read_output()
+    st = pipe.stats()
+    assert np.isfinite(img).all() and img[..., 3].min() == 1.0
+    assert st["rays_primary"] == W * H and st["primary_hits"] > W * H // 4
+    rays = st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]
+    print("\nC5: generate %.1fs, build both %.1fs (GPU BVH build %.1f ms), 4K frame %.2f ms = %.0f Mrays/s" % (
+        t1 - t0, t2 - t1, p.g.build_ms(), st["ms_total"], rays / st["ms_total"] / 1e3))
+
+
+def test_c4_many_instances_realtime_denoise_4k(gpu, oracle, capi):
+    blob = scenes.blob_mesh(level=3)                              # 1280 triangles
+    xf = scenes.instance_grid(64, spacing=3.0)                    # 4096 instances
+    inst = [(0, xf[k]) for k in range(xf.shape[0])]
+    p = Pair(oracle, capi, gpu, [blob], inst)
+    gn, gk, gp, gd = p.g.bvh(-1)
+    on, ok, op, od = p.o.bvh(-1)
+    assert np.array_equal(gk, ok) and nodes_equal(gn, on) and np.array_equal(gp, op) and gd == od
+    O, D = random_rays(200000, 22, [-100, -3, -100], [100, 3, 100])
+    for flags in (0, CULL):
+        assert_hits_equal(p.g.trace(O, D, flags=flags), p.o.trace(O, D, flags=flags, mode=1, nthreads=8), "instanced fast vs oracle flags=%d" % flags)
+    assert_hits_equal(p.g.trace(O, D, flags=ANY), p.o.trace(O, D, flags=ANY, mode=1, nthreads=8), "instanced any-hit", closest=False)
+    W, H = 3840, 2160
+    pipe = capi.Pipeline(gpu, capi.PIPELINE_REALTIME)
+    pipe.set_scene(p.g)
+    r = np.random.default_rng(5)
+    for k in range(len(inst)):
+        m = T.default_material()
+        m["albedo"][:3] = r.uniform(0.1, 0.9, 3)
+        m["type"] = k % 3
+        pipe.add_material(m)
+    pipe.set_environment_cube(scenes.sky_cubemap(32))
+    pipe.create_output(W, H)
+    pipe.build_acceleration_structures()
+    host = capi.ProgressiveHost(4)
+    cam = cam_array(dict(eye=(0.0, 30.0, 110.0), at=(0.0, 0.0, 0.0), up=(0, 1, 0), fov=0.9), W / H)
+    pipe.enable_timing(2)
+    dn = capi.Denoiser(gpu)
+    dn.create_output(W, H)
+    for f in range(2):
+        pipe.update(host.update_realtime(cam, 0.0, f + 1, W, H))
+        pipe.render()
+        dn.dispatch(pipe.output_device_ptr(0), pipe.output_device_ptr(1))
+    out = dn.read_output()
+    st = pipe.stats()
+    assert np.isfinite(out).all() and 0 < st["primary_hits"] < W * H
+    rays = st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]
+    print("\nC4: 4096 instances, 4K realtime frame %.2f ms = %.0f Mrays/s, denoise %.3f ms" % (
+        st["ms_total"], rays / st["ms_total"] / 1e3, dn.last_ms()))
