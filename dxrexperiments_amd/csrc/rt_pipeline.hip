@@ -3,23 +3,26 @@
 // The reference renders a frame with ONE DispatchRays whose raygen shader recurses
 // through TraceRay (src/ProgressiveRaytracingPipeline.cpp:215-247 ->
 // assets/shaders/ProgressiveRaytracing.hlsl).  Here the same per-pixel recursion
-// (depth <= 1 radiance, <= 2 shadow; RaytracingCommon.hlsli:11-12) is unrolled into
-// a fixed wavefront DAG of ray queues in HBM, one kernel per stage:
+// (reference limits: depth <= 1 radiance, <= 2 shadow, RaytracingCommon.hlsli:11-12;
+// this engine: radiance depth <= MAXD = 4) becomes a wavefront DAG of ray queues in
+// HBM, one kernel per stage:
 //
-//   primary      raygen + closest-hit traversal (cull back faces)  -> hit0, compaction of hit pixels
-//   shade0/emit  PrimaryClosestHit -> shade(): emits 2 shadow rays + diffuse + specular secondary rays
-//   trace        any-hit over the shadow queue; closest-hit over the secondary queue (+ compaction)
-//   shade1/emit  closest-hit shading of secondary hits: emits their 2 shadow rays each
-//   trace        any-hit over the second shadow queue
-//   resolve      re-runs shade() with every TraceRay replaced by its stored result, then
-//                gOutput = (n*prev + cur)/(n+1)                      (ProgressiveRaytracing.hlsl:36-38)
+//   primary        raygen + closest-hit traversal (cull back faces) -> level-0 hits, compaction
+//   shade 0 / emit PrimaryClosestHit -> shade(): emits 2 (AO: 4) shadow rays + the diffuse and
+//                  the specular ray of level 1
+//   for l = 1..max radiance depth:
+//     trace l      closest-hit over the ray queue of level l, compaction of its hits
+//     shade l/emit closest-hit shading of those hits: 2 shadow rays each + the specular ray of l+1
+//   shadow         any-hit over the shadow queues of ALL levels in one persistent launch
+//   resolve        re-runs shade() with every TraceRay replaced by its stored result, then
+//                  gOutput = (n*prev + cur)/(n+1)                      (ProgressiveRaytracing.hlsl:36-38)
 //
 // shade() is ONE template used in both the emit and the resolve stage, so the
 // arithmetic (and the RNG draw order) of both passes is identical by construction.
 // Queues are SoA float4 arrays (origin|tmin, direction|tmax) so a wave reads 1 KiB
-// per instruction; live rays are compacted with __ballot + popcount prefix sums and
-// one atomic per wave; diffuse and specular secondaries sit in separate batches so
-// waves stay as coherent as the sampling allows.
+// per instruction; hits are compacted with __ballot + popcount prefix sums and one
+// atomic per 1024-thread block; diffuse and specular secondaries sit in separate
+// batches so waves stay as coherent as the sampling allows.
 #include <hip/hip_fp16.h>
 
 #include <new>
@@ -41,8 +44,29 @@ constexpr int PBLOCK = 256;
 #define HIT_MISS -1.0f
 #define HIT_UNTRACED -2.0f
 
-enum { C_N0 = 0, C_N1 = 1, C_SECONDARY = 2, C_SHADOW = 3, C_POOL_PRIMARY = 4, C_POOL_SECONDARY = 5, C_POOL_SHADOW0 = 6,
-       C_POOL_SHADOW1 = 7, C_COUNT = 8 };
+// Radiance rays are traced level by level: level 0 = primary rays, level L = rays spawned by the hits of
+// level L-1.  MAX_RADIANCE_RAY_DEPTH (RaytracingCommon.hlsli:11) is 1 in the reference; the DAG below is
+// generic up to MAXD so that BASELINE config 5 ("4-bounce") runs.  Because indirect DIFFUSE is only sampled
+// at depth 0 (ProgressiveRaytracing.hlsl:107), every pixel owns at most two chains of specular bounces.
+constexpr int MAXD = 4;
+enum { C_NHIT = 0,                       // [0..MAXD] compacted hits per level
+       C_SECONDARY = MAXD + 1, C_SHADOW = MAXD + 2,
+       C_POOL_PRIMARY = MAXD + 3, C_POOL_SHADOW = MAXD + 4,
+       C_POOL_LEVEL = MAXD + 5,          // [1..MAXD] ray pools of the secondary levels
+       C_COUNT = 2 * MAXD + 6 };
+
+// Level L: the rays at radiance depth L (L >= 1; primary rays are generated, not stored), their hit
+// records, the compaction of the hits, and the shadow-ray queue of those hits.
+//   slots of level 1: w*cap + k  (w = 0 diffuse / 1 specular batch, k = compact index of the primary hit)
+//   slots of level L >= 2: j     (compact index of the level L-1 hit that spawned the ray)
+//   shadow queue of level L: s*hcap(L) + idx, idx = compact hit index, hcap(0) = cap, hcap(L>=1) = 2 cap
+struct LevelDev {
+    float4 *O, *D;              // ray queue (unused at level 0)
+    float4 *hit; uint32_t *inst;   // hit records, indexed by slot (level 0: by pixel slot q)
+    uint32_t *slot_j, *jlist;   // slot -> compact hit index (RT_NO_HIT if none), compact index -> slot
+    uint32_t *pix;              // slot -> pixel slot q (unused at level 0)
+    float4 *shO, *shD; uint32_t *vis;
+};
 
 struct PipeDev {
     SceneDev sc;
@@ -60,14 +84,11 @@ struct PipeDev {
     uint32_t kind;                      // RT_PIPELINE_PROGRESSIVE / RT_PIPELINE_REALTIME
     float4 *accum;
     float4 *aov_direct, *aov_indirect;  // realtime pipeline outputs (RealtimeRaytracing.hlsl:3-4)
-    float4 *hit0; uint32_t *inst0;
-    uint32_t *pix_k, *klist;
     uint32_t *counters;
-    float4 *secO, *secD, *hit1; uint32_t *inst1;
-    uint32_t *slot_j, *jlist;
-    float4 *sh0O, *sh0D; uint32_t *vis0;
-    float4 *sh1O, *sh1D; uint32_t *vis1;
+    LevelDev lv[MAXD + 1];
 };
+
+RT_DEV uint32_t hcap(const PipeDev &pd, int L) { return L == 0 ? pd.cap : 2u * pd.cap; }
 
 // ---- environment: TextureCube.SampleLevel(linear, dir, 0), RaytracingCommon.hlsli:149-159
 RT_DEV f3 sample_cube(const PipeDev &pd, f3 d)
@@ -335,75 +356,58 @@ RT_DEV RayD load_ray(const float4 *O, const float4 *D, size_t slot)
 
 // ---- the "TraceRay" providers of the two passes ---------------------------------
 
-// emit pass, depth 0: shadow slot s -> sh0[s*cap + k], secondary w -> sec[w*cap + k]
-struct EmitIO0 {
+// emit pass at radiance depth L: shadow ray s -> shadow queue of level L, secondary ray -> ray queue of level L+1
+struct EmitIO {
     const PipeDev &pd;
-    uint32_t k;
+    int L;
+    uint32_t idx, q;            // compact hit index at level L, pixel slot
     uint32_t shadow_mask, sec_mask;
-    RT_DEV EmitIO0(const PipeDev &p, uint32_t kk) : pd(p), k(kk), shadow_mask(0), sec_mask(0) {}
+    RT_DEV EmitIO(const PipeDev &p, int level, uint32_t i, uint32_t qq) : pd(p), L(level), idx(i), q(qq), shadow_mask(0), sec_mask(0) {}
     RT_DEV float shadow(int s, f3 o, f3 d, float tmin, float tmax, uint32_t depth)
     {
         if (depth >= pd.max_shadow) return 1.0f;
-        store_ray(pd.sh0O, pd.sh0D, (size_t)s * pd.cap + k, o, tmin, d, tmax);
+        store_ray(pd.lv[L].shO, pd.lv[L].shD, (size_t)s * hcap(pd, L) + idx, o, tmin, d, tmax);
         shadow_mask |= 1u << s;
         return 1.0f;
     }
     RT_DEV f3 secondary(int w, f3 o, f3 d, float tmin, uint32_t depth)
     {
-        if (depth >= pd.max_rad) return mk3(0.0f, 0.0f, 0.0f);
-        store_ray(pd.secO, pd.secD, (size_t)w * pd.cap + k, o, tmin, d, RAY_MAX_T);
+        if (depth >= pd.max_rad || L >= MAXD) return mk3(0.0f, 0.0f, 0.0f);
+        const size_t slot = L == 0 ? (size_t)w * pd.cap + idx : idx;
+        store_ray(pd.lv[L + 1].O, pd.lv[L + 1].D, slot, o, tmin, d, RAY_MAX_T);
+        pd.lv[L + 1].pix[slot] = q;
         sec_mask |= 1u << w;
         return mk3(0.0f, 0.0f, 0.0f);
     }
 };
 
-// emit pass, depth 1: shadow slot s -> sh1[s*2cap + j]; secondaries are never traced at depth 1
-struct EmitIO1 {
+// resolve pass at radiance depth L: every TraceRay is replaced by its stored result; a secondary hit
+// recurses into the next level (compile-time recursion, MAXD deep)
+template <int L, int MAXL>
+struct ResolveIO {
     const PipeDev &pd;
-    uint32_t j;
-    uint32_t shadow_mask;
-    RT_DEV EmitIO1(const PipeDev &p, uint32_t jj) : pd(p), j(jj), shadow_mask(0) {}
-    RT_DEV float shadow(int s, f3 o, f3 d, float tmin, float tmax, uint32_t depth)
-    {
-        if (depth >= pd.max_shadow) return 1.0f;
-        store_ray(pd.sh1O, pd.sh1D, (size_t)s * 2u * pd.cap + j, o, tmin, d, tmax);
-        shadow_mask |= 1u << s;
-        return 1.0f;
-    }
-    RT_DEV f3 secondary(int, f3, f3, float, uint32_t) { return mk3(0.0f, 0.0f, 0.0f); }
-};
-
-struct ResolveIO1 {
-    const PipeDev &pd;
-    uint32_t j;
-    RT_DEV ResolveIO1(const PipeDev &p, uint32_t jj) : pd(p), j(jj) {}
+    uint32_t idx, pix;
+    RT_DEV ResolveIO(const PipeDev &p, uint32_t i, uint32_t px) : pd(p), idx(i), pix(px) {}
     RT_DEV float shadow(int s, f3, f3, float, float, uint32_t depth)
     {
         if (depth >= pd.max_shadow) return 1.0f;
-        return pd.vis1[(size_t)s * 2u * pd.cap + j] ? 1.0f : 0.0f;
-    }
-    RT_DEV f3 secondary(int, f3, f3, float, uint32_t) { return mk3(0.0f, 0.0f, 0.0f); }
-};
-
-struct ResolveIO0 {
-    const PipeDev &pd;
-    uint32_t k, pix;
-    RT_DEV ResolveIO0(const PipeDev &p, uint32_t kk, uint32_t px) : pd(p), k(kk), pix(px) {}
-    RT_DEV float shadow(int s, f3, f3, float, float, uint32_t depth)
-    {
-        if (depth >= pd.max_shadow) return 1.0f;
-        return pd.vis0[(size_t)s * pd.cap + k] ? 1.0f : 0.0f;
+        return pd.lv[L].vis[(size_t)s * hcap(pd, L) + idx] ? 1.0f : 0.0f;
     }
     RT_DEV f3 secondary(int w, f3 o, f3 d, float tmin, uint32_t depth)
     {
-        if (depth >= pd.max_rad) return mk3(0.0f, 0.0f, 0.0f);
-        const size_t slot = (size_t)w * pd.cap + k;
-        const float4 h = pd.hit1[slot];
-        if (h.x == HIT_MISS) return sample_environment(pd, d);             // PrimaryMiss, :160-164
-        RayD r;
-        r.o = o; r.tmin = tmin; r.d = d; r.tmax = RAY_MAX_T;
-        ResolveIO1 io(pd, pd.slot_j[slot]);
-        return closest_hit(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.inst1[slot], depth + 1u, pix);
+        if constexpr (L >= MAXL) {
+            return mk3(0.0f, 0.0f, 0.0f);
+        } else {
+            if (depth >= pd.max_rad) return mk3(0.0f, 0.0f, 0.0f);
+            const size_t slot = L == 0 ? (size_t)w * pd.cap + idx : idx;
+            const float4 h = pd.lv[L + 1].hit[slot];
+            if (h.x == HIT_MISS) return sample_environment(pd, d);             // PrimaryMiss, :160-164
+            if (h.x == HIT_UNTRACED) return mk3(0.0f, 0.0f, 0.0f);
+            RayD r;
+            r.o = o; r.tmin = tmin; r.d = d; r.tmax = RAY_MAX_T;
+            ResolveIO<L + 1, MAXL> io(pd, pd.lv[L + 1].slot_j[slot], pix);
+            return closest_hit(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.lv[L + 1].inst[slot], depth + 1u, pix);
+        }
     }
 };
 
@@ -437,7 +441,7 @@ RT_DEV void wave_add(uint32_t v, uint32_t *counter)
 
 // ---- kernels -------------------------------------------------------------------------
 
-// primary stage: raygen is the ray source, hit0/inst0 the sink (pixel-indexed)
+// primary stage: raygen is the ray source, the level-0 hit records the sink (indexed by pixel slot)
 struct PrimarySrc {
     const PipeDev &pd;
     RT_DEV uint32_t count() const { return pd.cap; }
@@ -455,8 +459,8 @@ struct PrimarySink {
     RT_DEV void store(uint32_t q, const HitD &h, bool) const
     {
         const bool hit = h.inst != RT_NO_HIT;
-        pd.hit0[q] = make_float4(hit ? h.t : HIT_MISS, h.u, h.v, __uint_as_float(h.prim));
-        pd.inst0[q] = h.inst;
+        pd.lv[0].hit[q] = make_float4(hit ? h.t : HIT_MISS, h.u, h.v, __uint_as_float(h.prim));
+        pd.lv[0].inst[q] = h.inst;
     }
 };
 
@@ -469,36 +473,51 @@ __global__ void __launch_bounds__(PBLOCK) k_primary(PipeDev pd)
     trace_wave<STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, &pd.counters[C_POOL_PRIMARY], smem, nullptr);   // one 8x8 tile per wave
 }
 
-// compaction of the pixels whose primary ray hit: ballot + popcount prefix sum, one atomic per wave
-__global__ void __launch_bounds__(CBLOCK) k_compact_primary(PipeDev pd)
+// Compaction of the hits of level L (they get shaded): ballot + popcount prefix sums, one atomic per block.
+// Level 0 runs over the pixel slots, level 1 over its two batches, deeper levels over one batch.
+__global__ void __launch_bounds__(CBLOCK) k_compact_level(PipeDev pd, int L)
 {
-    const uint32_t q = blockIdx.x * CBLOCK + threadIdx.x;
-    const bool hit = q < pd.cap && pd.hit0[q].x != HIT_MISS;
-    const uint32_t k = block_compact(hit, &pd.counters[C_N0]);
-    if (q < pd.cap) pd.pix_k[q] = hit ? k : RT_NO_HIT;
-    if (hit) pd.klist[k] = q;
+    const uint32_t idx = blockIdx.x * CBLOCK + threadIdx.x;
+    bool in_range;
+    size_t slot;
+    if (L == 0) { in_range = idx < pd.cap; slot = idx; }
+    else {
+        const uint32_t n = pd.counters[C_NHIT + L - 1];
+        const uint32_t batches = L == 1 ? 2u : 1u;
+        in_range = idx < batches * n;
+        slot = !in_range ? 0 : (L == 1 ? (size_t)(idx / n) * pd.cap + idx % n : idx);
+    }
+    const bool hit = in_range && pd.lv[L].hit[slot].x >= 0.0f;
+    const uint32_t j = block_compact(hit, &pd.counters[C_NHIT + L]);
+    if (in_range) pd.lv[L].slot_j[slot] = hit ? j : RT_NO_HIT;
+    if (hit) pd.lv[L].jlist[j] = (uint32_t)slot;
 }
 
-__global__ void __launch_bounds__(PBLOCK) k_shade0_emit(PipeDev pd, uint32_t shadow_slots)
+// closest-hit shading of the compacted hits of level L in emit mode: writes their shadow rays and the rays
+// of level L+1; slots a hit does not use are marked "not traced"
+template <bool PRIMARY>
+__global__ void __launch_bounds__(PBLOCK) k_shade_emit(PipeDev pd, int level, uint32_t shadow_slots, uint32_t emit_next)
 {
-    const uint32_t k = blockIdx.x * PBLOCK + threadIdx.x;
-    uint32_t n_shadow = 0, n_sec = 0;
-    if (k < pd.counters[C_N0]) {
-        const uint32_t q = pd.klist[k];
-        uint32_t px, py;
-        (void)pix_xy(pd, q, px, py);
-        const RayD r = primary_ray(pd, px, py);
-        const float4 h = pd.hit0[q];
-        EmitIO0 io(pd, k);
-        (void)closest_hit(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.inst0[q], 0u, px + py * pd.width);
-        for (uint32_t s = 0; s < shadow_slots; s++)
-            if (!(io.shadow_mask & (1u << s))) store_invalid(pd.sh0O, pd.sh0D, (size_t)s * pd.cap + k);
-        for (uint32_t w = 0; w < 2; w++)
-            if (!(io.sec_mask & (1u << w))) store_invalid(pd.secO, pd.secD, (size_t)w * pd.cap + k);
-        n_shadow = (uint32_t)__popc(io.shadow_mask);
-        n_sec = (uint32_t)__popc(io.sec_mask);
+    const int L = PRIMARY ? 0 : level;          // (depth 0 compiles to its own kernel: it alone samples indirect diffuse)
+    __builtin_assume(PRIMARY || L >= 1);
+    const uint32_t idx = blockIdx.x * PBLOCK + threadIdx.x;
+    if (idx >= pd.counters[C_NHIT + L]) return;
+    const uint32_t slot = pd.lv[L].jlist[idx];
+    const uint32_t q = L == 0 ? slot : pd.lv[L].pix[slot];
+    uint32_t px, py;
+    (void)pix_xy(pd, q, px, py);
+    const RayD r = L == 0 ? primary_ray(pd, px, py) : load_ray(pd.lv[L].O, pd.lv[L].D, slot);
+    const float4 h = pd.lv[L].hit[slot];
+    EmitIO io(pd, L, idx, q);
+    (void)closest_hit(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.lv[L].inst[slot], (uint32_t)L, px + py * pd.width);
+    for (uint32_t s = 0; s < shadow_slots; s++)
+        if (!(io.shadow_mask & (1u << s))) store_invalid(pd.lv[L].shO, pd.lv[L].shD, (size_t)s * hcap(pd, L) + idx);
+    if (emit_next) {
+        if (L == 0) {
+            for (uint32_t w = 0; w < 2; w++)
+                if (!(io.sec_mask & (1u << w))) store_invalid(pd.lv[1].O, pd.lv[1].D, (size_t)w * pd.cap + idx);
+        } else if (!io.sec_mask) store_invalid(pd.lv[L + 1].O, pd.lv[L + 1].D, idx);
     }
-    (void)n_shadow; (void)n_sec;       // rays are counted by the traversal waves (one atomic per persistent wave)
 }
 
 // a ray queue of `batches` batches of *count rays; batch b lives at [b*stride, b*stride + *count)
@@ -520,12 +539,6 @@ struct QueueSrc {
     }
 };
 
-struct ShadowSink {      // ShadowMiss sets visibility 1 (ProgressiveRaytracing.hlsl:178-182)
-    QueueSrc q;
-    uint32_t *vis;
-    RT_DEV void store(uint32_t i, const HitD &h, bool) const { vis[q.slot(i)] = h.inst == RT_NO_HIT ? 1u : 0u; }
-};
-
 struct SecondarySink {
     QueueSrc q;
     float4 *hit1;
@@ -539,30 +552,54 @@ struct SecondarySink {
     }
 };
 
-// every shadow ray of the frame in ONE launch: queue 0 (rays from first hits) then queue 1 (from second hits)
-struct ShadowSrc2 {
-    QueueSrc a, b;
-    RT_DEV uint32_t count() const { return a.count() + b.count(); }
-    RT_DEV uint32_t flags() const { return a.fl; }
-    RT_DEV bool load(uint32_t i, RayD &r) const { const uint32_t ca = a.count(); return i < ca ? a.load(i, r) : b.load(i - ca, r); }
+// every shadow ray of the frame in ONE launch: the shadow queues of all shaded levels, back to back
+struct ShadowSrcN {
+    QueueSrc q[MAXD + 1];
+    uint32_t *vis[MAXD + 1];
+    int nq;
+    // (the loops are fully unrolled so that q[k] is always a compile-time member of the kernel argument)
+    RT_DEV uint32_t count() const
+    {
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k <= MAXD; k++) if (k < nq) c += q[k].count();
+        return c;
+    }
+    RT_DEV uint32_t flags() const { return q[0].fl; }
+    RT_DEV bool load(uint32_t i, RayD &r) const
+    {
+#pragma unroll
+        for (int k = 0; k <= MAXD; k++) {
+            if (k < nq) {
+                const uint32_t c = q[k].count();
+                if (i < c) return q[k].load(i, r);
+                i -= c;
+            }
+        }
+        r.o = mk3(0.0f, 0.0f, 0.0f); r.d = r.o; r.tmin = 0.0f; r.tmax = -1.0f;
+        return false;
+    }
 };
-struct ShadowSink2 {
-    ShadowSrc2 q;
-    uint32_t *vis_a, *vis_b;
+struct ShadowSinkN {      // ShadowMiss sets visibility 1 (ProgressiveRaytracing.hlsl:178-182)
+    ShadowSrcN s;
     RT_DEV void store(uint32_t i, const HitD &h, bool) const
     {
-        const uint32_t ca = q.a.count();
-        const uint32_t v = h.inst == RT_NO_HIT ? 1u : 0u;
-        if (i < ca) vis_a[q.a.slot(i)] = v;
-        else vis_b[q.b.slot(i - ca)] = v;
+#pragma unroll
+        for (int k = 0; k <= MAXD; k++) {
+            if (k < s.nq) {
+                const uint32_t c = s.q[k].count();
+                if (i < c) { s.vis[k][s.q[k].slot(i)] = h.inst == RT_NO_HIT ? 1u : 0u; return; }
+                i -= c;
+            }
+        }
     }
 };
 
 template <int STACK, bool TWO_LEVEL>
-__global__ void __launch_bounds__(PBLOCK) k_trace_shadow(SceneDev sc, ShadowSrc2 src, uint32_t *vis_a, uint32_t *vis_b, uint32_t *pool, uint32_t *stat)
+__global__ void __launch_bounds__(PBLOCK) k_trace_shadow(SceneDev sc, ShadowSrcN src, uint32_t *pool, uint32_t *stat)
 {
     __shared__ int smem[STACK * PBLOCK];
-    ShadowSink2 sink = {src, vis_a, vis_b};
+    ShadowSinkN sink = {src};
     trace_wave<STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem, stat);
 }
 
@@ -574,40 +611,7 @@ __global__ void __launch_bounds__(PBLOCK) k_trace_secondary(SceneDev sc, QueueSr
     trace_wave<STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem, stat);
 }
 
-// compaction of the secondary rays that hit (they get shaded and emit shadow rays)
-__global__ void __launch_bounds__(CBLOCK) k_compact_secondary(PipeDev pd)
-{
-    const uint32_t n = pd.counters[C_N0];
-    const uint32_t idx = blockIdx.x * CBLOCK + threadIdx.x;
-    const bool in_range = idx < 2u * n;
-    const size_t slot = in_range ? (size_t)(idx / n) * pd.cap + idx % n : 0;
-    const bool hit = in_range && pd.hit1[slot].x >= 0.0f;
-    const uint32_t j = block_compact(hit, &pd.counters[C_N1]);
-    if (in_range) pd.slot_j[slot] = hit ? j : RT_NO_HIT;
-    if (hit) pd.jlist[j] = (uint32_t)slot;
-}
-
-__global__ void __launch_bounds__(PBLOCK) k_shade1_emit(PipeDev pd)
-{
-    const uint32_t j = blockIdx.x * PBLOCK + threadIdx.x;
-    uint32_t n_shadow = 0;
-    if (j < pd.counters[C_N1]) {
-        const uint32_t slot = pd.jlist[j];
-        const uint32_t k = slot % pd.cap;
-        const uint32_t q = pd.klist[k];
-        uint32_t px, py;
-        (void)pix_xy(pd, q, px, py);
-        const RayD r = load_ray(pd.secO, pd.secD, slot);
-        const float4 h = pd.hit1[slot];
-        EmitIO1 io(pd, j);
-        (void)closest_hit(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.inst1[slot], 1u, px + py * pd.width);
-        for (uint32_t s = 0; s < 2; s++)
-            if (!(io.shadow_mask & (1u << s))) store_invalid(pd.sh1O, pd.sh1D, (size_t)s * 2u * pd.cap + j);
-        n_shadow = (uint32_t)__popc(io.shadow_mask);
-    }
-    (void)n_shadow;
-}
-
+template <int MAXL>
 __global__ void __launch_bounds__(PBLOCK) k_resolve(PipeDev pd)
 {
     const uint32_t q = blockIdx.x * PBLOCK + threadIdx.x;
@@ -615,15 +619,15 @@ __global__ void __launch_bounds__(PBLOCK) k_resolve(PipeDev pd)
     uint32_t px, py;
     if (!pix_xy(pd, q, px, py)) return;
     const RayD r = primary_ray(pd, px, py);
-    const float4 h = pd.hit0[q];
+    const float4 h = pd.lv[0].hit[q];
     Shaded sh;
     if (h.x == HIT_MISS) {
         sh.color = sample_environment(pd, r.d);             // PrimaryMiss
         sh.aov_direct = sh.color;                           // RealtimeRaytracing.hlsl:119-126
         sh.aov_indirect = mk3(0.0f, 0.0f, 0.0f);
     } else {
-        ResolveIO0 io(pd, pd.pix_k[q], px + py * pd.width);
-        sh = closest_hit_aov(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.inst0[q], 0u, px + py * pd.width);
+        ResolveIO<0, MAXL> io(pd, pd.lv[0].slot_j[q], px + py * pd.width);
+        sh = closest_hit_aov(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.lv[0].inst[q], 0u, px + py * pd.width);
     }
     const size_t pixel = (size_t)py * pd.width + px;
     if (pd.kind == RT_PIPELINE_REALTIME) {                  // RealtimeRaytracing.hlsl:44-45: two AOVs, no accumulation
@@ -652,8 +656,8 @@ __global__ void k_add_totals(const uint32_t *__restrict__ counters, unsigned lon
     totals[0] += cap;
     totals[1] += counters[C_SECONDARY];
     totals[2] += counters[C_SHADOW];
-    totals[3] += counters[C_N0];
-    totals[4] += counters[C_N1];
+    totals[3] += counters[C_NHIT + 0];
+    for (int l = 1; l <= MAXD; l++) totals[4] += counters[C_NHIT + l];
     totals[5] += 1;
 }
 
@@ -747,10 +751,12 @@ struct rt_pipeline {
     bool have_pfc = false;
     uint32_t max_rad = 1, max_shadow = 2, accum_mode = RT_ACCUM_RUNNING_MEAN;
     // queues (sized for `cap` pixels)
-    uint32_t cap = 0, sh0_batches = 0;
-    DevBuf hit0, inst0, pix_k, klist, counters, secO, secD, hit1, inst1, slot_j, jlist, sh0O, sh0D, vis0, sh1O, sh1D, vis1;
+    uint32_t cap = 0, sh0_batches = 0, levels = 0;
+    struct LevelBuf { DevBuf O, D, hit, inst, slot_j, jlist, pix, shO, shD, vis; } lv[MAXD + 1];
+    DevBuf counters;
     DevBuf half_out;
-    std::vector<hipEvent_t> ring;      // 8 events per remembered frame
+    std::vector<hipEvent_t> ring;      // EV_COUNT events per remembered frame
+    std::vector<uint8_t> ring_levels;  // radiance levels each remembered frame ran
     int ring_frames = 0;               // 0 = timing off
     uint64_t ring_pos = 0;             // frames recorded since enable / reset
     DevBuf totals, work;
@@ -763,55 +769,81 @@ struct rt_pipeline {
 
 namespace {
 
-int ensure_queues(rt_pipeline *p, uint32_t cap, uint32_t sh0_batches)
+// events of one frame: start | primary | shade 0 | (trace l, shade l) for l = 1..MAXD | shadow | resolve
+constexpr int EV_COUNT = 5 + 2 * MAXD;
+constexpr int EV_SHADOW = 3 + 2 * MAXD, EV_RESOLVE = 4 + 2 * MAXD;
+
+int ensure_queues(rt_pipeline *p, uint32_t cap, uint32_t sh0_batches, uint32_t levels)
 {
-    if (cap <= p->cap && sh0_batches <= p->sh0_batches) return RT_OK;
+    if (cap <= p->cap && sh0_batches <= p->sh0_batches && levels <= p->levels) return RT_OK;
     const size_t c = cap > p->cap ? cap : p->cap;
     const size_t sb = sh0_batches > p->sh0_batches ? sh0_batches : p->sh0_batches;
-    RT_TRY(p->hit0.reserve(c * 16)); RT_TRY(p->inst0.reserve(c * 4));
-    RT_TRY(p->pix_k.reserve(c * 4)); RT_TRY(p->klist.reserve(c * 4));
+    const uint32_t nl = levels > p->levels ? levels : p->levels;
     RT_TRY(p->counters.reserve(C_COUNT * 4));
-    RT_TRY(p->secO.reserve(2 * c * 16)); RT_TRY(p->secD.reserve(2 * c * 16));
-    RT_TRY(p->hit1.reserve(2 * c * 16)); RT_TRY(p->inst1.reserve(2 * c * 4));
-    RT_TRY(p->slot_j.reserve(2 * c * 4)); RT_TRY(p->jlist.reserve(2 * c * 4));
-    RT_TRY(p->sh0O.reserve(sb * c * 16)); RT_TRY(p->sh0D.reserve(sb * c * 16)); RT_TRY(p->vis0.reserve(sb * c * 4));
-    RT_TRY(p->sh1O.reserve(4 * c * 16)); RT_TRY(p->sh1D.reserve(4 * c * 16)); RT_TRY(p->vis1.reserve(4 * c * 4));
+    for (uint32_t l = 0; l <= nl; l++) {
+        rt_pipeline::LevelBuf &b = p->lv[l];
+        const size_t slots = l == 0 ? c : 2 * c, shadow = l == 0 ? sb * c : 4 * c;
+        if (l > 0) { RT_TRY(b.O.reserve(slots * 16)); RT_TRY(b.D.reserve(slots * 16)); RT_TRY(b.pix.reserve(slots * 4)); }
+        RT_TRY(b.hit.reserve(slots * 16)); RT_TRY(b.inst.reserve(slots * 4));
+        RT_TRY(b.slot_j.reserve(slots * 4)); RT_TRY(b.jlist.reserve(slots * 4));
+        RT_TRY(b.shO.reserve(shadow * 16)); RT_TRY(b.shD.reserve(shadow * 16)); RT_TRY(b.vis.reserve(shadow * 4));
+    }
     p->cap = (uint32_t)c;
     p->sh0_batches = (uint32_t)sb;
+    p->levels = nl;
     return RT_OK;
 }
+
+// radiance levels a frame traces: level l exists when hits of depth l-1 may spawn rays
+inline uint32_t frame_levels(const rt_pipeline *p) { return p->max_rad < (uint32_t)MAXD ? p->max_rad : (uint32_t)MAXD; }
 
 template <int STACK, bool TWO_LEVEL>
 void launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
 {
     hipStream_t st = p->ctx->stream;
     const bool T = p->ring_frames > 0;
-    hipEvent_t *ev = T ? &p->ring[(size_t)(p->ring_pos % (uint64_t)p->ring_frames) * 8] : nullptr;
+    const size_t ring_slot = T ? (size_t)(p->ring_pos % (uint64_t)p->ring_frames) : 0;
+    hipEvent_t *ev = T ? &p->ring[ring_slot * EV_COUNT] : nullptr;
     const uint32_t cap = pd.cap;
     const rt_context *ctx = p->ctx;
+    const uint32_t levels = frame_levels(p);
     const uint32_t any = RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH | RT_RAY_FLAG_SKIP_CLOSEST_HIT_SHADER;
-    const QueueSrc sec = {pd.secO, pd.secD, &pd.counters[C_N0], cap, 2u, RT_RAY_FLAG_NONE};          // ProgressiveRaytracing.hlsl:53
-    const QueueSrc sh0 = {pd.sh0O, pd.sh0D, &pd.counters[C_N0], cap, shadow_slots, any};              // RaytracingCommon.hlsli:94
-    const QueueSrc sh1 = {pd.sh1O, pd.sh1D, &pd.counters[C_N1], 2u * cap, 2u, any};
     if (T) (void)hipEventRecord(ev[0], st);
     // primary rays are coherent: one 8x8 tile per wave, scheduled by the hardware dispatcher
     k_primary<STACK, TWO_LEVEL><<<blocks(cap), PBLOCK, 0, st>>>(pd);
-    k_compact_primary<<<(cap + CBLOCK - 1) / CBLOCK, CBLOCK, 0, st>>>(pd);
+    k_compact_level<<<(cap + CBLOCK - 1) / CBLOCK, CBLOCK, 0, st>>>(pd, 0);
     if (T) (void)hipEventRecord(ev[1], st);
-    k_shade0_emit<<<blocks(cap), PBLOCK, 0, st>>>(pd, shadow_slots);
+    k_shade_emit<true><<<blocks(cap), PBLOCK, 0, st>>>(pd, 0, shadow_slots, levels >= 1 ? 1u : 0u);
     if (T) (void)hipEventRecord(ev[2], st);
-    k_trace_secondary<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_secondary<STACK, TWO_LEVEL>, PBLOCK, (size_t)cap * 2), PBLOCK, 0, st>>>(pd.sc, sec, pd.hit1, pd.inst1, &pd.counters[C_POOL_SECONDARY],
-                                                                                      &pd.counters[C_SECONDARY]);
-    k_compact_secondary<<<(2 * cap + CBLOCK - 1) / CBLOCK, CBLOCK, 0, st>>>(pd);
-    if (T) { (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }      // (shadow stage 0 is merged into the launch below)
-    k_shade1_emit<<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd);
-    if (T) (void)hipEventRecord(ev[5], st);
-    const ShadowSrc2 shadows = {sh0, sh1};
-    k_trace_shadow<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL>, PBLOCK, (size_t)cap * (shadow_slots + 4)), PBLOCK, 0, st>>>(
-        pd.sc, shadows, pd.vis0, pd.vis1, &pd.counters[C_POOL_SHADOW0], &pd.counters[C_SHADOW]);
-    if (T) (void)hipEventRecord(ev[6], st);
-    k_resolve<<<blocks(cap), PBLOCK, 0, st>>>(pd);
-    if (T) { (void)hipEventRecord(ev[7], st); p->ring_pos++; }
+    ShadowSrcN shadows;
+    memset(&shadows, 0, sizeof shadows);
+    shadows.q[0] = QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, shadow_slots, any};         // RaytracingCommon.hlsli:94
+    shadows.vis[0] = pd.lv[0].vis;
+    shadows.nq = 1;
+    size_t shadow_max = (size_t)cap * shadow_slots;
+    for (uint32_t l = 1; l <= levels; l++) {
+        // level 1: the diffuse and the specular batch of the primary hits; deeper: one ray per hit of level l-1
+        const QueueSrc rays = {pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE};   // ProgressiveRaytracing.hlsl:53
+        k_trace_secondary<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_secondary<STACK, TWO_LEVEL>, PBLOCK, (size_t)cap * 2), PBLOCK, 0, st>>>(
+            pd.sc, rays, pd.lv[l].hit, pd.lv[l].inst, &pd.counters[C_POOL_LEVEL + l - 1], &pd.counters[C_SECONDARY]);
+        k_compact_level<<<(2 * cap + CBLOCK - 1) / CBLOCK, CBLOCK, 0, st>>>(pd, (int)l);
+        if (T) (void)hipEventRecord(ev[3 + 2 * (l - 1)], st);
+        const bool casts_shadows = l < pd.max_shadow, spawns = l < levels;
+        if (casts_shadows || spawns) k_shade_emit<false><<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd, (int)l, 2u, spawns ? 1u : 0u);
+        if (T) (void)hipEventRecord(ev[4 + 2 * (l - 1)], st);
+        if (casts_shadows) {
+            shadows.q[shadows.nq] = QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any};
+            shadows.vis[shadows.nq] = pd.lv[l].vis;
+            shadows.nq++;
+            shadow_max += (size_t)cap * 4;
+        }
+    }
+    k_trace_shadow<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL>, PBLOCK, shadow_max), PBLOCK, 0, st>>>(
+        pd.sc, shadows, &pd.counters[C_POOL_SHADOW], &pd.counters[C_SHADOW]);
+    if (T) (void)hipEventRecord(ev[EV_SHADOW], st);
+    if (levels <= 1) k_resolve<1><<<blocks(cap), PBLOCK, 0, st>>>(pd);
+    else k_resolve<MAXD><<<blocks(cap), PBLOCK, 0, st>>>(pd);
+    if (T) { (void)hipEventRecord(ev[EV_RESOLVE], st); p->ring_levels[ring_slot] = (uint8_t)levels; p->ring_pos++; }
     k_add_totals<<<1, 64, 0, st>>>(pd.counters, p->totals.as<unsigned long long>(), pd.tw * pd.th);
 }
 
@@ -846,10 +878,12 @@ int rt_pipeline_destroy(rt_pipeline *p)
     if (!p) return RT_OK;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    DevBuf *all[] = {&p->d_mats, &p->d_env, &p->accum_own, &p->aov_own, &p->hit0, &p->inst0, &p->pix_k, &p->klist, &p->counters, &p->secO, &p->secD,
-                     &p->hit1, &p->inst1, &p->slot_j, &p->jlist, &p->sh0O, &p->sh0D, &p->vis0, &p->sh1O, &p->sh1D, &p->vis1, &p->half_out,
-                     &p->totals, &p->work};
+    DevBuf *all[] = {&p->d_mats, &p->d_env, &p->accum_own, &p->aov_own, &p->counters, &p->half_out, &p->totals, &p->work};
     for (DevBuf *b : all) b->release();
+    for (rt_pipeline::LevelBuf &l : p->lv) {
+        DevBuf *lb[] = {&l.O, &l.D, &l.hit, &l.inst, &l.slot_j, &l.jlist, &l.pix, &l.shO, &l.shD, &l.vis};
+        for (DevBuf *b : lb) b->release();
+    }
     for (hipEvent_t e : p->ring) if (e) (void)hipEventDestroy(e);
     if (p->scene) rt_scene_destroy(p->scene);
     rt_context *ctx = p->ctx;
@@ -954,8 +988,8 @@ int rt_pipeline_build_acceleration_structures(rt_pipeline *p)
 int rt_pipeline_set_depth_limits(rt_pipeline *p, uint32_t max_radiance_depth, uint32_t max_shadow_depth)
 {
     RT_REQUIRE(p, "null pipeline");
-    if (max_radiance_depth > 1) {
-        rt_set_error("max radiance depth %u: the wavefront DAG is unrolled for depth <= 1", max_radiance_depth);
+    if (max_radiance_depth > (uint32_t)MAXD) {
+        rt_set_error("max radiance depth %u: the wavefront DAG holds at most %d radiance levels", max_radiance_depth, MAXD);
         return RT_ERR_UNSUPPORTED;
     }
     p->max_rad = max_radiance_depth;
@@ -1017,7 +1051,7 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
     const uint32_t tw = x1 - x0, th = y1 - y0;
     const uint32_t tiles_x = (tw + 7u) / 8u, cap = tiles_x * ((th + 7u) / 8u) * 64u;
     const uint32_t shadow_slots = (p->kind == RT_PIPELINE_PROGRESSIVE && p->pfc.options.showAmbientOcclusionOnly) ? 4u : 2u;
-    RT_TRY(ensure_queues(p, cap, shadow_slots));
+    RT_TRY(ensure_queues(p, cap, shadow_slots, frame_levels(p)));
     if (!p->totals.p) {
         RT_TRY(p->totals.reserve(8 * sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(p->totals.p, 0, 8 * sizeof(unsigned long long), st));
@@ -1038,14 +1072,14 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
     pd.accum = p->accum;
     pd.aov_direct = p->accum;                       // realtime: output 0 = direct lighting, output 1 = indirect specular
     pd.aov_indirect = p->aov_own.as<float4>();
-    pd.hit0 = p->hit0.as<float4>(); pd.inst0 = p->inst0.as<uint32_t>();
-    pd.pix_k = p->pix_k.as<uint32_t>(); pd.klist = p->klist.as<uint32_t>();
     pd.counters = p->counters.as<uint32_t>();
-    pd.secO = p->secO.as<float4>(); pd.secD = p->secD.as<float4>();
-    pd.hit1 = p->hit1.as<float4>(); pd.inst1 = p->inst1.as<uint32_t>();
-    pd.slot_j = p->slot_j.as<uint32_t>(); pd.jlist = p->jlist.as<uint32_t>();
-    pd.sh0O = p->sh0O.as<float4>(); pd.sh0D = p->sh0D.as<float4>(); pd.vis0 = p->vis0.as<uint32_t>();
-    pd.sh1O = p->sh1O.as<float4>(); pd.sh1D = p->sh1D.as<float4>(); pd.vis1 = p->vis1.as<uint32_t>();
+    for (int l = 0; l <= MAXD; l++) {
+        rt_pipeline::LevelBuf &b = p->lv[l];
+        LevelDev &d = pd.lv[l];
+        d.O = b.O.as<float4>(); d.D = b.D.as<float4>(); d.hit = b.hit.as<float4>(); d.inst = b.inst.as<uint32_t>();
+        d.slot_j = b.slot_j.as<uint32_t>(); d.jlist = b.jlist.as<uint32_t>(); d.pix = b.pix.as<uint32_t>();
+        d.shO = b.shO.as<float4>(); d.shD = b.shD.as<float4>(); d.vis = b.vis.as<uint32_t>();
+    }
     HIP_TRY(hipMemsetAsync(pd.counters, 0, C_COUNT * 4, st));
     const uint32_t need = p->scene->stack_need;
     // LDS stack rows -> resident 256-thread blocks per CU: 24 -> 6, 31 -> 5, 39 -> 4, 52 -> 3, 78 -> 2, 160 -> 1
@@ -1115,18 +1149,35 @@ int rt_pipeline_enable_timing(rt_pipeline *p, int frames)
     HIP_TRY(hipSetDevice(p->ctx->device));
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     for (hipEvent_t e : p->ring) if (e) (void)hipEventDestroy(e);
-    p->ring.assign((size_t)frames * 8, nullptr);
+    p->ring.assign((size_t)frames * EV_COUNT, nullptr);
+    p->ring_levels.assign((size_t)frames, 0);
     for (hipEvent_t &e : p->ring) HIP_TRY(hipEventCreate(&e));
     p->ring_frames = frames;
     p->ring_pos = 0;
     return RT_OK;
 }
 
+// ms: primary | shade 0 | secondary traces (all levels) | 0 | secondary shades (all levels) | shadow | resolve | total
 static int stage_times(rt_pipeline *p, uint64_t frame, float ms[8])
 {
-    hipEvent_t *ev = &p->ring[(size_t)(frame % (uint64_t)p->ring_frames) * 8];
-    for (int k = 0; k < 7; k++) HIP_TRY(hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]));
-    HIP_TRY(hipEventElapsedTime(&ms[7], ev[0], ev[7]));
+    const size_t slot = (size_t)(frame % (uint64_t)p->ring_frames);
+    hipEvent_t *ev = &p->ring[slot * EV_COUNT];
+    const int levels = p->ring_levels[slot];
+    for (int k = 0; k < 8; k++) ms[k] = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms[1], ev[1], ev[2]));
+    int last = 2;
+    for (int l = 1; l <= levels; l++) {
+        float t = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&t, ev[last], ev[3 + 2 * (l - 1)]));
+        ms[2] += t;
+        HIP_TRY(hipEventElapsedTime(&t, ev[3 + 2 * (l - 1)], ev[4 + 2 * (l - 1)]));
+        ms[4] += t;
+        last = 4 + 2 * (l - 1);
+    }
+    HIP_TRY(hipEventElapsedTime(&ms[5], ev[last], ev[EV_SHADOW]));
+    HIP_TRY(hipEventElapsedTime(&ms[6], ev[EV_SHADOW], ev[EV_RESOLVE]));
+    HIP_TRY(hipEventElapsedTime(&ms[7], ev[0], ev[EV_RESOLVE]));
     return RT_OK;
 }
 
@@ -1146,8 +1197,9 @@ int rt_pipeline_get_stats(rt_pipeline *p, rt_stats *out)
     uint32_t c[C_COUNT];
     HIP_TRY(hipMemcpy(c, p->counters.p, sizeof c, hipMemcpyDeviceToHost));
     out->rays_primary = (uint64_t)(p->last_tile[2] - p->last_tile[0]) * (p->last_tile[3] - p->last_tile[1]);
-    out->primary_hits = c[C_N0];
-    out->secondary_hits = c[C_N1];
+    out->primary_hits = c[C_NHIT];
+    out->secondary_hits = 0;
+    for (int l = 1; l <= MAXD; l++) out->secondary_hits += c[C_NHIT + l];
     out->rays_secondary = c[C_SECONDARY];
     out->rays_shadow = c[C_SHADOW];
     out->frames = 1;
@@ -1207,12 +1259,17 @@ int rt_pipeline_count_work(rt_pipeline *p, rt_stage_work *out)
     const uint32_t cap = pd.cap, ss = p->last_shadow_slots;
     const uint32_t any = RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH | RT_RAY_FLAG_SKIP_CLOSEST_HIT_SHADER;
     k_count_primary<<<blocks(cap), PBLOCK, 0, st>>>(pd, w + 3 * RT_STAGE_PRIMARY);
-    k_count_queue<<<blocks(cap) * 2 + 2, PBLOCK, 0, st>>>(pd.sc, pd.secO, pd.secD, &pd.counters[C_N0], cap, 2, RT_RAY_FLAG_NONE,
-                                                          w + 3 * RT_STAGE_SECONDARY);
-    k_count_queue<<<(blocks(cap) + 1) * ss, PBLOCK, 0, st>>>(pd.sc, pd.sh0O, pd.sh0D, &pd.counters[C_N0], cap, ss, any,
+    k_count_queue<<<(blocks(cap) + 1) * ss, PBLOCK, 0, st>>>(pd.sc, pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any,
                                                              w + 3 * RT_STAGE_SHADOW0);
-    k_count_queue<<<(blocks((size_t)cap * 2) + 1) * 2, PBLOCK, 0, st>>>(pd.sc, pd.sh1O, pd.sh1D, &pd.counters[C_N1], 2 * cap, 2, any,
-                                                                        w + 3 * RT_STAGE_SHADOW1);
+    const uint32_t levels = pd.max_rad < (uint32_t)MAXD ? pd.max_rad : (uint32_t)MAXD;
+    for (uint32_t l = 1; l <= levels; l++) {        // every secondary level adds into the same two rows
+        const uint32_t batches = l == 1 ? 2u : 1u;
+        k_count_queue<<<(blocks((size_t)cap * 2) + 1) * batches, PBLOCK, 0, st>>>(pd.sc, pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, batches,
+                                                                                   RT_RAY_FLAG_NONE, w + 3 * RT_STAGE_SECONDARY);
+        if (l < pd.max_shadow)
+            k_count_queue<<<(blocks((size_t)cap * 2) + 1) * 2, PBLOCK, 0, st>>>(pd.sc, pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2 * cap, 2, any,
+                                                                                w + 3 * RT_STAGE_SHADOW1);
+    }
     HIP_TRY(hipGetLastError());
     unsigned long long h[RT_STAGE_COUNT * 3];
     HIP_TRY(hipMemcpyAsync(h, w, sizeof h, hipMemcpyDeviceToHost, st));
@@ -1231,8 +1288,8 @@ int rt_pipeline_read_primary_hits(rt_pipeline *p, float *t, uint32_t *prim, uint
     const size_t cap = pd.cap;
     std::vector<float4> h(cap);
     std::vector<uint32_t> hi(cap);
-    HIP_TRY(hipMemcpy(h.data(), p->hit0.p, cap * 16, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(hi.data(), p->inst0.p, cap * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h.data(), p->lv[0].hit.p, cap * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hi.data(), p->lv[0].inst.p, cap * 4, hipMemcpyDeviceToHost));
     for (size_t q = 0; q < cap; q++) {          // slots are 8x8-tiled: scatter back to scanline order
         const uint32_t tl = (uint32_t)(q >> 6), w = (uint32_t)(q & 63u);
         const uint32_t lx = (tl % pd.tiles_x) * 8u + (w & 7u), ly = (tl / pd.tiles_x) * 8u + (w >> 3);

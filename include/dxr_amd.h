@@ -147,7 +147,9 @@ int rt_pipeline_create_output(rt_pipeline *p, uint32_t format, uint32_t width, u
 /* Render into caller-owned device memory (w*h*4 floats), e.g. a torch tensor. */
 int rt_pipeline_bind_output(rt_pipeline *p, void *device_rgba32f, uint32_t width, uint32_t height);
 int rt_pipeline_build_acceleration_structures(rt_pipeline *p);               /* .cpp:99-102 */
-/* MAX_RADIANCE_RAY_DEPTH / MAX_SHADOW_RAY_DEPTH (RaytracingCommon.hlsli:11-12); defaults 1, 2 */
+/* MAX_RADIANCE_RAY_DEPTH / MAX_SHADOW_RAY_DEPTH (RaytracingCommon.hlsli:11-12); defaults 1, 2 (the values the
+ * reference compiles in).  The radiance depth may be raised to 4 (specular chains, BASELINE config 5);
+ * more -> RT_ERR_UNSUPPORTED.  The shadow depth is unbounded (levels past the radiance depth cast none). */
 int rt_pipeline_set_depth_limits(rt_pipeline *p, uint32_t max_radiance_depth, uint32_t max_shadow_depth);
 int rt_pipeline_set_accumulation_mode(rt_pipeline *p, uint32_t mode);        /* RT_ACCUM_* */
 int rt_pipeline_clear_output(rt_pipeline *p);

@@ -126,17 +126,21 @@ def test_material_types_and_depth_limits(gpu, capi, oracle, mtype, refl):
     osc = make_oracle_scene(oracle, [(v, i)], [(0, None)])
     host = capi.ProgressiveHost(3)
     cam = cam_array(scenes.cornell_camera(), W / H)
-    for (mr, ms) in ((1, 2), (0, 2), (1, 1), (1, 0)):
+    # the reference compiles (1, 2) in (RaytracingCommon.hlsli:11-12); deeper specular chains are BASELINE config 5
+    for (mr, ms) in ((1, 2), (0, 2), (1, 1), (1, 0), (2, 2), (4, 2), (3, 4), (4, 5), (2, 1)):
         p.set_depth_limits(mr, ms)
         p.clear_output()
         pfc = host.update(cam, 0.0, 5, W, H)
         pfc["cameraParams"]["accumCount"] = 0
         p.update(pfc)
         p.render()
-        acc, _ = osc.render(mat, pfc, W, H, max_radiance_depth=mr, max_shadow_depth=ms, nthreads=8)
+        acc, ost = osc.render(mat, pfc, W, H, max_radiance_depth=mr, max_shadow_depth=ms, nthreads=8)
         assert np.array_equal(p.read_output(), acc), "depth limits (%d,%d)" % (mr, ms)
+        gst = p.stats()
+        for key in ("rays_primary", "rays_secondary", "rays_shadow", "primary_hits", "secondary_hits"):
+            assert gst[key] == ost[key], (key, mr, ms)
     with pytest.raises(capi.RtError):
-        p.set_depth_limits(2, 2)
+        p.set_depth_limits(5, 2)
 
 
 def test_instanced_scene_materials_and_misses(gpu, capi, oracle):
@@ -167,6 +171,25 @@ def test_instanced_scene_materials_and_misses(gpu, capi, oracle):
         acc, ost = osc.render(omats, pfc, W, H, accum=acc, env_faces=env, nthreads=8)
         assert np.array_equal(p.read_output(), acc)
     assert 0 < ost["primary_hits"] < W * H      # both hit and miss pixels were exercised
+    # the same scene as a 4-bounce path trace (BASELINE config 5): mirrors between instances, two-level traversal
+    for m in mats:
+        m["type"] = 2
+        m["reflectivity"] = 0.8
+        m["roughness"] = 0.05
+    for k, m in enumerate(mats):
+        p.set_material(k, m)
+    p.set_depth_limits(4, 3)
+    p.clear_output()
+    pfc = host.update(cam, 0.0, 9, W, H)
+    pfc["cameraParams"]["accumCount"] = 0
+    p.update(pfc)
+    p.render()
+    acc, ost = osc.render(np.stack(mats), pfc, W, H, env_faces=env, max_radiance_depth=4, max_shadow_depth=3, nthreads=8)
+    assert np.array_equal(p.read_output(), acc)
+    gst = p.stats()
+    for key in ("rays_secondary", "rays_shadow", "primary_hits", "secondary_hits"):
+        assert gst[key] == ost[key], key
+    assert ost["secondary_hits"] > ost["primary_hits"]      # chains really go past depth 1
 
 
 def test_max_iterations_early_out_and_formats(gpu, capi, oracle):

@@ -76,6 +76,14 @@ def test_realtime_pipeline_instanced_with_misses(gpu, capi, oracle):
     d, ind, ost = osc.render_realtime(np.stack(mats), pfc, W, H, env_faces=env, nthreads=8)
     assert np.array_equal(p.read_output(0), d) and np.array_equal(p.read_output(1), ind)
     assert 0 < ost["primary_hits"] < W * H
+    # deeper specular chains (the reference compiles depth 1 in; the engine takes up to 4)
+    p.set_depth_limits(3, 3)
+    p.render()
+    d, ind, ost = osc.render_realtime(np.stack(mats), pfc, W, H, env_faces=env, max_radiance_depth=3, max_shadow_depth=3, nthreads=8)
+    assert np.array_equal(p.read_output(0), d) and np.array_equal(p.read_output(1), ind)
+    gst = p.stats()
+    for key in ("rays_secondary", "rays_shadow", "secondary_hits"):
+        assert gst[key] == ost[key], key
 
 
 def synthetic_aovs(W, H, seed):

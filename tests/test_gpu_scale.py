@@ -1,5 +1,5 @@
 """BASELINE configs 4 and 5 at their full sizes (parity-test cases, not bench lines):
-C5  synthetic 10 M-triangle mesh, 3840x2160   -> BVH index-exact, hits bit-exact on a ray sample, a 4K frame renders
+C5  synthetic 10 M-triangle mesh, 3840x2160, 4 bounces -> BVH index-exact, hits bit-exact on a ray sample, a window of the 4K frame bit-exact
 C4  4096 instances of one mesh (TLAS over many BLAS instances), 3840x2160, realtime pipeline + denoiser."""
 import time
 
@@ -30,11 +30,16 @@ def test_c5_ten_million_triangles(gpu, oracle, capi):
     gc = p.g.trace(O[:20000], D[:20000], flags=0, canonical=True)
     ob = p.o.trace(O[:20000], D[:20000], flags=0, mode=1, nthreads=8)
     assert np.array_equal(gc["nodes"], ob["nodes"]) and np.array_equal(gc["tris"], ob["tris"])
-    # one 4K progressive frame
+    # 4K progressive frames as a 4-bounce path trace: glossy surface, specular chains up to radiance depth 4
     W, H = 3840, 2160
     pipe = capi.Pipeline(gpu)
     pipe.set_scene(p.g)
-    pipe.add_material(T.default_material())
+    mat = T.default_material()
+    mat["type"] = 2
+    mat["reflectivity"] = 0.6
+    mat["roughness"] = 0.3
+    pipe.add_material(mat)
+    pipe.set_depth_limits(4, 2)
     pipe.set_environment_cube(scenes.sky_cubemap(32))
     pipe.create_output(W, H)
     pipe.build_acceleration_structures()
@@ -42,12 +47,23 @@ def test_c5_ten_million_triangles(gpu, oracle, capi):
     cam = cam_array(dict(eye=(0.0, 6.0, 19.0), at=(0.0, -4.0, 0.0), up=(0, 1, 0), fov=0.8), W / H)
     pipe.enable_timing(2)
     for f in range(2):
-        pipe.update(host.update(cam, 0.0, f + 1, W, H))
+        pfc = host.update(cam, 0.0, f + 1, W, H)
+        pipe.update(pfc)
         pipe.render()
     img = pipe.read_output()
     st = pipe.stats()
     assert np.isfinite(img).all() and img[..., 3].min() == 1.0
     assert st["rays_primary"] == W * H and st["primary_hits"] > W * H // 4
+    assert st["secondary_hits"] > st["primary_hits"]
+    # a 96x32 window of a single 4K frame against the oracle, bit for bit
+    tile = (1900, 1300, 1996, 1332)
+    pfc["cameraParams"]["accumCount"] = 0
+    pipe.clear_output()
+    pipe.update(pfc)
+    pipe.render()
+    one = pipe.read_output()
+    ref, _ = p.o.render(mat, pfc, W, H, env_faces=scenes.sky_cubemap(32), tile=tile, max_radiance_depth=4, max_shadow_depth=2, nthreads=8)
+    assert np.array_equal(one[tile[1]:tile[3], tile[0]:tile[2]], ref[tile[1]:tile[3], tile[0]:tile[2]])
     rays = st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]
     print("\nC5: generate %.1fs, build both %.1fs (GPU BVH build %.1f ms), 4K frame %.2f ms = %.0f Mrays/s" % (
         t1 - t0, t2 - t1, p.g.build_ms(), st["ms_total"], rays / st["ms_total"] / 1e3))
