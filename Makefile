@@ -10,7 +10,7 @@ LIBDIR = dxrexperiments_amd/lib
 LIBNAME ?= libdxrexperiments_amd.so
 LIB = $(LIBDIR)/$(LIBNAME)
 HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math \
-           -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero \
+           -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize \
            -Wall -Wno-unused-function -Iinclude $(EXTRA)
 SRCS = $(CSRC)/rt_api.hip $(CSRC)/rt_bvh_build.hip $(CSRC)/rt_bvh_ploc.hip $(CSRC)/rt_trace.hip $(CSRC)/rt_pipeline.hip $(CSRC)/rt_denoise.hip \
        $(CSRC)/rt_obj.cpp $(CSRC)/rt_host.cpp $(CSRC)/rt_dds.cpp

@@ -124,6 +124,8 @@ static int context_create(int device, void *stream, bool own, rt_context **out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         c->cu_count = (uint32_t)prop.multiProcessorCount;
+    const char *sr = getenv("RT_LDS_STACK_ROWS");
+    if (sr) c->lds_stack_rows = (uint32_t)atoi(sr);
     const char *pb = getenv("RT_PERSISTENT_BLOCKS_PER_CU");
     if (pb && atoi(pb) >= 1 && atoi(pb) <= 16) c->blocks_per_cu_override = (uint32_t)atoi(pb);
     const char *fb = getenv("RT_FAST_BVH");
@@ -164,6 +166,7 @@ void rt_context_release(rt_context *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf &b : ctx->scratch) b.release();
     ctx->pool.release();
+    ctx->deep_stack.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -298,6 +298,8 @@ int lbvh_from_boxes(rt_context *ctx, BvhDev &bv, const Box6 *boxes, uint32_t n, 
 {
     hipStream_t st = ctx->stream;
     const unsigned B = 256;
+    // the traversal addresses a 64-B slab as base + (index << 6) with a 32-bit byte offset (rt_trace_wave.h)
+    if (n > (1u << 26)) { rt_set_error("acceleration structure over %u primitives: the limit is 2^26 (67,108,864)", n); return RT_ERR_UNSUPPORTED; }
     bv.n = n;
     RT_TRY(bv.nodes.reserve(sizeof(rt_bvh_node) * (2 * (size_t)n - 1)));
     RT_TRY(bv.keys.reserve(sizeof(uint64_t) * n));
@@ -467,6 +469,11 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
         // TLAS path and the sentinel that marks the bottom of a BLAS walk
         s->two_level = !(n == 1 && (s->h_inst[0].flags & RT_INST_IDENTITY));
         s->stack_need = s->two_level ? s->tlas.fast_depth + 1 + deepest : deepest;
+        // the canonical traversal (parity / counting kernels and the deep-stack path of the fast one) keeps
+        // 128-entry private stacks per structure
+        uint32_t canon = s->tlas.max_depth;
+        for (uint32_t i = 0; i < n; i++) canon = s->inst[i].model->blas.max_depth > canon ? s->inst[i].model->blas.max_depth : canon;
+        if (canon >= 127) { rt_set_error("acceleration structure %u levels deep: the limit is 126", canon); rc = RT_ERR_UNSUPPORTED; break; }
         if (getenv("RT_VERBOSE"))
             fprintf(stderr, "[dxr_amd] TLAS %u instances depth %u; deepest BLAS layout depth %u (%s); stack need %u; %s walk\n", n,
                     s->tlas.max_depth, deepest, ctx->use_ploc ? "PLOC" : "LBVH", s->stack_need, s->two_level ? "two-level" : "single-level");

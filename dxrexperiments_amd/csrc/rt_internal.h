@@ -101,6 +101,7 @@ struct SceneDev {
     const rt_bvh_node *tlas_cnodes;
     uint32_t n_inst;
     int tlas_root_code;
+    int *deep_stack;             // global stack rows beyond the LDS rows (rt_trace_wave.h); nullptr: never needed
 };
 
 // ---- host objects --------------------------------------------------------------
@@ -116,7 +117,9 @@ struct rt_context {
     bool use_ploc = true;        // RT_FAST_BVH=lbvh keeps the canonical LBVH as the traversal layout
     uint32_t cu_count = 256;     // compute units of the device
     uint32_t blocks_per_cu_override = 0;    // RT_PERSISTENT_BLOCKS_PER_CU: 0 = ask the occupancy API per kernel
+    uint32_t lds_stack_rows = 0;            // RT_LDS_STACK_ROWS=6: the small-stack instantiation (tests of the deep-stack path)
     DevBuf pool;                 // ray-pool counters of rt_trace_batch
+    DevBuf deep_stack;           // global stack rows of the traversal kernels (rt_scene_dev_for_launch)
     DevBuf scratch[8];           // staging for host-pointer batch calls
 };
 
@@ -170,6 +173,7 @@ struct rt_scene {
         s.tlas_cnodes = tlas.nodes.as<rt_bvh_node>();
         s.n_inst = (uint32_t)inst.size();
         s.tlas_root_code = tlas.root_code;
+        s.deep_stack = nullptr;
         return s;
     }
 };
@@ -203,6 +207,27 @@ static inline unsigned rt_persistent_grid(const rt_context *ctx, K kernel, int b
     const size_t want = (rays + (size_t)block - 1) / (size_t)block;
     const size_t cap = (size_t)ctx->cu_count * (size_t)per_cu;
     return (unsigned)(want < cap ? (want ? want : 1) : cap);
+}
+
+#ifndef RT_LDS_STACK_ROWS
+#define RT_LDS_STACK_ROWS 24            // LDS stack rows of the production kernels: 24 KiB per 256-thread block, 6 blocks per CU
+#endif
+#define RT_LDS_STACK_ROWS_TEST 6        // second instantiation (env RT_LDS_STACK_ROWS=6): tests force rays onto the global rows
+
+// The scene as the traversal kernels see it, with the global stack rows a launch of `threads` threads whose
+// kernels keep `lds_rows` rows in LDS may need: the tree bounds a walk to stack_need (+1 speculative) entries.
+static inline int rt_scene_dev_for_launch(rt_context *ctx, const rt_scene *s, uint32_t lds_rows, size_t threads, SceneDev *out)
+{
+    *out = s->dev();
+    const uint32_t bound = s->stack_need + 2;
+    if (bound <= lds_rows) return RT_OK;
+    RT_TRY(ctx->deep_stack.reserve((size_t)(bound - lds_rows) * threads * sizeof(int)));
+    out->deep_stack = ctx->deep_stack.as<int>();
+    return RT_OK;
+}
+static inline uint32_t rt_lds_stack_rows(const rt_context *ctx)
+{
+    return ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST ? RT_LDS_STACK_ROWS_TEST : RT_LDS_STACK_ROWS;
 }
 
 // rt_api.hip

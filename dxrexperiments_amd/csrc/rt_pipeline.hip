@@ -1057,7 +1057,8 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
         HIP_TRY(hipMemsetAsync(p->totals.p, 0, 8 * sizeof(unsigned long long), st));
     }
     PipeDev pd;
-    pd.sc = p->scene->dev();
+    // (threads of the largest launch: the primary stage runs one thread per pixel slot, the persistent stages fewer)
+    RT_TRY(rt_scene_dev_for_launch(ctx, p->scene, rt_lds_stack_rows(ctx), cap > ctx->cu_count * 16u * PBLOCK ? cap : ctx->cu_count * 16u * PBLOCK, &pd.sc));
     pd.pfc = p->pfc;
     pd.mats = p->d_mats.as<rt_material_params>();
     pd.nmats = (uint32_t)p->mats.size();
@@ -1081,15 +1082,10 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
         d.shO = b.shO.as<float4>(); d.shD = b.shD.as<float4>(); d.vis = b.vis.as<uint32_t>();
     }
     HIP_TRY(hipMemsetAsync(pd.counters, 0, C_COUNT * 4, st));
-    const uint32_t need = p->scene->stack_need;
-    // LDS stack rows -> resident 256-thread blocks per CU: 24 -> 6, 31 -> 5, 39 -> 4, 52 -> 3, 78 -> 2, 160 -> 1
-    if (need < 24) launch_frame_any<24>(p, pd, shadow_slots);
-    else if (need < 31) launch_frame_any<31>(p, pd, shadow_slots);
-    else if (need < 39) launch_frame_any<39>(p, pd, shadow_slots);
-    else if (need < 52) launch_frame_any<52>(p, pd, shadow_slots);
-    else if (need < 78) launch_frame_any<78>(p, pd, shadow_slots);
-    else if (need < 160) launch_frame_any<160>(p, pd, shadow_slots);
-    else { rt_set_error("traversal stack need %u exceeds 159 entries", need); return RT_ERR_UNSUPPORTED; }
+    // 24 LDS stack rows = 24 KiB per 256-thread block = 6 resident blocks per CU, whatever the depth of the
+    // tree; the rare deeper walk continues in global rows (rt_trace_wave.h)
+    if (ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST) launch_frame_any<RT_LDS_STACK_ROWS_TEST>(p, pd, shadow_slots);
+    else launch_frame_any<RT_LDS_STACK_ROWS>(p, pd, shadow_slots);
     HIP_TRY(hipGetLastError());
     p->last_pd = pd;
     p->last_shadow_slots = shadow_slots;
@@ -1301,6 +1297,21 @@ int rt_pipeline_read_primary_hits(rt_pipeline *p, float *t, uint32_t *prim, uint
     }
     return RT_OK;
 }
+
+#ifdef RT_TRACE_STATS
+// instrumentation build only: wave / lane counters of the pipeline's traversal kernels since the last call
+int rt_debug_trace_stats(unsigned long long out[8 + 64])
+{
+    unsigned long long zero[64];
+    memset(zero, 0, sizeof zero);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rtd::g_trace_stats), 8 * sizeof zero[0]));
+    HIP_TRY(hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(rtd::g_trace_sp_hist), sizeof zero));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rtd::g_trace_stats), zero, 8 * sizeof zero[0]));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rtd::g_trace_sp_hist), zero, sizeof zero));
+    return RT_OK;
+}
+#endif
 
 int rt_debug_sample_cube(rt_context *ctx, const float *faces, uint32_t size, const float *dirs, float *out, size_t n)
 {

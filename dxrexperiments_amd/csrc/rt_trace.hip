@@ -74,7 +74,7 @@ int rt_launch_trace(rt_context *ctx, const rt_scene *s, const float4 *o, const f
                     uint32_t kernel, const TraceOut &out)
 {
     if (n == 0) return RT_OK;
-    const SceneDev sc = s->dev();
+    SceneDev sc = s->dev();
     hipStream_t st = ctx->stream;
     if (kernel == RT_TRACE_CANONICAL) {
         const unsigned grid = (unsigned)((n + TRACE_BLOCK - 1) / TRACE_BLOCK);
@@ -86,19 +86,12 @@ int rt_launch_trace(rt_context *ctx, const rt_scene *s, const float4 *o, const f
         HIP_TRY(hipMemsetAsync(ctx->pool.p, 0, 64, st));
         BatchSrc src = {o, d, (uint32_t)n, ray_flags};
         BatchSink sink = {out};
-        const uint32_t need = s->stack_need;
         HIP_TRY(hipEventRecord(ctx->ev0, st));
         uint32_t *pool = ctx->pool.as<uint32_t>();
-        if (need < 24) launch_fast<24>(ctx, s->two_level, st, sc, src, sink, pool);
-        else if (need < 31) launch_fast<31>(ctx, s->two_level, st, sc, src, sink, pool);
-        else if (need < 39) launch_fast<39>(ctx, s->two_level, st, sc, src, sink, pool);
-        else if (need < 52) launch_fast<52>(ctx, s->two_level, st, sc, src, sink, pool);
-        else if (need < 78) launch_fast<78>(ctx, s->two_level, st, sc, src, sink, pool);
-        else if (need < 160) launch_fast<160>(ctx, s->two_level, st, sc, src, sink, pool);
-        else {
-            rt_set_error("traversal stack need %u exceeds 159 entries", need);
-            return RT_ERR_UNSUPPORTED;
-        }
+        // a fixed number of LDS stack rows whatever the depth of the tree: deeper walks continue in global rows
+        RT_TRY(rt_scene_dev_for_launch(ctx, s, rt_lds_stack_rows(ctx), (size_t)ctx->cu_count * 16 * TRACE_BLOCK, &sc));
+        if (ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST) launch_fast<RT_LDS_STACK_ROWS_TEST>(ctx, s->two_level, st, sc, src, sink, pool);
+        else launch_fast<RT_LDS_STACK_ROWS>(ctx, s->two_level, st, sc, src, sink, pool);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev1, st));

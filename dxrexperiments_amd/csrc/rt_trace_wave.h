@@ -50,6 +50,68 @@ RT_DEV v4f ldg16(const void *base, size_t byte_off)
 #define RT_POOL_CHUNK 128u              // rays per chunk of the queue a wave takes at a time
 #endif
 
+#ifndef RT_EXIT_K
+#define RT_EXIT_K 2                     // leave the node loop once (lanes still on internal nodes) * K < lanes waiting on a leaf
+#endif
+
+// (Packed fp32 -- v_pk_add_f32 / v_pk_mul_f32 on the (lo, hi) plane pairs -- was measured and is no faster
+// on gfx950: a packed op issues in twice the time of a scalar one, tools/microbench/valu_rate.hip.)
+
+#ifdef RT_TRACE_STATS      /* instrumentation build only (tools/trace_stats.py): SIMD-utilisation counters */
+__device__ unsigned long long g_trace_stats[8];
+__device__ unsigned long long g_trace_sp_hist[64];      // rays by the deepest stack pointer they reached
+#define RT_STAT_WAVE(k) do { if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_read_exec())) st_w[k]++; } while (0)
+#define RT_STAT_LANE(k) (st_l[k]++)
+#else
+#define RT_STAT_WAVE(k) ((void)0)
+#define RT_STAT_LANE(k) ((void)0)
+#endif
+
+// The traversal stack: STACK rows per lane in LDS (stk[row * BLOCK], one dword per lane per row, bank =
+// lane mod 32: conflict free), rows beyond that in global memory (deep[(row - STACK) * threads + thread]).
+// The LDS rows are sized for occupancy, not for the deepest possible walk: Sponza-class rays never hold
+// more than 15 entries although the tree is 29 levels deep (tools/trace_stats.py), so the global rows are
+// correctness insurance that is rarely or never touched; the hot loop runs only while sp < STACK and
+// is pure LDS, a second copy of the step (DEEP) serves the lanes above that.
+template <int STACK, int BLOCK>
+struct LaneStack {
+    int *lds;            // smem + threadIdx.x
+    int *deep;           // global rows of this thread (nullptr when the tree cannot need them)
+    uint32_t threads;    // threads of the launch: stride between global rows
+    RT_DEV int read(int row) const { return row < STACK ? lds[row * BLOCK] : deep[(size_t)(row - STACK) * threads]; }
+    RT_DEV void write(int row, int v) const
+    {
+        if (row < STACK) lds[row * BLOCK] = v;
+        else deep[(size_t)(row - STACK) * threads] = v;
+    }
+};
+
+// One step on an internal node: both children are slab-tested, the nearer hit child is entered, the farther
+// one is written to the stack slot above the top unconditionally (it only counts if the top moves), the
+// slot below the top is read speculatively (it only counts if both children miss).  Branch free.
+template <bool DEEP, int STACK, int BLOCK>
+RT_DEV void node_step(const Slab *slabs, const RayInv &ri, float tmin, float tbest, const LaneStack<STACK, BLOCK> &st, int &node, int &sp)
+{
+    // 32-bit byte offset from the (wave-uniform, single-level) slab base: SGPR base + VGPR offset addressing
+    const char *sl = (const char *)slabs + ((uint32_t)node << 6);
+    const v4f q0 = ldg16(sl, 0), q1 = ldg16(sl, 16), q2 = ldg16(sl, 32), q3 = ldg16(sl, 48);
+    float e0, e1;
+    const bool h0 = slab_hit(ri, q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, tmin, tbest, e0);
+    const bool h1 = slab_hit(ri, q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, tmin, tbest, e1);
+    const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+    const bool both = h0 && h1, none = !(h0 || h1);
+    const bool swap = e1 < e0;
+    const int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+    const int one = h0 ? c0 : c1;
+    const int below = sp > 0 ? sp - 1 : 0;
+    const int top = DEEP ? st.read(below) : st.lds[below * BLOCK];     // speculative pop (unconditional read)
+    const int popped = sp > 0 ? top : RT_NODE_EMPTY;
+    if (DEEP) st.write(sp, farc);                                      // speculative push
+    else st.lds[sp * BLOCK] = farc;
+    node = both ? nearc : (none ? popped : one);
+    sp = both ? sp + 1 : ((none && sp > 0) ? sp - 1 : sp);
+}
+
 RT_DEV bool node_is_internal(int node) { return node >= 0 && node < RT_NODE_EMPTY; }
 
 RT_DEV unsigned long long lanemask_lt()
@@ -67,11 +129,18 @@ template <int STACK, int BLOCK, bool TWO_LEVEL, uint32_t CHUNK, class Src, class
 RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uint32_t *pool, int *smem, uint32_t *traced_counter)
 {
     uint32_t n_traced = 0;           // rays this lane actually traversed (statistics)
+#ifdef RT_TRACE_STATS
+    unsigned long long st_w[4] = {0, 0, 0, 0}, st_l[4] = {0, 0, 0, 0};   // node steps, leaf phases, triangle iterations, outer iterations
+    int st_maxsp = 0;
+#endif
     const uint32_t total = src.count();
     const uint32_t flags = src.flags();
     const bool first = (flags & RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH) != 0;
     const bool cull = (flags & RT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES) != 0;
-    int *stk = smem + threadIdx.x;                 // stk[level * BLOCK]
+    LaneStack<STACK, BLOCK> st;
+    st.lds = smem + threadIdx.x;
+    st.threads = gridDim.x * BLOCK;
+    st.deep = sc.deep_stack ? sc.deep_stack + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
 
     // single-level scenes (one identity instance) walk the BLAS directly in world space
     const InstanceRec *in0 = sc.inst;
@@ -151,35 +220,34 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 
 
         // ---- walk internal nodes until this lane stands on a leaf (or runs dry) ----------
-        while (alive && node_is_internal(node)) {
-            const char *sl = (const char *)(slabs + node);
-            const v4f q0 = ldg16(sl, 0), q1 = ldg16(sl, 16), q2 = ldg16(sl, 32), q3 = ldg16(sl, 48);
-#ifdef RT_EXPERIMENT_EXTRA_LOADS      /* timing experiment: re-load the same half line, fold into a dummy */
-            {
-                const char *sx = (const char *)((uintptr_t)sl ^ 64u);      // the other half of the same 128-B line
-                const v4f x0 = ldg16(sx, 0), x1 = ldg16(sx, 16), x2 = ldg16(sx, 32), x3 = ldg16(sx, 48);
-                asm volatile("" :: "v"(x0.x), "v"(x1.y), "v"(x2.z), "v"(x3.w));
-            }
+#if RT_EXIT_K > 0
+        const int n_alive = __popcll(__ballot(alive));
 #endif
-            float e0, e1;
-            const bool h0 = slab_hit(cur.ri, q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, r.tmin, best.t, e0);
-            const bool h1 = slab_hit(cur.ri, q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, r.tmin, best.t, e1);
-            const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-            const bool both = h0 && h1, none = !(h0 || h1);
-            const bool swap = e1 < e0;
-            const int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-            const int one = h0 ? c0 : c1;
-            const int below = sp > 0 ? sp - 1 : 0;
-            const int popped = sp > 0 ? stk[below * BLOCK] : RT_NODE_EMPTY;   // speculative pop
-            stk[sp * BLOCK] = farc;                                           // speculative push
-            node = both ? nearc : (none ? popped : one);
-            sp = both ? sp + 1 : ((none && sp > 0) ? sp - 1 : sp);
+        while (alive && node_is_internal(node) && sp < STACK) {
+            RT_STAT_WAVE(0); RT_STAT_LANE(0);
+            node_step<false>(slabs, cur.ri, r.tmin, best.t, st, node, sp);
+#ifdef RT_TRACE_STATS
+            st_maxsp = sp > st_maxsp ? sp : st_maxsp;
+#endif
+#if RT_EXIT_K > 0
+            // stragglers: most of the wave already waits on a leaf -> run the leaf phase now, come back after
+            const int walking = __popcll(__ballot(alive && node_is_internal(node)));
+            if (walking * RT_EXIT_K < n_alive - walking) break;
+#endif
         }
+        // lanes whose stack has outgrown the LDS rows walk on with the global rows until it fits again
+        while (alive && node_is_internal(node) && sp >= STACK) node_step<true>(slabs, cur.ri, r.tmin, best.t, st, node, sp);
 
         // ---- leaves, instance entry / exit, termination -----------------------------------
-        if (alive) {
+        RT_STAT_WAVE(3);
+        if (alive && !node_is_internal(node)) {
+            RT_STAT_WAVE(1); RT_STAT_LANE(1);
             bool pop = true;
             if (node == RT_NODE_EMPTY) {
+#ifdef RT_TRACE_STATS
+                atomicAdd(&g_trace_sp_hist[st_maxsp < 63 ? st_maxsp : 63], 1ull);
+                st_maxsp = 0;
+#endif
                 sink.store(idx, best, true);
                 alive = false;
                 pop = false;
@@ -200,7 +268,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     slabs = in->slabs;
                     tris = in->tris;
                     in_blas = true;
-                    stk[sp * BLOCK] = RT_NODE_SENTINEL;
+                    st.write(sp, RT_NODE_SENTINEL);
                     sp++;
                     node = in->root_code;
                     pop = false;
@@ -209,6 +277,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 const uint32_t code = (uint32_t)~node;
                 const uint32_t first_tri = code >> 3, cnt = (code & 7u) + 1u;
                 for (uint32_t k = 0; k < cnt; k++) {
+                    RT_STAT_WAVE(2); RT_STAT_LANE(2);
                     const char *tp = (const char *)(tris + first_tri + k);
                     const v4f a = ldg16(tp, 0), b = ldg16(tp, 16), c = ldg16(tp, 32);
                     const uint32_t prim = __float_as_uint(c.y);
@@ -222,11 +291,17 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 }
             }
             if (pop) {
-                if (sp > 0) { sp--; node = stk[sp * BLOCK]; }
+                if (sp > 0) { sp--; node = st.read(sp); }
                 else node = RT_NODE_EMPTY;
             }
         }
     }
+#ifdef RT_TRACE_STATS
+    for (int k = 0; k < 4; k++) {
+        if (st_w[k]) atomicAdd(&g_trace_stats[2 * k], st_w[k]);
+        if (st_l[k]) atomicAdd(&g_trace_stats[2 * k + 1], st_l[k]);
+    }
+#endif
     if (traced_counter) {            // one no-return atomic per persistent wave
         for (int o = 32; o > 0; o >>= 1) n_traced += (uint32_t)__shfl_xor((int)n_traced, o, 64);
         if ((threadIdx.x & 63u) == 0u && n_traced) atomicAdd(traced_counter, n_traced);

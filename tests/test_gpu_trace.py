@@ -87,3 +87,19 @@ def test_sponza_class_rays(gpu, oracle, capi):
     O, D = random_rays(3000, 11, [-16, -4, -7], [16, 7, 7])
     compare_all(p, O, D, brute=True)
     assert p.g.trace_last_ms() >= 0
+
+
+def test_small_lds_stack_spills_to_global_rows():
+    """The production kernels keep 24 stack rows per lane in LDS and continue in global memory beyond them
+    (rt_trace_wave.h); real scenes rarely get there, so the 6-row instantiation (RT_LDS_STACK_ROWS=6) re-runs
+    the deep-tree parity tests with most rays spilling."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, RT_LDS_STACK_ROWS="6")
+    sel = ["test_gpu_trace.py::test_soup_with_tmin_tmax_windows", "test_gpu_trace.py::test_instanced_two_level",
+           "test_gpu_pipeline.py::test_instanced_scene_materials_and_misses", "test_gpu_pipeline.py::test_material_types_and_depth_limits"]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + [os.path.join(here, s) for s in sel],
+                       env=env, cwd=os.path.dirname(here), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]

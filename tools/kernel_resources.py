@@ -6,8 +6,8 @@ import subprocess
 import sys
 
 src = sys.argv[1]
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
-       "-Iinclude", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
+       "-Iinclude", *sys.argv[2:], "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
 out = subprocess.run(cmd, stderr=subprocess.PIPE, text=True).stderr
 cur = None
 rows = {}

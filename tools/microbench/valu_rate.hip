@@ -1,0 +1,122 @@
+// Microbenchmark: issue cost of the VALU instructions the traversal step is made of, on gfx950.
+//   hipcc -O3 --offload-arch=gfx950 -w tools/microbench/valu_rate.hip -o tools/microbench/valu_rate
+// 2048 blocks x 256 threads (8 waves per SIMD), every wave runs `iters` iterations of 8 independent
+// copies of one instruction; reported: ns per wave64 instruction per SIMD.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#define R8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+#define REGS "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k(float *out, int iters, float s)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    v2f p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
+    const v2f s2 = {s, s};
+    const unsigned long long m = __builtin_amdgcn_read_exec() >> 1;      // wave-uniform lane mask in an SGPR pair
+    for (int i = 0; i < iters; i++) {
+        if (MODE == 0) {
+#define OP(n) "v_mul_f32 %" #n ", %" #n ", %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 1) {
+            asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(s2));
+        } else if (MODE == 2) {
+#define OP(n) "v_min_f32 %" #n ", %" #n ", %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 3) {
+#define OP(n) "v_min3_f32 %" #n ", %" #n ", %8, %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 4) {
+#define OP(n) "v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
+            asm volatile(R8(OP) : REGS : "v"(s) : "vcc");
+#undef OP
+        } else if (MODE == 5) {
+#define OP(n) "v_cndmask_b32_e64 %" #n ", %" #n ", %8, %9\n"
+            asm volatile(R8(OP) : REGS : "v"(s), "s"(m));
+#undef OP
+        } else if (MODE == 6) {
+#define OP(n) "v_sub_f32 %" #n ", %" #n ", %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 7) {
+#define OP(n) "v_fma_f32 %" #n ", %" #n ", %8, %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 8) {
+#define OP(n) "v_add_u32 %" #n ", %" #n ", %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 9) {
+#define OP(n) "v_cmp_lt_f32 vcc, %" #n ", %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s) : "vcc");
+#undef OP
+        } else if (MODE == 10) {
+#define OP(n) "v_cmp_lt_f32_e64 s[20:21], %" #n ", %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s) : "s20", "s21");
+#undef OP
+        } else if (MODE == 11) {
+#define OP(n) "v_max_f32 %" #n ", %" #n ", %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 12) {
+#define OP(n) "v_lshl_or_b32 %" #n ", %" #n ", 10, %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 13) {
+#define OP(n) "v_mov_b32 %" #n ", %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 14) {
+#define OP(n) "v_med3_f32 %" #n ", %" #n ", %8, %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 16) {      // the compiler's own select: (a < s) ? a : s  (v_cmp + v_cndmask)
+            a0 = a0 < s ? a0 + 1.0f : s; a1 = a1 < s ? a1 + 1.0f : s; a2 = a2 < s ? a2 + 1.0f : s; a3 = a3 < s ? a3 + 1.0f : s;
+            a4 = a4 < s ? a4 + 1.0f : s; a5 = a5 < s ? a5 + 1.0f : s; a6 = a6 < s ? a6 + 1.0f : s; a7 = a7 < s ? a7 + 1.0f : s;
+            asm volatile("" : REGS);
+        } else if (MODE == 15) {
+#define OP(n) "v_mul_f32 %" #n ", 0x3f800080, %" #n "\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+}
+
+template <int MODE>
+float run(float *d, int blocks, int iters)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    k<MODE><<<blocks, 256>>>(d, iters, 1.0000001f);
+    hipEventRecord(e0);
+    k<MODE><<<blocks, 256>>>(d, iters, 1.0000001f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}
+
+int main()
+{
+    const int blocks = 256 * 8, iters = 100000;
+    float *d; hipMalloc(&d, blocks * 256 * 4);
+    const char *names[] = {"v_mul_f32", "v_pk_mul_f32", "v_min_f32", "v_min3_f32", "v_cndmask_b32 vcc", "v_cndmask_b32 sgpr", "v_sub_f32", "v_fma_f32",
+                           "v_add_u32", "v_cmp_lt_f32 vcc", "v_cmp_lt_f32 sgpr", "v_max_f32", "v_lshl_or_b32", "v_mov_b32", "v_med3_f32", "v_mul_f32 literal", "cmp+add+cndmask (x3)"};
+    float ms[17] = {run<0>(d, blocks, iters), run<1>(d, blocks, iters), run<2>(d, blocks, iters), run<3>(d, blocks, iters), run<4>(d, blocks, iters),
+                    run<5>(d, blocks, iters), run<6>(d, blocks, iters), run<7>(d, blocks, iters), run<8>(d, blocks, iters), run<9>(d, blocks, iters),
+                    run<10>(d, blocks, iters), run<11>(d, blocks, iters), run<12>(d, blocks, iters), run<13>(d, blocks, iters), run<14>(d, blocks, iters),
+                    run<15>(d, blocks, iters), run<16>(d, blocks, iters)};
+    for (int m = 0; m < 17; m++) {
+        const int per = m == 1 ? 4 : 8;
+        const double wave_insts = (double)blocks * 4 * iters * per;
+        printf("%-20s %8.3f ms  %.3f ns per wave64 instruction per SIMD\n", names[m], ms[m], ms[m] * 1e6 / (wave_insts / 1024.0));
+    }
+    return 0;
+}
