@@ -87,6 +87,21 @@ def cpu_baseline(verts, tris, mat, env, pfc, W, H, budget_s):
                       % (bands, band, rays, dt, build_s)}
 
 
+def measured_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE need separate passes, so they cannot be taken inside this run): profiles/<round>/traffic.json,
+    written by tools/traffic_from_pmc.py with the gfx950 FETCH_SIZE correction applied.  None if absent."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    for rnd in sorted(os.listdir(os.path.join(here, "profiles")), reverse=True) if os.path.isdir(os.path.join(here, "profiles")) else []:
+        path = os.path.join(here, "profiles", rnd, "traffic.json")
+        if os.path.isfile(path):
+            with open(path) as f:
+                k = json.load(f).get("kernels", {}).get(kernel)
+            if k:
+                return k["bytes_per_launch"]
+    return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -207,7 +222,7 @@ def main():
             dom = max(TRACE_STAGES, key=lambda s: stages[s]["avg_ms"])
             out["roofline"] = {"bound": "hbm", "kernel": stages[dom]["kernel"], "stage": dom,
                                "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": stages[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                               "frac": stages[dom]["GBps"] / HBM_PEAK_GBS, "traffic": measured_traffic(stages[dom]["kernel"]),
                                "algorithmic_bytes_per_launch": stages[dom]["algorithmic_bytes"],
                                "avg_launch_ms": stages[dom]["avg_ms"], "launches_timed": n_t}
             tb = sum(stages[s]["algorithmic_bytes"] for s in TRACE_STAGES)
