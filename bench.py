@@ -107,6 +107,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (tests/test_gpu_scale.py runs two ranks on the one GPU of a test box): every rank on one
+    # device, and gloo instead of RCCL, which refuses two ranks per device
+    if "DXR_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["DXR_BENCH_DEVICE"])
+    backend = os.environ.get("DXR_BENCH_BACKEND", "nccl")
     if args.gpus > 1 and world == 1:
         sys.exit(relaunch_distributed(args))
     if world != args.gpus:
@@ -122,7 +127,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm: xGMI between the GPUs of the node
+        else:
+            dist.init_process_group(backend)
 
     W, H, K, Wu = args.width, args.height, args.steps, args.warmup
     verts, tris = scenes.sponza_class(seed=42)

@@ -99,6 +99,9 @@ SIGNATURES = {
     "rt_pipeline_get_output_device_ptr": (_i, [_p, _u32, _pp]),
     "rt_pipeline_read_output": (_i, [_p, _p, _sz]),
     "rt_pipeline_read_output_n": (_i, [_p, _u32, _p, _sz]),
+    "rt_pipeline_write_output": (_i, [_p, _p, _sz]),
+    "rt_pipeline_save_checkpoint": (_i, [_p, _p, C.c_char_p]),
+    "rt_pipeline_load_checkpoint": (_i, [_p, _p, C.c_char_p]),
     "rt_realtime_host_update": (_i, [_p, _p, _f, _u32, _u32, _u32, _p]),
     "rt_denoiser_create": (_i, [_p, _pp]),
     "rt_denoiser_destroy": (_i, [_p]),
@@ -122,6 +125,8 @@ SIGNATURES = {
     "rt_progressive_host_options": (_i, [_p, _pp]),
     "rt_progressive_host_set_flags": (_i, [_p, _i, _i]),
     "rt_progressive_host_reset": (_i, [_p]),
+    "rt_progressive_host_save_state": (_i, [_p, _p, _sz, C.POINTER(_sz)]),
+    "rt_progressive_host_load_state": (_i, [_p, _p, _sz]),
     "rt_progressive_host_update": (_i, [_p, _p, _f, _u32, _u32, _u32, _p]),
     "rt_debug_math": (_i, [_p, _i, _p, _p, _p, _sz]),
     "rt_debug_sample": (_i, [_p, _i, _p, _p, _f, _p, _p, _p, _sz]),
@@ -443,6 +448,17 @@ class Pipeline:
         _check(lib().rt_pipeline_get_output_device_ptr(self.h, output, C.byref(p)))
         return p.value
 
+    def write_output(self, image):
+        """Inverse of read_output() for the fp32 accumulation image."""
+        img = np.ascontiguousarray(image, np.float32)
+        _check(lib().rt_pipeline_write_output(self.h, _ptr(img), img.nbytes))
+
+    def save_checkpoint(self, path, host=None):
+        _check(lib().rt_pipeline_save_checkpoint(self.h, host.h if host is not None else None, os.fsencode(path)))
+
+    def load_checkpoint(self, path, host=None):
+        _check(lib().rt_pipeline_load_checkpoint(self.h, host.h if host is not None else None, os.fsencode(path)))
+
     def read_output(self, output=0):
         if self.format == T.FORMAT_R16G16B16A16_FLOAT:
             out = np.empty((self.height, self.width, 4), np.float16)
@@ -527,6 +543,17 @@ class ProgressiveHost:
 
     def reset(self):
         _check(lib().rt_progressive_host_reset(self.h))
+
+    def save_state(self):
+        n = C.c_size_t()
+        _check(lib().rt_progressive_host_save_state(self.h, None, 0, C.byref(n)))
+        buf = (C.c_uint8 * n.value)()
+        _check(lib().rt_progressive_host_save_state(self.h, buf, n.value, C.byref(n)))
+        return bytes(buf)
+
+    def load_state(self, blob):
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        _check(lib().rt_progressive_host_load_state(self.h, buf, len(blob)))
 
     def update(self, camera11, elapsed_time, elapsed_frames, width, height):
         cam = _f32(camera11, 11)

@@ -14,6 +14,8 @@
 
 #include <new>
 #include <random>
+#include <sstream>
+#include <string>
 
 #include "rt_internal.h"
 
@@ -120,6 +122,61 @@ int rt_progressive_host_reset(rt_progressive_host *h)
 {
     RT_REQUIRE(h, "null argument");
     h->have_last = false;          // next update sees a "moved" camera, like mLastCameraVPMatrix = Matrix4() (:309-311)
+    return RT_OK;
+}
+
+// state = fixed header + the mt19937 engine in its standard text form (operator<<)
+namespace {
+struct HostStateHeader {
+    uint32_t magic, accum_count, have_last, accumulation_enabled, animation_paused, rng_bytes;
+    float last_camera[11];
+    rt_debug_options options;
+};
+const uint32_t kHostStateMagic = 0x31534844u;      // "DHS1"
+}  // namespace
+
+int rt_progressive_host_save_state(const rt_progressive_host *h, void *buf, size_t capacity, size_t *bytes)
+{
+    RT_REQUIRE(h && bytes, "null argument");
+    std::ostringstream os;
+    os << h->rng;
+    const std::string rng = os.str();
+    HostStateHeader hd;
+    memset(&hd, 0, sizeof hd);
+    hd.magic = kHostStateMagic;
+    hd.accum_count = h->accum_count;
+    hd.have_last = h->have_last ? 1u : 0u;
+    hd.accumulation_enabled = h->accumulation_enabled ? 1u : 0u;
+    hd.animation_paused = h->animation_paused ? 1u : 0u;
+    hd.rng_bytes = (uint32_t)rng.size();
+    memcpy(hd.last_camera, h->last_camera, sizeof hd.last_camera);
+    hd.options = h->options;
+    *bytes = sizeof hd + rng.size();
+    if (!buf) return RT_OK;
+    RT_REQUIRE(capacity >= *bytes, "state buffer too small");
+    memcpy(buf, &hd, sizeof hd);
+    memcpy((char *)buf + sizeof hd, rng.data(), rng.size());
+    return RT_OK;
+}
+
+int rt_progressive_host_load_state(rt_progressive_host *h, const void *buf, size_t bytes)
+{
+    RT_REQUIRE(h && buf, "null argument");
+    HostStateHeader hd;
+    RT_REQUIRE(bytes >= sizeof hd, "host state truncated");
+    memcpy(&hd, buf, sizeof hd);
+    RT_REQUIRE(hd.magic == kHostStateMagic && bytes == sizeof hd + (size_t)hd.rng_bytes, "not a host state record");
+    std::istringstream is(std::string((const char *)buf + sizeof hd, hd.rng_bytes));
+    std::mt19937 rng;
+    is >> rng;
+    RT_REQUIRE(!is.fail(), "host state: bad RNG record");
+    h->rng = rng;
+    h->accum_count = hd.accum_count;
+    h->have_last = hd.have_last != 0;
+    h->accumulation_enabled = hd.accumulation_enabled != 0;
+    h->animation_paused = hd.animation_paused != 0;
+    memcpy(h->last_camera, hd.last_camera, sizeof h->last_camera);
+    h->options = hd.options;
     return RT_OK;
 }
 

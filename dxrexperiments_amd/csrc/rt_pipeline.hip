@@ -1138,6 +1138,79 @@ int rt_pipeline_read_output_n(rt_pipeline *p, uint32_t id, void *host, size_t by
 
 int rt_pipeline_read_output(rt_pipeline *p, void *host, size_t bytes) { return rt_pipeline_read_output_n(p, 0, host, bytes); }
 
+int rt_pipeline_write_output(rt_pipeline *p, const void *host_rgba32f, size_t bytes)
+{
+    RT_REQUIRE(p && host_rgba32f, "null argument");
+    if (!p->accum) { rt_set_error("no output resource"); return RT_ERR_STATE; }
+    RT_REQUIRE(bytes == (size_t)p->width * p->height * 16, "host buffer must be width*height*16 bytes (RGBA32F)");
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    HIP_TRY(hipMemcpyAsync(p->accum, host_rgba32f, bytes, hipMemcpyHostToDevice, p->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    return RT_OK;
+}
+
+// checkpoint file: "DXRACCUM1\n", u32 width, u32 height, u64 state bytes, host state, width*height float4
+static const char kCheckpointMagic[10] = {'D', 'X', 'R', 'A', 'C', 'C', 'U', 'M', '1', '\n'};
+
+int rt_pipeline_save_checkpoint(rt_pipeline *p, const rt_progressive_host *h, const char *path)
+{
+    RT_REQUIRE(p && path, "null argument");
+    if (!p->accum) { rt_set_error("no output resource"); return RT_ERR_STATE; }
+    RT_REQUIRE(p->kind == RT_PIPELINE_PROGRESSIVE, "checkpoint: only the progressive pipeline accumulates");
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    const size_t bytes = (size_t)p->width * p->height * 16;
+    std::vector<char> img(bytes), state;
+    HIP_TRY(hipMemcpyAsync(img.data(), p->accum, bytes, hipMemcpyDeviceToHost, p->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    size_t sb = 0;
+    if (h) {
+        RT_TRY(rt_progressive_host_save_state(h, nullptr, 0, &sb));
+        state.resize(sb);
+        RT_TRY(rt_progressive_host_save_state(h, state.data(), sb, &sb));
+    }
+    FILE *f = fopen(path, "wb");
+    if (!f) { rt_set_error("checkpoint: cannot create %s", path); return RT_ERR_IO; }
+    const uint32_t wh[2] = {p->width, p->height};
+    const uint64_t sb64 = sb;
+    bool ok = fwrite(kCheckpointMagic, 1, sizeof kCheckpointMagic, f) == sizeof kCheckpointMagic && fwrite(wh, 4, 2, f) == 2 &&
+              fwrite(&sb64, 8, 1, f) == 1 && (sb == 0 || fwrite(state.data(), 1, sb, f) == sb) && fwrite(img.data(), 1, bytes, f) == bytes;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { rt_set_error("checkpoint: short write to %s", path); return RT_ERR_IO; }
+    return RT_OK;
+}
+
+int rt_pipeline_load_checkpoint(rt_pipeline *p, rt_progressive_host *h, const char *path)
+{
+    RT_REQUIRE(p && path, "null argument");
+    if (!p->accum) { rt_set_error("no output resource"); return RT_ERR_STATE; }
+    FILE *f = fopen(path, "rb");
+    if (!f) { rt_set_error("checkpoint: cannot open %s", path); return RT_ERR_IO; }
+    char magic[sizeof kCheckpointMagic];
+    uint32_t wh[2] = {0, 0};
+    uint64_t sb = 0;
+    int rc = RT_OK;
+    std::vector<char> state, img;
+    do {
+        if (fread(magic, 1, sizeof magic, f) != sizeof magic || memcmp(magic, kCheckpointMagic, sizeof magic) != 0 || fread(wh, 4, 2, f) != 2 ||
+            fread(&sb, 8, 1, f) != 1 || sb > (1u << 20)) { rt_set_error("checkpoint: %s is not an accumulation checkpoint", path); rc = RT_ERR_IO; break; }
+        if (wh[0] != p->width || wh[1] != p->height) {
+            rt_set_error("checkpoint: %s holds a %ux%u image, the output is %ux%u", path, wh[0], wh[1], p->width, p->height);
+            rc = RT_ERR_INVALID_ARG;
+            break;
+        }
+        state.resize((size_t)sb);
+        img.resize((size_t)wh[0] * wh[1] * 16);
+        if ((sb && fread(state.data(), 1, (size_t)sb, f) != sb) || fread(img.data(), 1, img.size(), f) != img.size()) {
+            rt_set_error("checkpoint: %s is truncated", path);
+            rc = RT_ERR_IO;
+        }
+    } while (0);
+    fclose(f);
+    if (rc != RT_OK) return rc;
+    if (h && sb) RT_TRY(rt_progressive_host_load_state(h, state.data(), (size_t)sb));
+    return rt_pipeline_write_output(p, img.data(), img.size());
+}
+
 int rt_pipeline_enable_timing(rt_pipeline *p, int frames)
 {
     RT_REQUIRE(p, "null pipeline");

@@ -86,6 +86,9 @@ public:
     virtual void *getOutputResource(UINT id) override { void *p = nullptr; DXRFramework::ThrowIfFailed(rt_pipeline_get_output_device_ptr(mPipeline, id, &p)); return p; }
     // copy the accumulation image to the host (RGBA32F, or RGBA16F if created with that format)
     void readOutput(void *host, size_t bytes) { DXRFramework::ThrowIfFailed(rt_pipeline_read_output(mPipeline, host, bytes)); }
+    // accumulation checkpoint: image + mAccumCount / last camera / options / RNG; resuming continues bit for bit
+    void saveCheckpoint(const char *path) { DXRFramework::ThrowIfFailed(rt_pipeline_save_checkpoint(mPipeline, mHost, path)); }
+    void loadCheckpoint(const char *path) { DXRFramework::ThrowIfFailed(rt_pipeline_load_checkpoint(mPipeline, mHost, path)); }
 
     virtual bool *isActive() override { return &mActive; }
     virtual const char *getName() override { return rt_pipeline_get_name(mPipeline); }

@@ -165,6 +165,14 @@ int rt_pipeline_get_output_device_ptr(rt_pipeline *p, uint32_t id, void **ptr); 
 /* synchronises; host buffer is w*h*4 floats (RGBA32F) or halfs (RGBA16F) */
 int rt_pipeline_read_output(rt_pipeline *p, void *host, size_t bytes);
 int rt_pipeline_read_output_n(rt_pipeline *p, uint32_t id, void *host, size_t bytes);   /* output id < getNumOutputs() */
+/* the inverse of rt_pipeline_read_output for the fp32 accumulation image (w*h*16 bytes): resume of an accumulation */
+int rt_pipeline_write_output(rt_pipeline *p, const void *host_rgba32f, size_t bytes);
+/* Accumulation checkpoint (the reference loses its accumulation on exit): the fp32 accumulation
+ * image plus the host-side state update() carries from frame to frame (mAccumCount, last camera, options, flags,
+ * RNG) in one file.  Loading it into a pipeline with an output of the same size and continuing reproduces the
+ * uninterrupted run bit for bit.  `h` may be NULL (image only). */
+int rt_pipeline_save_checkpoint(rt_pipeline *p, const rt_progressive_host *h, const char *path);
+int rt_pipeline_load_checkpoint(rt_pipeline *p, rt_progressive_host *h, const char *path);
 /* synchronises; stage timings need rt_pipeline_enable_timing(p, frames > 0): HIP events
  * are recorded around every stage kernel on the context stream, in a ring that
  * remembers the last `frames` frames */
@@ -193,6 +201,9 @@ int rt_progressive_host_destroy(rt_progressive_host *h);
 int rt_progressive_host_options(rt_progressive_host *h, rt_debug_options **options);   /* mShaderDebugOptions :74-84 */
 int rt_progressive_host_set_flags(rt_progressive_host *h, int accumulation_enabled, int animation_paused);
 int rt_progressive_host_reset(rt_progressive_host *h);                      /* frameDirty :309-311 */
+/* serialised host state (see rt_pipeline_save_checkpoint): call with buf = NULL to get the size in *bytes */
+int rt_progressive_host_save_state(const rt_progressive_host *h, void *buf, size_t capacity, size_t *bytes);
+int rt_progressive_host_load_state(rt_progressive_host *h, const void *buf, size_t bytes);
 int rt_progressive_host_update(rt_progressive_host *h, const float camera[11], float elapsed_time,
                                uint32_t elapsed_frames, uint32_t width, uint32_t height,
                                rt_per_frame_constants *out);                /* update :177-213 */

@@ -192,6 +192,41 @@ def test_instanced_scene_materials_and_misses(gpu, capi, oracle):
     assert ost["secondary_hits"] > ost["primary_hits"]      # chains really go past depth 1
 
 
+def test_checkpoint_resume_is_bit_exact(gpu, capi, oracle, tmp_path):
+    """8 frames straight == 4 frames, checkpoint, a NEW pipeline + host, load, 4 more frames."""
+    W, H = 96, 64
+    v, i = oracle.obj_load(CORNELL_OBJ)
+    cam = cam_array(scenes.cornell_camera(), W / H)
+    straight = make_gpu_pipeline(capi, gpu, [(v, i)], [(0, None)], [T.default_material()], W, H)
+    h0 = capi.ProgressiveHost(21)
+    for f in range(8):
+        straight.update(h0.update(cam, 0.0, f + 1, W, H))
+        straight.render()
+    first = make_gpu_pipeline(capi, gpu, [(v, i)], [(0, None)], [T.default_material()], W, H)
+    h1 = capi.ProgressiveHost(21)
+    for f in range(4):
+        first.update(h1.update(cam, 0.0, f + 1, W, H))
+        first.render()
+    path = str(tmp_path / "accum.ckpt")
+    first.save_checkpoint(path, h1)
+    second = make_gpu_pipeline(capi, gpu, [(v, i)], [(0, None)], [T.default_material()], W, H)
+    h2 = capi.ProgressiveHost(999)
+    second.load_checkpoint(path, h2)
+    assert np.array_equal(second.read_output(), first.read_output())
+    for f in range(4, 8):
+        second.update(h2.update(cam, 0.0, f + 1, W, H))
+        second.render()
+    assert np.array_equal(second.read_output(), straight.read_output())
+    other = make_gpu_pipeline(capi, gpu, [(v, i)], [(0, None)], [T.default_material()], W + 8, H)
+    with pytest.raises(capi.RtError):
+        other.load_checkpoint(path, h2)              # size mismatch
+    with pytest.raises(capi.RtError):
+        second.load_checkpoint(str(tmp_path / "missing.ckpt"), h2)
+    img = np.random.default_rng(3).random((H, W, 4), dtype=np.float32)
+    second.write_output(img)
+    assert np.array_equal(second.read_output(), img)
+
+
 def test_max_iterations_early_out_and_formats(gpu, capi, oracle):
     W, H = 32, 32
     v, i = oracle.obj_load(CORNELL_OBJ)

@@ -108,3 +108,30 @@ def test_c4_many_instances_realtime_denoise_4k(gpu, oracle, capi):
     rays = st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]
     print("\nC4: 4096 instances, 4K realtime frame %.2f ms = %.0f Mrays/s, denoise %.3f ms" % (
         st["ms_total"], rays / st["ms_total"] / 1e3, dn.last_ms()))
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 path end to end (rendezvous, frame sharding, SUM accumulation, all-reduce, max-over-ranks
+    timing, rank-0 JSON) with two ranks sharing this box's single GPU: gloo stands in for RCCL, which refuses
+    two ranks per device.  The 8-GPU run itself is the driver's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DXR_BENCH_BACKEND="gloo", DXR_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29871", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--width", "480", "--height", "270", "--cpu-seconds", "0"]
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["frames_per_gpu"] == 4
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--width", "480", "--height", "270",
+                          "--cpu-seconds", "0"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    # weak scaling: two ranks trace twice the frames, i.e. about twice the rays per step
+    assert abs(d["value"] * d["ms_per_step"] / (d1["value"] * d1["ms_per_step"]) - 2.0) < 0.05

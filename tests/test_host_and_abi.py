@@ -113,6 +113,26 @@ def test_progressive_flags_and_reset(capi):
     assert not np.array_equal(d0, d1)
 
 
+def test_host_state_round_trip(capi):
+    """The host half of an accumulation checkpoint: accumCount, last camera, options, flags and the RNG stream."""
+    cam = cam_array(scenes.cornell_camera(), 1.0)
+    a = capi.ProgressiveHost(77)
+    a.options["noIndirectDiffuse"] = 1
+    for f in range(5):
+        a.update(cam, 0.0, f + 1, 64, 48)
+    blob = a.save_state()
+    b = capi.ProgressiveHost(1)          # different seed, default options: everything must come from the blob
+    b.load_state(blob)
+    for f in range(5, 9):
+        pa, pb = a.update(cam, 0.0, f + 1, 64, 48), b.update(cam, 0.0, f + 1, 64, 48)
+        assert pa.tobytes() == pb.tobytes()
+        assert int(pb["cameraParams"]["accumCount"]) == f and int(pb["options"]["noIndirectDiffuse"]) == 1
+    with pytest.raises(capi.RtError):
+        b.load_state(blob[:-3])
+    with pytest.raises(capi.RtError):
+        b.load_state(b"\0" * len(blob))
+
+
 def test_scene_generators_are_deterministic():
     v1, t1 = scenes.sponza_class(detail=0.25)
     v2, t2 = scenes.sponza_class(detail=0.25)
