@@ -113,7 +113,7 @@ struct rt_context {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_trace_ms = 0.0f;
-    uint32_t leaf_max = 4;       // triangles per collapsed leaf in the traversal layout
+    uint32_t leaf_max = 2;       // triangles per collapsed leaf in the traversal layout (RT_LEAF_MAX; 2 measured best: 1 4.05, 2 3.69, 3 3.80, 4 3.87, 8 4.23 ms/frame)
     bool use_ploc = true;        // RT_FAST_BVH=lbvh keeps the canonical LBVH as the traversal layout
     uint32_t cu_count = 256;     // compute units of the device
     uint32_t blocks_per_cu_override = 0;    // RT_PERSISTENT_BLOCKS_PER_CU: 0 = ask the occupancy API per kernel
