@@ -124,6 +124,8 @@ SIGNATURES = {
     "rt_progressive_host_destroy": (_i, [_p]),
     "rt_progressive_host_options": (_i, [_p, _pp]),
     "rt_progressive_host_set_flags": (_i, [_p, _i, _i]),
+    "rt_image_write_pfm": (_i, [C.c_char_p, _p, _u32, _u32]),
+    "rt_image_write_png": (_i, [C.c_char_p, _p, _u32, _u32, _f, _f, _i]),
     "rt_progressive_host_reset": (_i, [_p]),
     "rt_progressive_host_save_state": (_i, [_p, _p, _sz, C.POINTER(_sz)]),
     "rt_progressive_host_load_state": (_i, [_p, _p, _sz]),
@@ -567,6 +569,18 @@ class ProgressiveHost:
         out = np.zeros((), T.PER_FRAME_CONSTANTS)
         _check(lib().rt_realtime_host_update(self.h, _ptr(cam), elapsed_time, elapsed_frames, width, height, _ptr(out)))
         return out
+
+
+def write_pfm(path, image):
+    """fp32 RGB portable float map of an (H, W, 4) float32 image."""
+    img = np.ascontiguousarray(image, np.float32)
+    _check(lib().rt_image_write_pfm(os.fsencode(path), _ptr(img), img.shape[1], img.shape[0]))
+
+
+def write_png(path, image, exposure=1.0, gamma=2.2, tonemap=True):
+    """8-bit RGB PNG of an (H, W, 4) float32 image: exposure, optional Reinhard, gamma."""
+    img = np.ascontiguousarray(image, np.float32)
+    _check(lib().rt_image_write_png(os.fsencode(path), _ptr(img), img.shape[1], img.shape[0], exposure, gamma, int(tonemap)))
 
 
 class Denoiser:

@@ -2,10 +2,11 @@
 // material the reference app hard-codes, drives update()/render() for N frames and writes the
 // accumulation image as a PFM.  Uses only the reference-shaped C++ API (dxrexperiments_amd/include).
 //
-//   progressive <model.obj> <width> <height> <frames> <out.pfm> [eye.x eye.y eye.z at.x at.y at.z]
+//   progressive <model.obj> <width> <height> <frames> <out.pfm|out.png> [eye.x eye.y eye.z at.x at.y at.z]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "ProgressiveRaytracingPipeline.h"
@@ -15,7 +16,7 @@ using namespace DXRFramework;
 int main(int argc, char **argv)
 {
     if (argc < 6) {
-        std::fprintf(stderr, "usage: %s model.obj width height frames out.pfm [eye xyz at xyz]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s model.obj width height frames out.pfm|out.png [eye xyz at xyz]\n", argv[0]);
         return 2;
     }
     const UINT width = std::atoi(argv[2]), height = std::atoi(argv[3]), frames = std::atoi(argv[4]);
@@ -60,12 +61,11 @@ int main(int argc, char **argv)
         std::printf("%s: %u frames, %.2f fps, ~%.2f Million Primary Rays/s, BVH build %.2f ms\n", pipeline->getName(), frames, frames / s,
                     double(width) * height * frames / s / 1e6, scene->getBuildMilliseconds());
 
-        FILE *f = std::fopen(argv[5], "wb");
-        if (!f) { std::perror(argv[5]); return 1; }
-        std::fprintf(f, "PF\n%u %u\n-1.0\n", width, height);
-        for (int y = int(height) - 1; y >= 0; --y)                        // PFM rows run bottom to top
-            for (UINT x = 0; x < width; ++x) std::fwrite(&image[(size_t(y) * width + x) * 4], sizeof(float), 3, f);
-        std::fclose(f);
+        // .png -> 8-bit view through the compositor's display transform, anything else -> lossless fp32 PFM
+        const std::string out = argv[5];
+        const bool png = out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0;
+        DXRFramework::ThrowIfFailed(png ? rt_image_write_png(out.c_str(), image.data(), width, height, 1.0f, 2.2f, 1)
+                                        : rt_image_write_pfm(out.c_str(), image.data(), width, height));
     } catch (const std::exception &e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -237,6 +237,15 @@ int rt_denoiser_read_output(rt_denoiser *d, void *host, size_t bytes);          
 int rt_denoiser_read_intermediate(rt_denoiser *d, void *host, size_t bytes);                   /* pass H image (tests) */
 int rt_denoiser_last_ms(rt_denoiser *d, float *ms);
 
+/* ---- image files for host copies of the outputs (the reference only blits to its window,
+ *      src/DXRExperimentsApp.cpp:213-214).  rgba32f = width*height float4, row 0 on top. ---------------- */
+/* lossless fp32 RGB portable float map */
+int rt_image_write_pfm(const char *path, const float *rgba32f, uint32_t width, uint32_t height);
+/* 8-bit RGB PNG for viewing: v*exposure, optional Reinhard v/(1+v), v^(1/gamma) (the compositor's display
+ * transform, DenoiseCommon.hlsli:29-41, with host libm: not a parity path) */
+int rt_image_write_png(const char *path, const float *rgba32f, uint32_t width, uint32_t height,
+                       float exposure, float gamma, int tonemap);
+
 /* ---- device math probes (tests): evaluate the kernels' deterministic
  *      sin/cos/exp/log/pow/sqrt/div and samplers on the GPU ------------------- */
 int rt_debug_math(rt_context *ctx, int fn, const float *x, const float *y, float *out, size_t n);

@@ -133,6 +133,42 @@ def test_host_state_round_trip(capi):
         b.load_state(b"\0" * len(blob))
 
 
+def test_image_writers(capi, tmp_path):
+    """PFM is lossless; the PNG decodes (zlib stream, CRCs) to the display transform of the image."""
+    import struct
+    import zlib
+    r = np.random.default_rng(8)
+    img = r.uniform(-0.2, 3.0, (37, 53, 4)).astype(np.float32)
+    img[0, 0, 0] = np.nan
+    pfm, png = str(tmp_path / "a.pfm"), str(tmp_path / "a.png")
+    capi.write_pfm(pfm, img)
+    raw = open(pfm, "rb").read()
+    head = b"PF\n53 37\n-1.0\n"
+    assert raw.startswith(head)
+    back = np.frombuffer(raw[len(head):], "<f4").reshape(37, 53, 3)[::-1]
+    assert np.array_equal(back, img[..., :3], equal_nan=True)
+    capi.write_png(png, img, exposure=1.5, gamma=2.2, tonemap=True)
+    raw = open(png, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, {}
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        body = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + body)
+        chunks.setdefault(typ, b"")
+        chunks[typ] += body
+        pos += 12 + n
+    assert struct.unpack(">IIBBBBB", chunks[b"IHDR"]) == (53, 37, 8, 2, 0, 0, 0) and b"IEND" in chunks
+    px = np.frombuffer(zlib.decompress(chunks[b"IDAT"]), np.uint8).reshape(37, 53 * 3 + 1)
+    assert (px[:, 0] == 0).all()
+    v = np.nan_to_num(img[..., :3].astype(np.float64) * 1.5, nan=0.0).clip(0, None)
+    want = (v / (1 + v)) ** (1 / 2.2) * 255
+    got = px[:, 1:].reshape(37, 53, 3).astype(np.float64)
+    assert np.abs(got - want).max() <= 0.51
+    with pytest.raises(capi.RtError):
+        capi.write_png(str(tmp_path / "no" / "dir.png"), img)
+
+
 def test_scene_generators_are_deterministic():
     v1, t1 = scenes.sponza_class(detail=0.25)
     v2, t2 = scenes.sponza_class(detail=0.25)
