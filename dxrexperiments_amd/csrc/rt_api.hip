@@ -124,6 +124,8 @@ static int context_create(int device, void *stream, bool own, rt_context **out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         c->cu_count = (uint32_t)prop.multiProcessorCount;
+    const char *lt = getenv("RT_LDS_TOP");
+    if (lt && atoi(lt) == 0) c->lds_top = false;
     const char *sr = getenv("RT_LDS_STACK_ROWS");
     if (sr) c->lds_stack_rows = (uint32_t)atoi(sr);
     const char *pb = getenv("RT_PERSISTENT_BLOCKS_PER_CU");

@@ -292,6 +292,33 @@ __global__ void k_gather_tris(const uint64_t *__restrict__ keys, const rt_vertex
 
 inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
+// The first RT_TOP_NODES internal nodes of a traversal layout in breadth-first order, as a table of their
+// own: a child that is in the table is coded RT_NODE_TOP | its table index, every other child keeps its
+// code.  Every ray walks these nodes, so the traversal kernels keep the table in LDS (rt_trace_wave.h).
+// One thread: <= 128 dependent 64-B reads, once per build.
+__global__ void k_top_table(const Slab *__restrict__ slabs, int root_code, Slab *__restrict__ top, uint32_t *__restrict__ top_n)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (root_code < 0) { *top_n = 0; return; }           // the whole structure is one leaf
+    int queue[RT_TOP_NODES];
+    int head = 0, tail = 0;
+    queue[tail++] = root_code;
+    while (head < tail) {
+        Slab s = slabs[queue[head]];
+        int c[2] = {__float_as_int(s.q3.x), __float_as_int(s.q3.y)};
+        for (int k = 0; k < 2; k++)
+            if (c[k] >= 0 && tail < RT_TOP_NODES) {
+                queue[tail] = c[k];
+                c[k] = RT_NODE_TOP | tail;
+                tail++;
+            }
+        s.q3.x = __int_as_float(c[0]);
+        s.q3.y = __int_as_float(c[1]);
+        top[head++] = s;
+    }
+    *top_n = (uint32_t)tail;
+}
+
 // Steps 2..6 for a structure whose primitive boxes and bounds are already on the device.
 int lbvh_from_boxes(rt_context *ctx, BvhDev &bv, const Box6 *boxes, uint32_t n, const float *d_bounds, bool tlas,
                     DevBuf &tmp_keys, DevBuf &tmp_sort, DevBuf &tmp_enc, DevBuf &tmp_depth)
@@ -368,6 +395,16 @@ int rt_build_blas(rt_context *ctx, rt_model *m)
         else m->blas.root_code = 0;
         // production traversal layout: re-cluster the same leaves with PLOC (rt_bvh_ploc.hip)
         if (ctx->use_ploc && (rc = rt_build_ploc_layout(ctx, m)) != RT_OK) break;
+        if ((rc = m->blas.top.reserve(sizeof(Slab) * RT_TOP_NODES + sizeof(uint32_t))) != RT_OK) break;
+        {
+            uint32_t *d_n = (uint32_t *)(m->blas.top.as<Slab>() + RT_TOP_NODES);
+            k_top_table<<<1, 64, 0, st>>>(m->blas.slabs.as<Slab>(), m->blas.root_code, m->blas.top.as<Slab>(), d_n);
+            if (hipMemcpyAsync(&m->blas.top_n, d_n, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                rt_set_error("top table build failed: %s", hipGetErrorString(hipGetLastError()));
+                rc = RT_ERR_HIP;
+                break;
+            }
+        }
         m->built = true;
     } while (0);
     boxes.release(); enc.release(); bounds.release(); tkeys.release(); tsort.release(); tenc.release(); tdepth.release();

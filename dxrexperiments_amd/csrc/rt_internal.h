@@ -102,7 +102,15 @@ struct SceneDev {
     uint32_t n_inst;
     int tlas_root_code;
     int *deep_stack;             // global stack rows beyond the LDS rows (rt_trace_wave.h); nullptr: never needed
+    const Slab *top;             // single-level scenes: the first top_n slabs of the BLAS in breadth-first order,
+    uint32_t top_n;              //   child codes remapped (RT_NODE_TOP | index); the kernels keep them in LDS
 };
+
+#define RT_NODE_TOP   0x40000000      // internal-node code that indexes the LDS-resident top of the tree
+#ifndef RT_TOP_NODES
+#define RT_TOP_NODES  192             // slabs of the top table: 12 KiB of LDS per 256-thread block (measured, ms per frame at
+#endif                                //   26 LDS rows in all: 64 nodes 3.64, 128 3.62, 192 3.56, 256 3.56)
+#define RT_TOP_ROWS(BLOCK) (RT_TOP_NODES * 16 / (BLOCK))      // LDS rows (of BLOCK ints) the top table takes
 
 // ---- host objects --------------------------------------------------------------
 
@@ -117,6 +125,7 @@ struct rt_context {
     bool use_ploc = true;        // RT_FAST_BVH=lbvh keeps the canonical LBVH as the traversal layout
     uint32_t cu_count = 256;     // compute units of the device
     uint32_t blocks_per_cu_override = 0;    // RT_PERSISTENT_BLOCKS_PER_CU: 0 = ask the occupancy API per kernel
+    bool lds_top = true;                    // RT_LDS_TOP=0: every node comes from global memory
     uint32_t lds_stack_rows = 0;            // RT_LDS_STACK_ROWS=6: the small-stack instantiation (tests of the deep-stack path)
     DevBuf pool;                 // ray-pool counters of rt_trace_batch
     DevBuf deep_stack;           // global stack rows of the traversal kernels (rt_scene_dev_for_launch)
@@ -132,9 +141,11 @@ struct BvhDev {
     DevBuf parents;              // uint32[2n-1]
     DevBuf ranges;               // uint2[n-1]          leaf range of every internal node
     DevBuf slabs;                // Slab[max(n-1,1)]    traversal layout
+    DevBuf top;                  // Slab[RT_TOP_NODES]  breadth-first top of the traversal layout (rt_build_top_table)
+    uint32_t top_n = 0;
     int root_code = -1;
     uint32_t fast_depth = 0;     // stack entries the traversal layout can need
-    void release() { nodes.release(); keys.release(); parents.release(); ranges.release(); slabs.release(); }
+    void release() { nodes.release(); keys.release(); parents.release(); ranges.release(); slabs.release(); top.release(); }
 };
 
 struct rt_model {
@@ -174,6 +185,8 @@ struct rt_scene {
         s.n_inst = (uint32_t)inst.size();
         s.tlas_root_code = tlas.root_code;
         s.deep_stack = nullptr;
+        s.top = nullptr;
+        s.top_n = 0;
         return s;
     }
 };
@@ -210,8 +223,8 @@ static inline unsigned rt_persistent_grid(const rt_context *ctx, K kernel, int b
 }
 
 #ifndef RT_LDS_STACK_ROWS
-#define RT_LDS_STACK_ROWS 24            // LDS stack rows of the production kernels: 24 KiB per 256-thread block, 6 blocks per CU
-#endif
+#define RT_LDS_STACK_ROWS 14            // LDS stack rows of the single-level kernels; with the 12-row top table 26 KiB per
+#endif                                  // 256-thread block = 6 blocks per CU.  Two-level kernels have no top table and use all 26 rows
 #define RT_LDS_STACK_ROWS_TEST 6        // second instantiation (env RT_LDS_STACK_ROWS=6): tests force rays onto the global rows
 
 // The scene as the traversal kernels see it, with the global stack rows a launch of `threads` threads whose
@@ -219,15 +232,21 @@ static inline unsigned rt_persistent_grid(const rt_context *ctx, K kernel, int b
 static inline int rt_scene_dev_for_launch(rt_context *ctx, const rt_scene *s, uint32_t lds_rows, size_t threads, SceneDev *out)
 {
     *out = s->dev();
+    if (!s->two_level && ctx->lds_top) {          // one identity instance: rays walk its BLAS directly
+        const rt_model *m = s->inst[0].model;
+        out->top = m->blas.top.as<Slab>();
+        out->top_n = m->blas.top_n;
+    }
     const uint32_t bound = s->stack_need + 2;
     if (bound <= lds_rows) return RT_OK;
     RT_TRY(ctx->deep_stack.reserve((size_t)(bound - lds_rows) * threads * sizeof(int)));
     out->deep_stack = ctx->deep_stack.as<int>();
     return RT_OK;
 }
-static inline uint32_t rt_lds_stack_rows(const rt_context *ctx)
+static inline uint32_t rt_lds_stack_rows(const rt_context *ctx, bool two_level)
 {
-    return ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST ? RT_LDS_STACK_ROWS_TEST : RT_LDS_STACK_ROWS;
+    const uint32_t rows = ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST ? RT_LDS_STACK_ROWS_TEST : RT_LDS_STACK_ROWS;
+    return two_level ? rows + RT_TOP_ROWS(256) : rows;
 }
 
 // rt_api.hip

@@ -467,10 +467,10 @@ struct PrimarySink {
 template <int STACK, bool TWO_LEVEL>
 __global__ void __launch_bounds__(PBLOCK) k_primary(PipeDev pd)
 {
-    __shared__ int smem[STACK * PBLOCK];
+    __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     PrimarySrc src = {pd};
     PrimarySink sink = {pd};
-    trace_wave<STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, &pd.counters[C_POOL_PRIMARY], smem, nullptr);   // one 8x8 tile per wave
+    trace_wave<TWO_LEVEL ? STACK + RT_TOP_ROWS(PBLOCK) : STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, &pd.counters[C_POOL_PRIMARY], smem, nullptr);   // one 8x8 tile per wave
 }
 
 // Compaction of the hits of level L (they get shaded): ballot + popcount prefix sums, one atomic per block.
@@ -598,17 +598,17 @@ struct ShadowSinkN {      // ShadowMiss sets visibility 1 (ProgressiveRaytracing
 template <int STACK, bool TWO_LEVEL>
 __global__ void __launch_bounds__(PBLOCK) k_trace_shadow(SceneDev sc, ShadowSrcN src, uint32_t *pool, uint32_t *stat)
 {
-    __shared__ int smem[STACK * PBLOCK];
+    __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     ShadowSinkN sink = {src};
-    trace_wave<STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem, stat);
+    trace_wave<TWO_LEVEL ? STACK + RT_TOP_ROWS(PBLOCK) : STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem, stat);
 }
 
 template <int STACK, bool TWO_LEVEL>
 __global__ void __launch_bounds__(PBLOCK) k_trace_secondary(SceneDev sc, QueueSrc src, float4 *hit1, uint32_t *inst1, uint32_t *pool, uint32_t *stat)
 {
-    __shared__ int smem[STACK * PBLOCK];
+    __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     SecondarySink sink = {src, hit1, inst1};
-    trace_wave<STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem, stat);
+    trace_wave<TWO_LEVEL ? STACK + RT_TOP_ROWS(PBLOCK) : STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem, stat);
 }
 
 template <int MAXL>
@@ -1058,7 +1058,7 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
     }
     PipeDev pd;
     // (threads of the largest launch: the primary stage runs one thread per pixel slot, the persistent stages fewer)
-    RT_TRY(rt_scene_dev_for_launch(ctx, p->scene, rt_lds_stack_rows(ctx), cap > ctx->cu_count * 16u * PBLOCK ? cap : ctx->cu_count * 16u * PBLOCK, &pd.sc));
+    RT_TRY(rt_scene_dev_for_launch(ctx, p->scene, rt_lds_stack_rows(ctx, p->scene->two_level), cap > ctx->cu_count * 16u * PBLOCK ? cap : ctx->cu_count * 16u * PBLOCK, &pd.sc));
     pd.pfc = p->pfc;
     pd.mats = p->d_mats.as<rt_material_params>();
     pd.nmats = (uint32_t)p->mats.size();

@@ -89,12 +89,20 @@ struct LaneStack {
 // One step on an internal node: both children are slab-tested, the nearer hit child is entered, the farther
 // one is written to the stack slot above the top unconditionally (it only counts if the top moves), the
 // slot below the top is read speculatively (it only counts if both children miss).  Branch free.
-template <bool DEEP, int STACK, int BLOCK>
-RT_DEV void node_step(const Slab *slabs, const RayInv &ri, float tmin, float tbest, const LaneStack<STACK, BLOCK> &st, int &node, int &sp)
+template <bool DEEP, bool TOP, int STACK, int BLOCK>
+RT_DEV void node_step(const Slab *slabs, const int *top, const RayInv &ri, float tmin, float tbest, const LaneStack<STACK, BLOCK> &st, int &node, int &sp)
 {
-    // 32-bit byte offset from the (wave-uniform, single-level) slab base: SGPR base + VGPR offset addressing
-    const char *sl = (const char *)slabs + ((uint32_t)node << 6);
-    const v4f q0 = ldg16(sl, 0), q1 = ldg16(sl, 16), q2 = ldg16(sl, 32), q3 = ldg16(sl, 48);
+    v4f q0, q1, q2, q3;
+    if (TOP && (node & RT_NODE_TOP)) {
+        // the top of the tree is LDS resident: every ray walks it, and divergent 16-B global loads cost the
+        // vector L1 about a clock per lane whether they hit or not
+        const v4f *t = (const v4f *)(top + ((node & 0xFFFF) << 4));
+        q0 = t[0]; q1 = t[1]; q2 = t[2]; q3 = t[3];
+    } else {
+        // 32-bit byte offset from the (wave-uniform, single-level) slab base: SGPR base + VGPR offset addressing
+        const char *sl = (const char *)slabs + ((uint32_t)node << 6);
+        q0 = ldg16(sl, 0); q1 = ldg16(sl, 16); q2 = ldg16(sl, 32); q3 = ldg16(sl, 48);
+    }
     float e0, e1;
     const bool h0 = slab_hit(ri, q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, tmin, tbest, e0);
     const bool h1 = slab_hit(ri, q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, tmin, tbest, e1);
@@ -104,8 +112,8 @@ RT_DEV void node_step(const Slab *slabs, const RayInv &ri, float tmin, float tbe
     const int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
     const int one = h0 ? c0 : c1;
     const int below = sp > 0 ? sp - 1 : 0;
-    const int top = DEEP ? st.read(below) : st.lds[below * BLOCK];     // speculative pop (unconditional read)
-    const int popped = sp > 0 ? top : RT_NODE_EMPTY;
+    const int above = DEEP ? st.read(below) : st.lds[below * BLOCK];   // speculative pop (unconditional read)
+    const int popped = sp > 0 ? above : RT_NODE_EMPTY;
     if (DEEP) st.write(sp, farc);                                      // speculative push
     else st.lds[sp * BLOCK] = farc;
     node = both ? nearc : (none ? popped : one);
@@ -146,7 +154,15 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
     const InstanceRec *in0 = sc.inst;
     const Slab *blas_slabs0 = TWO_LEVEL ? nullptr : in0->slabs;
     const TriRec *tris0 = TWO_LEVEL ? nullptr : in0->tris;
-    const int root0 = TWO_LEVEL ? sc.tlas_root_code : in0->root_code;
+    // the LDS-resident top of the tree (single-level walks): smem rows STACK .. STACK + RT_TOP_ROWS - 1
+    int *topl = smem + STACK * BLOCK;
+    const bool have_top = !TWO_LEVEL && sc.top_n != 0;
+    if (have_top) {
+        const int *src_top = (const int *)sc.top;
+        for (uint32_t i = threadIdx.x; i < sc.top_n * 16u; i += BLOCK) topl[i] = src_top[i];
+        __syncthreads();
+    }
+    const int root0 = TWO_LEVEL ? sc.tlas_root_code : (have_top ? RT_NODE_TOP : in0->root_code);
 
     bool alive = false;
     bool exhausted = false;          // wave-uniform: the global pool has nothing left
@@ -225,7 +241,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 #endif
         while (alive && node_is_internal(node) && sp < STACK) {
             RT_STAT_WAVE(0); RT_STAT_LANE(0);
-            node_step<false>(slabs, cur.ri, r.tmin, best.t, st, node, sp);
+            node_step<false, !TWO_LEVEL>(slabs, topl, cur.ri, r.tmin, best.t, st, node, sp);
 #ifdef RT_TRACE_STATS
             st_maxsp = sp > st_maxsp ? sp : st_maxsp;
 #endif
@@ -236,7 +252,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 #endif
         }
         // lanes whose stack has outgrown the LDS rows walk on with the global rows until it fits again
-        while (alive && node_is_internal(node) && sp >= STACK) node_step<true>(slabs, cur.ri, r.tmin, best.t, st, node, sp);
+        while (alive && node_is_internal(node) && sp >= STACK) node_step<true, !TWO_LEVEL>(slabs, topl, cur.ri, r.tmin, best.t, st, node, sp);
 
         // ---- leaves, instance entry / exit, termination -----------------------------------
         RT_STAT_WAVE(3);
