@@ -124,6 +124,7 @@ static int context_create(int device, void *stream, bool own, rt_context **out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         c->cu_count = (uint32_t)prop.multiProcessorCount;
+    if (hipHostMalloc((void **)&c->pinned, 64 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) c->pinned = nullptr;
     const char *lt = getenv("RT_LDS_TOP");
     if (lt && atoi(lt) == 0) c->lds_top = false;
     const char *sr = getenv("RT_LDS_STACK_ROWS");
@@ -169,6 +170,8 @@ void rt_context_release(rt_context *ctx)
     for (DevBuf &b : ctx->scratch) b.release();
     ctx->pool.release();
     ctx->deep_stack.release();
+    ctx->build_arena.release();
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -17,6 +17,8 @@
 //      collapsed into leaves, triangles gathered in sorted order.
 #include "rt_internal.h"
 
+#include <chrono>
+
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
@@ -292,6 +294,29 @@ __global__ void k_gather_tris(const uint64_t *__restrict__ keys, const rt_vertex
 
 inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
+// Temporaries of a build over n primitives as slices of the context's build arena (sized for the larger of
+// the LBVH and the PLOC phase, which run one after the other).  A slice that turns out too small makes
+// its DevBuf allocate on its own (DevBuf::reserve), so the sizes here are a fast path, not a contract.
+struct BuildTemps { DevBuf boxes, enc, bounds, tkeys, tsort, tenc, tdepth; };
+int take_build_temps(rt_context *ctx, uint32_t n, BuildTemps &t)
+{
+    const size_t A = 256;
+    auto up = [&](size_t b) { return (b + A - 1) & ~(A - 1); };
+    const size_t want[7] = {up(sizeof(Box6) * (size_t)n), A, A, up(8 * (size_t)n), up(16 * (size_t)n + (4u << 20)), up(24 * (size_t)n), A};
+    size_t lbvh = 0;
+    for (size_t w : want) lbvh += w;
+    const size_t ploc = rt_ploc_temp_bytes(n);
+    RT_TRY(ctx->build_arena.reserve(lbvh > ploc ? lbvh : ploc));
+    DevBuf *bufs[7] = {&t.boxes, &t.enc, &t.bounds, &t.tkeys, &t.tsort, &t.tenc, &t.tdepth};
+    size_t at = 0;
+    for (int k = 0; k < 7; k++) { bufs[k]->adopt((char *)ctx->build_arena.p + at, want[k]); at += want[k]; }
+    return RT_OK;
+}
+void drop_build_arena_if_large(rt_context *ctx)
+{
+    if (ctx->build_arena.bytes > ((size_t)256 << 20)) ctx->build_arena.release();      // keep small arenas for the next build
+}
+
 // The first RT_TOP_NODES internal nodes of a traversal layout in breadth-first order, as a table of their
 // own: a child that is in the table is coded RT_NODE_TOP | its table index, every other child keeps its
 // code.  Every ray walks these nodes, so the traversal kernels keep the table in LDS (rt_trace_wave.h).
@@ -371,18 +396,33 @@ int rt_build_blas(rt_context *ctx, rt_model *m)
     hipStream_t st = ctx->stream;
     const unsigned B = 256;
     const uint32_t n = m->n_tris;
-    DevBuf boxes, enc, bounds, tkeys, tsort, tenc, tdepth;
+    BuildTemps bt;
+    DevBuf &boxes = bt.boxes, &enc = bt.enc, &bounds = bt.bounds, &tkeys = bt.tkeys, &tsort = bt.tsort, &tenc = bt.tenc, &tdepth = bt.tdepth;
     int rc = RT_OK;
+    const bool verbose = getenv("RT_VERBOSE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {          // RT_VERBOSE: wall time of each build phase (synchronises: diagnostics only)
+        if (!verbose) return;
+        (void)hipStreamSynchronize(st);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[dxr_amd]   BLAS %-18s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     do {
+        if ((rc = take_build_temps(ctx, n, bt)) != RT_OK) break;
+        mark("arena");
         if ((rc = boxes.reserve(sizeof(Box6) * (size_t)n)) != RT_OK) break;
         if ((rc = enc.reserve(6 * sizeof(uint32_t))) != RT_OK) break;
         if ((rc = bounds.reserve(6 * sizeof(float))) != RT_OK) break;
         if ((rc = m->tris.reserve(sizeof(TriRec) * (size_t)n)) != RT_OK) break;
+        mark("tris alloc");
         k_init_bounds<<<1, 64, 0, st>>>(enc.as<uint32_t>());
         k_tri_boxes<<<grid_for(n, B), B, 0, st>>>(m->d_verts.as<rt_vertex>(), m->d_idx.as<uint32_t>(), n, boxes.as<Box6>(),
                                                   enc.as<uint32_t>());
         k_decode_bounds<<<1, 64, 0, st>>>(enc.as<uint32_t>(), bounds.as<float>());
+        mark("alloc + boxes");
         if ((rc = lbvh_from_boxes(ctx, m->blas, boxes.as<Box6>(), n, bounds.as<float>(), false, tkeys, tsort, tenc, tdepth)) != RT_OK) break;
+        mark("LBVH");
         k_gather_tris<<<grid_for(n, B), B, 0, st>>>(m->blas.keys.as<uint64_t>(), m->d_verts.as<rt_vertex>(),
                                                     m->d_idx.as<uint32_t>(), n, m->tris.as<TriRec>());
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
@@ -394,7 +434,9 @@ int rt_build_blas(rt_context *ctx, rt_model *m)
         else if (n <= ctx->leaf_max) m->blas.root_code = ~(int)(n - 1);            // leaf(first 0, count n)
         else m->blas.root_code = 0;
         // production traversal layout: re-cluster the same leaves with PLOC (rt_bvh_ploc.hip)
+        mark("gather");
         if (ctx->use_ploc && (rc = rt_build_ploc_layout(ctx, m)) != RT_OK) break;
+        mark("PLOC layout");
         if ((rc = m->blas.top.reserve(sizeof(Slab) * RT_TOP_NODES + sizeof(uint32_t))) != RT_OK) break;
         {
             uint32_t *d_n = (uint32_t *)(m->blas.top.as<Slab>() + RT_TOP_NODES);
@@ -405,9 +447,12 @@ int rt_build_blas(rt_context *ctx, rt_model *m)
                 break;
             }
         }
+        mark("top table");
         m->built = true;
     } while (0);
     boxes.release(); enc.release(); bounds.release(); tkeys.release(); tsort.release(); tenc.release(); tdepth.release();
+    drop_build_arena_if_large(ctx);
+    mark("free");
     return rc;
 }
 
@@ -484,9 +529,11 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
         for (int c = 0; c < 3; c++) { hb[i].lo[c] = r.wlo[c]; hb[i].hi[c] = r.whi[c]; }
         deepest = m->blas.fast_depth > deepest ? m->blas.fast_depth : deepest;
     }
-    DevBuf boxes, enc, bounds, tkeys, tsort, tenc, tdepth;
+    BuildTemps bt;
+    DevBuf &boxes = bt.boxes, &enc = bt.enc, &bounds = bt.bounds, &tkeys = bt.tkeys, &tsort = bt.tsort, &tenc = bt.tenc, &tdepth = bt.tdepth;
     int rc = RT_OK;
     do {
+        if ((rc = take_build_temps(ctx, n, bt)) != RT_OK) break;
         if ((rc = s->d_inst.reserve(sizeof(InstanceRec) * (size_t)n)) != RT_OK) break;
         if ((rc = boxes.reserve(sizeof(Box6) * (size_t)n)) != RT_OK) break;
         if ((rc = enc.reserve(6 * sizeof(uint32_t))) != RT_OK) break;

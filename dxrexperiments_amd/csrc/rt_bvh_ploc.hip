@@ -86,15 +86,27 @@ __global__ void k_ploc_flags(const uint32_t *__restrict__ nn, uint32_t c, uint32
     keep[i] = (mutual && i > j) ? 0u : 1u;         // the higher index disappears
 }
 
-__global__ void k_ploc_apply(const uint32_t *__restrict__ nn, const uint32_t *__restrict__ keep, const uint32_t *__restrict__ merge,
-                             const uint32_t *__restrict__ keep_pos, const uint32_t *__restrict__ merge_pos, uint32_t c, uint32_t n,
-                             uint32_t next_node, const uint32_t *__restrict__ cl_node, const Box6 *__restrict__ cl_box,
-                             uint32_t *__restrict__ out_node, Box6 *__restrict__ out_box, uint32_t *__restrict__ left,
-                             uint32_t *__restrict__ right, Box6 *__restrict__ node_box, uint32_t *__restrict__ size,
-                             uint32_t *__restrict__ parent)
+// a piece of the build's one temporary allocation
+struct View {
+    void *p = nullptr;
+    template <class T> T *as() const { return (T *)p; }
+};
+
+// the arrays one PLOC round reads and writes
+struct PlocArrays {
+    uint32_t *nn, *keep, *merge, *keep_pos, *merge_pos;
+    uint32_t *cl_node[2];
+    Box6 *cl_box[2];
+    uint32_t *left, *right, *size, *parent;
+    Box6 *node_box;
+};
+
+__device__ __forceinline__ void ploc_apply_one(uint32_t i, const uint32_t *nn, const uint32_t *keep, const uint32_t *merge,
+                                               const uint32_t *keep_pos, const uint32_t *merge_pos, uint32_t n, uint32_t next_node,
+                                               const uint32_t *cl_node, const Box6 *cl_box, uint32_t *out_node, Box6 *out_box,
+                                               uint32_t *left, uint32_t *right, Box6 *node_box, uint32_t *size, uint32_t *parent)
 {
-    const uint32_t i = blockIdx.x * PB + threadIdx.x;
-    if (i >= c || !keep[i]) return;
+    if (!keep[i]) return;
     const uint32_t pos = keep_pos[i];
     if (merge[i]) {
         const uint32_t j = nn[i];
@@ -116,6 +128,88 @@ __global__ void k_ploc_apply(const uint32_t *__restrict__ nn, const uint32_t *__
         out_node[pos] = cl_node[i];
         out_box[pos] = cl_box[i];
     }
+}
+
+__global__ void k_ploc_apply(const uint32_t *__restrict__ nn, const uint32_t *__restrict__ keep, const uint32_t *__restrict__ merge,
+                             const uint32_t *__restrict__ keep_pos, const uint32_t *__restrict__ merge_pos, uint32_t c, uint32_t n,
+                             uint32_t next_node, const uint32_t *__restrict__ cl_node, const Box6 *__restrict__ cl_box,
+                             uint32_t *__restrict__ out_node, Box6 *__restrict__ out_box, uint32_t *__restrict__ left,
+                             uint32_t *__restrict__ right, Box6 *__restrict__ node_box, uint32_t *__restrict__ size,
+                             uint32_t *__restrict__ parent)
+{
+    const uint32_t i = blockIdx.x * PB + threadIdx.x;
+    if (i >= c) return;
+    ploc_apply_one(i, nn, keep, merge, keep_pos, merge_pos, n, next_node, cl_node, cl_box, out_node, out_box, left, right, node_box, size, parent);
+}
+
+// The tail of the clustering: once PLOC_TAIL or fewer clusters are left, ONE workgroup runs all the
+// remaining rounds (nearest neighbour, mutual-pair flags, the two prefix sums, merge) back to back with
+// barriers in between -- the same arithmetic and the same node numbering as the multi-kernel rounds,
+// without ~40 rounds of launches and host round trips for a handful of clusters each.
+constexpr uint32_t PLOC_TAIL = 4096, TAIL_BLOCK = 1024;
+__global__ void __launch_bounds__(TAIL_BLOCK) k_ploc_tail(PlocArrays a, uint32_t c, uint32_t n, uint32_t next_node, int cur, uint32_t *__restrict__ result)
+{
+    __shared__ uint32_t part_keep[TAIL_BLOCK], part_merge[TAIL_BLOCK];
+    constexpr uint32_t PER = PLOC_TAIL / TAIL_BLOCK;
+    const uint32_t t = threadIdx.x;
+    while (c > 1) {
+        const Box6 *box = a.cl_box[cur];
+        for (uint32_t i = t; i < c; i += TAIL_BLOCK) {               // nearest neighbour (k_ploc_nn)
+            const Box6 me = box[i];
+            float best = __uint_as_float(0x7f800000u);
+            uint32_t arg = i;
+            for (int d = -PLOC_RADIUS; d <= PLOC_RADIUS; d++) {
+                const int j = (int)i + d;
+                if (d == 0 || j < 0 || j >= (int)c) continue;
+                const float ar = merged_area(me, box[j]);
+                if (ar < best) { best = ar; arg = (uint32_t)j; }
+            }
+            a.nn[i] = arg;
+        }
+        __syncthreads();
+        uint32_t k_sum = 0, m_sum = 0;
+        for (uint32_t e = 0; e < PER; e++) {                          // flags (k_ploc_flags), PER consecutive clusters per thread
+            const uint32_t i = t * PER + e;
+            if (i >= c) break;
+            const uint32_t j = a.nn[i];
+            const bool mutual = j != i && a.nn[j] == i;
+            const uint32_t mg = (mutual && i < j) ? 1u : 0u, kp = (mutual && i > j) ? 0u : 1u;
+            a.merge[i] = mg;
+            a.keep[i] = kp;
+            k_sum += kp;
+            m_sum += mg;
+        }
+        part_keep[t] = k_sum;
+        part_merge[t] = m_sum;
+        __syncthreads();
+        for (uint32_t off = 1; off < TAIL_BLOCK; off <<= 1) {         // inclusive scan of the per-thread sums
+            const uint32_t pk = t >= off ? part_keep[t - off] : 0u, pm = t >= off ? part_merge[t - off] : 0u;
+            __syncthreads();
+            part_keep[t] += pk;
+            part_merge[t] += pm;
+            __syncthreads();
+        }
+        uint32_t k_run = part_keep[t] - k_sum, m_run = part_merge[t] - m_sum;      // exclusive prefix of this thread's run
+        for (uint32_t e = 0; e < PER; e++) {
+            const uint32_t i = t * PER + e;
+            if (i >= c) break;
+            a.keep_pos[i] = k_run;
+            a.merge_pos[i] = m_run;
+            k_run += a.keep[i];
+            m_run += a.merge[i];
+        }
+        const uint32_t kept = part_keep[TAIL_BLOCK - 1], merged = part_merge[TAIL_BLOCK - 1];
+        __syncthreads();
+        if (merged == 0 || kept != c - merged) break;                 // no progress: reported by the host
+        for (uint32_t i = t; i < c; i += TAIL_BLOCK)
+            ploc_apply_one(i, a.nn, a.keep, a.merge, a.keep_pos, a.merge_pos, n, next_node, a.cl_node[cur], a.cl_box[cur], a.cl_node[cur ^ 1],
+                           a.cl_box[cur ^ 1], a.left, a.right, a.node_box, a.size, a.parent);
+        __syncthreads();
+        c = kept;
+        next_node += merged;
+        cur ^= 1;
+    }
+    if (t == 0) { result[0] = c; result[1] = next_node; }
 }
 
 // leaf boxes into node_box[0..n-1] so every node id indexes one box array
@@ -199,6 +293,14 @@ inline unsigned gr(size_t n) { return (unsigned)((n + PB - 1) / PB); }
 
 }  // namespace
 
+// bytes of temporaries rt_build_ploc_layout slices out of the context's build arena (an upper estimate: the
+// scan scratch is small next to the rest)
+size_t rt_ploc_temp_bytes(uint32_t n)
+{
+    const size_t nn2 = 2 * (size_t)n;
+    return 8 * (size_t)n + 2 * sizeof(Box6) * (size_t)n + 20 * ((size_t)n + 1) + 12 * (size_t)n + sizeof(Box6) * nn2 + 12 * nn2 + ((size_t)1 << 20) + 18 * 256;
+}
+
 // Rebuilds m->blas.slabs / m->tris / root_code / fast_depth from a PLOC tree.  The canonical arrays
 // (nodes, keys, parents) are left untouched.
 int rt_build_ploc_layout(rt_context *ctx, rt_model *m)
@@ -206,39 +308,35 @@ int rt_build_ploc_layout(rt_context *ctx, rt_model *m)
     const uint32_t n = m->n_tris;
     if (n < 2 * ctx->leaf_max + 2) return RT_OK;          // tiny meshes: the LBVH layout is as good as any
     hipStream_t st = ctx->stream;
-    DevBuf cl_node[2], cl_box[2], nn, keep, merge, keep_pos, merge_pos, left, right, node_box, size, parent, offset, slot, scan_tmp, depth;
+    // every temporary of the build is carved out of ONE allocation (hipMalloc / hipFree synchronise the
+    // device and cost more than the kernels of a small build)
+    View cl_node[2], cl_box[2], nn, keep, merge, keep_pos, merge_pos, left, right, node_box, size, parent, offset, slot, scan_tmp, depth;
     int rc = RT_OK;
     do {
         const size_t nn2 = 2 * (size_t)n - 1;
-        for (int k = 0; k < 2 && rc == RT_OK; k++) {
-            rc = cl_node[k].reserve(4 * (size_t)n);
-            if (rc == RT_OK) rc = cl_box[k].reserve(sizeof(Box6) * (size_t)n);
-        }
-        DevBuf *u32s[] = {&nn, &keep, &merge, &keep_pos, &merge_pos};
-        for (DevBuf *b : u32s) if (rc == RT_OK) rc = b->reserve(4 * ((size_t)n + 1));
-        if (rc == RT_OK) rc = left.reserve(4 * (size_t)(n - 1));
-        if (rc == RT_OK) rc = right.reserve(4 * (size_t)(n - 1));
-        if (rc == RT_OK) rc = node_box.reserve(sizeof(Box6) * nn2);
-        if (rc == RT_OK) rc = size.reserve(4 * nn2);
-        if (rc == RT_OK) rc = parent.reserve(4 * nn2);
-        if (rc == RT_OK) rc = offset.reserve(4 * nn2);
-        if (rc == RT_OK) rc = slot.reserve(4 * (size_t)(n - 1));
-        if (rc == RT_OK) rc = depth.reserve(4);
-        if (rc != RT_OK) break;
         size_t tmp_bytes = 0;
-        if (rocprim::exclusive_scan(nullptr, tmp_bytes, keep.as<uint32_t>(), keep_pos.as<uint32_t>(), 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st) != hipSuccess) {
+        if (rocprim::exclusive_scan(nullptr, tmp_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st) != hipSuccess) {
             rt_set_error("rocprim::exclusive_scan sizing failed");
             rc = RT_ERR_HIP;
             break;
         }
-        if ((rc = scan_tmp.reserve(tmp_bytes)) != RT_OK) break;
+        struct Want { View *v; size_t bytes; };
+        const Want wants[] = {{&cl_node[0], 4 * (size_t)n}, {&cl_node[1], 4 * (size_t)n}, {&cl_box[0], sizeof(Box6) * (size_t)n}, {&cl_box[1], sizeof(Box6) * (size_t)n},
+                              {&nn, 4 * ((size_t)n + 1)}, {&keep, 4 * ((size_t)n + 1)}, {&merge, 4 * ((size_t)n + 1)}, {&keep_pos, 4 * ((size_t)n + 1)},
+                              {&merge_pos, 4 * ((size_t)n + 1)}, {&left, 4 * (size_t)(n - 1)}, {&right, 4 * (size_t)(n - 1)}, {&node_box, sizeof(Box6) * nn2},
+                              {&size, 4 * nn2}, {&parent, 4 * nn2}, {&offset, 4 * nn2}, {&slot, 4 * (size_t)(n - 1)}, {&scan_tmp, tmp_bytes}, {&depth, 8}};
+        size_t total = 0;
+        for (const Want &w : wants) total += (w.bytes + 255) & ~(size_t)255;
+        if ((rc = ctx->build_arena.reserve(total)) != RT_OK) break;      // normally already there (rt_ploc_temp_bytes)
+        size_t at = 0;
+        for (const Want &w : wants) { w.v->p = (char *)ctx->build_arena.p + at; at += (w.bytes + 255) & ~(size_t)255; }
 
         k_ploc_init<<<gr(n), PB, 0, st>>>(m->blas.nodes.as<rt_bvh_node>(), n, cl_node[0].as<uint32_t>(), cl_box[0].as<Box6>(),
                                          size.as<uint32_t>(), parent.as<uint32_t>());
         k_ploc_leaf_boxes<<<gr(n), PB, 0, st>>>(cl_box[0].as<Box6>(), n, node_box.as<Box6>());
         uint32_t c = n, next_node = n;
         int cur = 0;
-        for (int round = 0; c > 1 && round < 4096; round++) {
+        for (int round = 0; c > PLOC_TAIL && round < 4096; round++) {
             k_ploc_nn<<<gr(c), PB, 0, st>>>(cl_box[cur].as<Box6>(), c, nn.as<uint32_t>());
             k_ploc_flags<<<gr(c), PB, 0, st>>>(nn.as<uint32_t>(), c, keep.as<uint32_t>(), merge.as<uint32_t>());
             // scans run over c+1 elements so that element c holds the totals (its input flag is garbage-free: set to 0)
@@ -252,7 +350,8 @@ int rt_build_ploc_layout(rt_context *ctx, rt_model *m)
                                               merge_pos.as<uint32_t>(), c, n, next_node, cl_node[cur].as<uint32_t>(), cl_box[cur].as<Box6>(),
                                               cl_node[cur ^ 1].as<uint32_t>(), cl_box[cur ^ 1].as<Box6>(), left.as<uint32_t>(),
                                               right.as<uint32_t>(), node_box.as<Box6>(), size.as<uint32_t>(), parent.as<uint32_t>());
-            uint32_t totals[2];
+            uint32_t stack_totals[2];
+            uint32_t *totals = ctx->pinned ? ctx->pinned : stack_totals;      // page-locked: no staging copy
             if (hipMemcpyAsync(&totals[0], keep_pos.as<uint32_t>() + c, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipMemcpyAsync(&totals[1], merge_pos.as<uint32_t>() + c, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess) {
@@ -270,6 +369,24 @@ int rt_build_ploc_layout(rt_context *ctx, rt_model *m)
             cur ^= 1;
         }
         if (rc != RT_OK) break;
+        if (c > 1) {
+            PlocArrays pa;
+            pa.nn = nn.as<uint32_t>(); pa.keep = keep.as<uint32_t>(); pa.merge = merge.as<uint32_t>();
+            pa.keep_pos = keep_pos.as<uint32_t>(); pa.merge_pos = merge_pos.as<uint32_t>();
+            for (int k = 0; k < 2; k++) { pa.cl_node[k] = cl_node[k].as<uint32_t>(); pa.cl_box[k] = cl_box[k].as<Box6>(); }
+            pa.left = left.as<uint32_t>(); pa.right = right.as<uint32_t>(); pa.size = size.as<uint32_t>(); pa.parent = parent.as<uint32_t>();
+            pa.node_box = node_box.as<Box6>();
+            uint32_t *d_res = depth.as<uint32_t>();              // (two words: reserved below)
+            k_ploc_tail<<<1, TAIL_BLOCK, 0, st>>>(pa, c, n, next_node, cur, d_res);
+            uint32_t res[2] = {0, 0};
+            if (hipMemcpyAsync(res, d_res, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                rt_set_error("PLOC tail failed: %s", hipGetErrorString(hipGetLastError()));
+                rc = RT_ERR_HIP;
+                break;
+            }
+            c = res[0];
+            next_node = res[1];
+        }
         if (c != 1 || next_node != 2 * n - 1) {
             rt_set_error("PLOC did not converge (%u clusters, %u nodes)", c, next_node);
             rc = RT_ERR_STATE;
@@ -292,8 +409,5 @@ int rt_build_ploc_layout(rt_context *ctx, rt_model *m)
         m->blas.fast_depth = d;
         m->blas.root_code = 0;                             // pre-order: the root is slab 0
     } while (0);
-    DevBuf *all[] = {&cl_node[0], &cl_node[1], &cl_box[0], &cl_box[1], &nn, &keep, &merge, &keep_pos, &merge_pos, &left, &right,
-                     &node_box, &size, &parent, &offset, &slot, &scan_tmp, &depth};
-    for (DevBuf *b : all) b->release();
     return rc;
 }

@@ -40,10 +40,14 @@ void rt_set_error(const char *fmt, ...);
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    bool borrowed = false;       // p points into somebody else's allocation (adopt): never freed here
+    // use a slice of another allocation; a later reserve() beyond it falls back to an allocation of its own
+    void adopt(void *ptr, size_t n) { release(); p = ptr; bytes = n; borrowed = ptr != nullptr; }
     int reserve(size_t n)
     {
         if (n <= bytes) return RT_OK;
-        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        if (p && !borrowed) (void)hipFree(p);
+        p = nullptr; bytes = 0; borrowed = false;
         hipError_t e = hipMalloc(&p, n ? n : 16);
         if (e != hipSuccess) {
             rt_set_error("hipMalloc(%zu): %s", n, hipGetErrorString(e));
@@ -55,9 +59,10 @@ struct DevBuf {
     }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p && !borrowed) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
+        borrowed = false;
     }
     template <class T> T *as() const { return (T *)p; }
 };
@@ -129,6 +134,9 @@ struct rt_context {
     uint32_t lds_stack_rows = 0;            // RT_LDS_STACK_ROWS=6: the small-stack instantiation (tests of the deep-stack path)
     DevBuf pool;                 // ray-pool counters of rt_trace_batch
     DevBuf deep_stack;           // global stack rows of the traversal kernels (rt_scene_dev_for_launch)
+    uint32_t *pinned = nullptr;  // 64 words of page-locked host memory: small device-to-host read-backs without staging
+    DevBuf build_arena;          // temporaries of the acceleration-structure builds: one allocation, sliced (hipMalloc
+                                 // and hipFree synchronise the device and cost more than the kernels of a small build)
     DevBuf scratch[8];           // staging for host-pointer batch calls
 };
 
@@ -248,6 +256,9 @@ static inline uint32_t rt_lds_stack_rows(const rt_context *ctx, bool two_level)
     const uint32_t rows = ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST ? RT_LDS_STACK_ROWS_TEST : RT_LDS_STACK_ROWS;
     return two_level ? rows + RT_TOP_ROWS(256) : rows;
 }
+
+// rt_bvh_ploc.hip
+size_t rt_ploc_temp_bytes(uint32_t n);
 
 // rt_api.hip
 void rt_context_retain(rt_context *ctx);
