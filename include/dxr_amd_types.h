@@ -127,10 +127,10 @@ typedef struct rt_stats {
     uint64_t secondary_hits;
     float    ms_primary;         /* raygen + primary traversal            */
     float    ms_shade0;          /* first-hit shading / ray emission      */
-    float    ms_trace_secondary; /* secondary closest-hit traversal       */
-    float    ms_trace_shadow0;   /* shadow traversal for first hits       */
-    float    ms_shade1;          /* second-hit shading / ray emission     */
-    float    ms_trace_shadow1;   /* shadow traversal for second hits      */
+    float    ms_trace_secondary; /* closest-hit traversal of levels >= 1   */
+    float    ms_trace_shadow0;   /* 0: every shadow ray of a frame runs in one launch, timed below */
+    float    ms_shade1;          /* shading / ray emission of levels >= 1  */
+    float    ms_trace_shadow1;   /* shadow traversal, all levels           */
     float    ms_resolve;         /* final shade + accumulate              */
     float    ms_total;
     uint64_t frames;             /* frames the counts / times above cover  */

@@ -254,3 +254,17 @@ def test_tiles_and_sum_mode(oracle):
     for f in range(4):
         sc.render(mat, g["pfc"][f], 64, 64, accum=s, env_constant=(0.5, 0.5, 0.5), accum_mode=T.ACCUM_SUM)
     assert np.abs(s / 4 - g["images"][3]).max() < 1e-5
+
+
+def test_oracle_selftest_under_sanitizers():
+    """the whole oracle (OBJ, LBVH, brute force == BVH, progressive + realtime shading on two threads,
+    denoiser, host update) in one program under ASan + UBSan and under TSan."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    odir = os.path.join(root, "oracle")
+    subprocess.run(["make", "-C", odir, "selftest_asan", "selftest_tsan"], check=True, stdout=subprocess.DEVNULL, timeout=600)
+    obj = os.path.join(root, "tests", "golden", "cornell.obj")
+    for exe in ("selftest_asan", "selftest_tsan"):
+        r = subprocess.run([os.path.join(odir, exe), obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0 and "oracle selftest ok" in r.stdout, r.stdout[-3000:]
