@@ -49,3 +49,12 @@ def tile_rows(rank, world_size, height, band=64):
         if b % world_size == rank:
             out.append((y0, min(y0 + band, height)))
     return out
+
+
+def combine_tiles(image, group=None):
+    """Partitioning B, the only exchange: every rank rendered its own bands into an otherwise ZERO buffer
+    (rt_pipeline_render_tile leaves foreign pixels untouched), so a SUM all-reduce is a gather -- x + 0 == x
+    exactly -- and every rank ends up with the whole image, bit-identical to the single-GPU frame."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(image, op=dist.ReduceOp.SUM, group=group)
+    return image

@@ -135,3 +135,17 @@ def test_bench_two_ranks_on_one_gpu():
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     # weak scaling: two ranks trace twice the frames, i.e. about twice the rays per step
     assert abs(d["value"] * d["ms_per_step"] / (d1["value"] * d1["ms_per_step"]) - 2.0) < 0.05
+
+
+def test_tile_partition_two_ranks_on_one_gpu():
+    """BASELINE config 5's multi-GPU scheme end to end: interleaved row bands per rank, one all-reduce as the gather,
+    bit-identical to the whole frame (tests/scripts/tile_ranks.py; gloo + one device stand in for RCCL + 8 GPUs)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DXR_BENCH_BACKEND="gloo", DXR_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29873", os.path.join(root, "tests", "scripts", "tile_ranks.py")]
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "tiles ok: 2 ranks" in r.stdout, r.stdout[-3000:]
