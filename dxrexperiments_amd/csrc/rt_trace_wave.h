@@ -47,7 +47,7 @@ RT_DEV v4f ldg16(const void *base, size_t byte_off)
 #define RT_REFILL_LANES 16              // refill a wave once this many of its 64 lanes are idle
 #endif
 #ifndef RT_POOL_CHUNK
-#define RT_POOL_CHUNK 128u              // rays per chunk of the queue a wave takes at a time
+#define RT_POOL_CHUNK 64u               // rays per chunk of the queue a wave takes at a time (32: 3.55, 64: 3.44, 128: 3.47, 256: 3.57 ms/frame)
 #endif
 
 #ifndef RT_EXIT_K
@@ -200,7 +200,9 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
 #else
                 // static interleaving: wave w of W owns chunks w, w+W, w+2W, ... of the queue; no
-                // atomics (same-address returning atomics cost ~60 ns each here and serialise)
+                // atomics (same-address returning atomics cost ~60 ns each here and serialise: even
+                // handing out only the last 1/16 of a queue through a global counter, to even out the
+                // end of the launch, was measured +43 % on the frame)
                 const uint32_t base = next_chunk * CHUNK;
                 next_chunk += n_waves;
 #endif
