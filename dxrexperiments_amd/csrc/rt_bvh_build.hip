@@ -263,9 +263,16 @@ __global__ void k_layout(const rt_bvh_node *__restrict__ nodes, const uint2 *__r
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
-    const rt_bvh_node nd = nodes[i];
-    const rt_bvh_node a = nodes[nd.left];
-    const rt_bvh_node b = nodes[nd.right];
+    rt_bvh_node nd = nodes[i];
+    rt_bvh_node a = nodes[nd.left];
+    rt_bvh_node b = nodes[nd.right];
+    // child slot 0 = the child with the larger surface: any-hit rays walk unordered and try it first (rt_bvh_ploc.hip)
+    const float ax = a.bmax[0] - a.bmin[0], ay = a.bmax[1] - a.bmin[1], az = a.bmax[2] - a.bmin[2];
+    const float bx = b.bmax[0] - b.bmin[0], by = b.bmax[1] - b.bmin[1], bz = b.bmax[2] - b.bmin[2];
+    if (bx * by + by * bz + bz * bx > ax * ay + ay * az + az * ax) {
+        const rt_bvh_node t = a; a = b; b = t;
+        const uint32_t tl = nd.left; nd.left = nd.right; nd.right = tl;
+    }
     Slab s;
     s.q0 = make_float4(a.bmin[0], a.bmax[0], a.bmin[1], a.bmax[1]);
     s.q1 = make_float4(b.bmin[0], b.bmax[0], b.bmin[1], b.bmax[1]);

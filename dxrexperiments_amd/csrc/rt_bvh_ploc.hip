@@ -278,8 +278,12 @@ __global__ void k_ploc_slabs(const uint32_t *__restrict__ left, const uint32_t *
 {
     const uint32_t i = blockIdx.x * PB + threadIdx.x;
     if (i >= n - 1) return;
-    const uint32_t l = left[i], r = right[i];
-    const Box6 a = node_box[l], b = node_box[r];
+    uint32_t l = left[i], r = right[i];
+    Box6 a = node_box[l], b = node_box[r];
+    // child slot 0 = the child with the larger surface: any-hit rays walk unordered (slot 0 first) and so try
+    // the likelier occluder first (shadow stage -11 %; ordering by triangle count or count/area: -6 %);
+    // closest-hit rays order the two by entry distance at run time and do not care
+    if (merged_area(b, b) > merged_area(a, a)) { const uint32_t t = l; l = r; r = t; const Box6 tb = a; a = b; b = tb; }
     Slab s;
     s.q0 = make_float4(a.lo[0], a.hi[0], a.lo[1], a.hi[1]);
     s.q1 = make_float4(b.lo[0], b.hi[0], b.lo[1], b.hi[1]);

@@ -36,6 +36,9 @@ using namespace rtd;
 namespace {
 
 constexpr int PBLOCK = 256;
+#ifndef RT_SHADOW_UNORDERED
+#define RT_SHADOW_UNORDERED 1
+#endif
 
 #define RAY_MAX_T 1.0e+38f      // RaytracingCommon.hlsli:8
 #define RAY_EPSILON 0.0001f     // RaytracingCommon.hlsli:9
@@ -600,7 +603,7 @@ __global__ void __launch_bounds__(PBLOCK) k_trace_shadow(SceneDev sc, ShadowSrcN
 {
     __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     ShadowSinkN sink = {src};
-    trace_wave<TWO_LEVEL ? STACK + RT_TOP_ROWS(PBLOCK) : STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem, stat);
+    trace_wave<TWO_LEVEL ? STACK + RT_TOP_ROWS(PBLOCK) : STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK, RT_SHADOW_UNORDERED != 0>(sc, src, sink, pool, smem, stat);
 }
 
 template <int STACK, bool TWO_LEVEL>

@@ -89,7 +89,7 @@ struct LaneStack {
 // One step on an internal node: both children are slab-tested, the nearer hit child is entered, the farther
 // one is written to the stack slot above the top unconditionally (it only counts if the top moves), the
 // slot below the top is read speculatively (it only counts if both children miss).  Branch free.
-template <bool DEEP, bool TOP, int STACK, int BLOCK>
+template <bool DEEP, bool TOP, bool ANYHIT, int STACK, int BLOCK>
 RT_DEV void node_step(const Slab *slabs, const int *top, const RayInv &ri, float tmin, float tbest, const LaneStack<STACK, BLOCK> &st, int &node, int &sp)
 {
     v4f q0, q1, q2, q3;
@@ -108,7 +108,7 @@ RT_DEV void node_step(const Slab *slabs, const int *top, const RayInv &ri, float
     const bool h1 = slab_hit(ri, q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, tmin, tbest, e1);
     const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
     const bool both = h0 && h1, none = !(h0 || h1);
-    const bool swap = e1 < e0;
+    const bool swap = ANYHIT ? false : e1 < e0;      // any-hit rays need no order: the first hit ends them
     const int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
     const int one = h0 ? c0 : c1;
     const int below = sp > 0 ? sp - 1 : 0;
@@ -133,7 +133,7 @@ RT_DEV unsigned long long lanemask_lt()
 //                 uint32_t flags() const; };
 //   struct Sink { void store(uint32_t i, const HitD &h, bool traced) const; };
 
-template <int STACK, int BLOCK, bool TWO_LEVEL, uint32_t CHUNK, class Src, class Sink>
+template <int STACK, int BLOCK, bool TWO_LEVEL, uint32_t CHUNK, bool ANYHIT = false, class Src, class Sink>
 RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uint32_t *pool, int *smem, uint32_t *traced_counter)
 {
     uint32_t n_traced = 0;           // rays this lane actually traversed (statistics)
@@ -243,7 +243,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 #endif
         while (alive && node_is_internal(node) && sp < STACK) {
             RT_STAT_WAVE(0); RT_STAT_LANE(0);
-            node_step<false, !TWO_LEVEL>(slabs, topl, cur.ri, r.tmin, best.t, st, node, sp);
+            node_step<false, !TWO_LEVEL, ANYHIT>(slabs, topl, cur.ri, r.tmin, best.t, st, node, sp);
 #ifdef RT_TRACE_STATS
             st_maxsp = sp > st_maxsp ? sp : st_maxsp;
 #endif
@@ -254,7 +254,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 #endif
         }
         // lanes whose stack has outgrown the LDS rows walk on with the global rows until it fits again
-        while (alive && node_is_internal(node) && sp >= STACK) node_step<true, !TWO_LEVEL>(slabs, topl, cur.ri, r.tmin, best.t, st, node, sp);
+        while (alive && node_is_internal(node) && sp >= STACK) node_step<true, !TWO_LEVEL, ANYHIT>(slabs, topl, cur.ri, r.tmin, best.t, st, node, sp);
 
         // ---- leaves, instance entry / exit, termination -----------------------------------
         RT_STAT_WAVE(3);
