@@ -54,9 +54,7 @@ constexpr int PBLOCK = 256;
 constexpr int MAXD = 4;
 enum { C_NHIT = 0,                       // [0..MAXD] compacted hits per level
        C_SECONDARY = MAXD + 1, C_SHADOW = MAXD + 2,
-       C_POOL_PRIMARY = MAXD + 3, C_POOL_SHADOW = MAXD + 4,
-       C_POOL_LEVEL = MAXD + 5,          // [1..MAXD] ray pools of the secondary levels
-       C_COUNT = 2 * MAXD + 6 };
+       C_COUNT = MAXD + 3 };
 
 // Level L: the rays at radiance depth L (L >= 1; primary rays are generated, not stored), their hit
 // records, the compaction of the hits, and the shadow-ray queue of those hits.
@@ -88,8 +86,12 @@ struct PipeDev {
     float4 *accum;
     float4 *aov_direct, *aov_indirect;  // realtime pipeline outputs (RealtimeRaytracing.hlsl:3-4)
     uint32_t *counters;
+    uint32_t *pools;            // chunk counters of the persistent launches: [1 + MAXD][RT_POOL_GROUPS], 128 B apart
     LevelDev lv[MAXD + 1];
 };
+
+constexpr size_t POOL_BYTES = (size_t)(1 + MAXD) * RT_POOL_GROUPS * RT_POOL_STRIDE * 4;      // shadow launch, levels 1..MAXD
+constexpr size_t POOL_OFFSET_WORDS = 64;      // the pools start on a 256-B boundary after the scalar counters
 
 RT_DEV uint32_t hcap(const PipeDev &pd, int L) { return L == 0 ? pd.cap : 2u * pd.cap; }
 
@@ -473,7 +475,7 @@ __global__ void __launch_bounds__(PBLOCK) k_primary(PipeDev pd)
     __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     PrimarySrc src = {pd};
     PrimarySink sink = {pd};
-    trace_wave<TWO_LEVEL ? STACK + RT_TOP_ROWS(PBLOCK) : STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, &pd.counters[C_POOL_PRIMARY], smem, nullptr);   // one 8x8 tile per wave
+    trace_wave<TWO_LEVEL ? STACK + RT_TOP_ROWS(PBLOCK) : STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, nullptr, smem, nullptr);   // one 8x8 tile per wave, dealt by the hardware dispatcher
 }
 
 // Compaction of the hits of level L (they get shaded): ballot + popcount prefix sums, one atomic per block.
@@ -782,7 +784,7 @@ int ensure_queues(rt_pipeline *p, uint32_t cap, uint32_t sh0_batches, uint32_t l
     const size_t c = cap > p->cap ? cap : p->cap;
     const size_t sb = sh0_batches > p->sh0_batches ? sh0_batches : p->sh0_batches;
     const uint32_t nl = levels > p->levels ? levels : p->levels;
-    RT_TRY(p->counters.reserve(C_COUNT * 4));
+    RT_TRY(p->counters.reserve(POOL_OFFSET_WORDS * 4 + POOL_BYTES));
     for (uint32_t l = 0; l <= nl; l++) {
         rt_pipeline::LevelBuf &b = p->lv[l];
         const size_t slots = l == 0 ? c : 2 * c, shadow = l == 0 ? sb * c : 4 * c;
@@ -828,7 +830,7 @@ void launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
         // level 1: the diffuse and the specular batch of the primary hits; deeper: one ray per hit of level l-1
         const QueueSrc rays = {pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE};   // ProgressiveRaytracing.hlsl:53
         k_trace_secondary<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_secondary<STACK, TWO_LEVEL>, PBLOCK, (size_t)cap * 2), PBLOCK, 0, st>>>(
-            pd.sc, rays, pd.lv[l].hit, pd.lv[l].inst, &pd.counters[C_POOL_LEVEL + l - 1], &pd.counters[C_SECONDARY]);
+            pd.sc, rays, pd.lv[l].hit, pd.lv[l].inst, pd.pools + (size_t)l * RT_POOL_GROUPS * RT_POOL_STRIDE, &pd.counters[C_SECONDARY]);
         k_compact_level<<<(2 * cap + CBLOCK - 1) / CBLOCK, CBLOCK, 0, st>>>(pd, (int)l);
         if (T) (void)hipEventRecord(ev[3 + 2 * (l - 1)], st);
         const bool casts_shadows = l < pd.max_shadow, spawns = l < levels;
@@ -842,7 +844,7 @@ void launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
         }
     }
     k_trace_shadow<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL>, PBLOCK, shadow_max), PBLOCK, 0, st>>>(
-        pd.sc, shadows, &pd.counters[C_POOL_SHADOW], &pd.counters[C_SHADOW]);
+        pd.sc, shadows, pd.pools, &pd.counters[C_SHADOW]);
     if (T) (void)hipEventRecord(ev[EV_SHADOW], st);
     if (levels <= 1) k_resolve<1><<<blocks(cap), PBLOCK, 0, st>>>(pd);
     else k_resolve<MAXD><<<blocks(cap), PBLOCK, 0, st>>>(pd);
@@ -1084,7 +1086,9 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
         d.slot_j = b.slot_j.as<uint32_t>(); d.jlist = b.jlist.as<uint32_t>(); d.pix = b.pix.as<uint32_t>();
         d.shO = b.shO.as<float4>(); d.shD = b.shD.as<float4>(); d.vis = b.vis.as<uint32_t>();
     }
-    HIP_TRY(hipMemsetAsync(pd.counters, 0, C_COUNT * 4, st));
+    static_assert(C_COUNT <= POOL_OFFSET_WORDS, "scalar counters overlap the chunk pools");
+    pd.pools = pd.counters + POOL_OFFSET_WORDS;
+    HIP_TRY(hipMemsetAsync(pd.counters, 0, POOL_OFFSET_WORDS * 4 + POOL_BYTES, st));
     // 24 LDS stack rows = 24 KiB per 256-thread block = 6 resident blocks per CU, whatever the depth of the
     // tree; the rare deeper walk continues in global rows (rt_trace_wave.h)
     if (ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST) launch_frame_any<RT_LDS_STACK_ROWS_TEST>(p, pd, shadow_slots);

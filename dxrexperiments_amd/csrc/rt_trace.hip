@@ -82,8 +82,8 @@ int rt_launch_trace(rt_context *ctx, const rt_scene *s, const float4 *o, const f
         k_trace_canonical<<<grid, TRACE_BLOCK, 0, st>>>(sc, o, d, n, ray_flags, out);
     } else {
         if (n > 0xFFFFFF00ull) { rt_set_error("rt_trace_batch: more than 2^32 rays in one batch"); return RT_ERR_INVALID_ARG; }
-        RT_TRY(ctx->pool.reserve(64));
-        HIP_TRY(hipMemsetAsync(ctx->pool.p, 0, 64, st));
+        RT_TRY(ctx->pool.reserve(RT_POOL_GROUPS * RT_POOL_STRIDE * 4));
+        HIP_TRY(hipMemsetAsync(ctx->pool.p, 0, RT_POOL_GROUPS * RT_POOL_STRIDE * 4, st));
         BatchSrc src = {o, d, (uint32_t)n, ray_flags};
         BatchSink sink = {out};
         HIP_TRY(hipEventRecord(ctx->ev0, st));

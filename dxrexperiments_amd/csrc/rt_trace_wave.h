@@ -50,6 +50,10 @@ RT_DEV v4f ldg16(const void *base, size_t byte_off)
 #define RT_POOL_CHUNK 64u               // rays per chunk of the queue a wave takes at a time (32: 3.55, 64: 3.44, 128: 3.47, 256: 3.57 ms/frame)
 #endif
 
+#ifndef RT_POOL_GROUPS
+#define RT_POOL_GROUPS 32u              // chunk counters per traversal launch (8: 3.08, 32: 3.07, 128: 3.09, 512: 3.12 ms; static: 3.21)
+#endif
+#define RT_POOL_STRIDE 32u              // words between two counters: one 128-B L2 line each
 #ifndef RT_EXIT_K
 #define RT_EXIT_K 2                     // leave the node loop once (lanes still on internal nodes) * K < lanes waiting on a leaf
 #endif
@@ -169,6 +173,8 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the chunk of the queue being handed out
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
     uint32_t next_chunk = blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;   // wave-uniform
+    const uint32_t n_groups = gridDim.x < RT_POOL_GROUPS ? gridDim.x : RT_POOL_GROUPS;
+    const uint32_t pool_group = blockIdx.x % n_groups;
     uint32_t idx = 0;
     RayD r;
     RayInv wri;
@@ -194,18 +200,25 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
         const int n_idle = __popcll(idle);
         if (!exhausted && n_idle >= RT_REFILL_LANES) {
             if (chunk_next >= chunk_end) {
-#ifdef RT_POOL_ATOMIC
-                uint32_t base = 0;
-                if ((threadIdx.x & 63u) == 0u) base = atomicAdd(pool, CHUNK);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-#else
-                // static interleaving: wave w of W owns chunks w, w+W, w+2W, ... of the queue; no
-                // atomics (same-address returning atomics cost ~60 ns each here and serialise: even
-                // handing out only the last 1/16 of a queue through a global counter, to even out the
-                // end of the launch, was measured +43 % on the frame)
-                const uint32_t base = next_chunk * CHUNK;
-                next_chunk += n_waves;
-#endif
+                // Which chunk next?  Per-ray cost varies, so a static share per wave leaves the launch waiting
+                // for its unluckiest waves.  ONE global counter is no answer: same-address returning atomics
+                // cost ~60 ns each here and serialise (a single-counter pool was 3x slower; even handing out
+                // only the last 1/16 of a queue that way cost +43 %).  So the queue is dealt to RT_POOL_GROUPS
+                // groups of workgroups (group g owns chunks g, g+G, g+2G, ...) and the waves of a group
+                // share one counter: 1/G of the contention, balancing across the group's ~190 waves (-4 % on
+                // the frame).  Workgroups are dealt to the XCDs round-robin and G is a multiple of 8, so a
+                // group and its counter stay on one XCD.
+                uint32_t cidx;
+                if (pool) {
+                    uint32_t k = 0;
+                    if ((threadIdx.x & 63u) == 0u) k = atomicAdd(&pool[pool_group * RT_POOL_STRIDE], 1u);
+                    k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+                    cidx = pool_group + k * n_groups;
+                } else {
+                    cidx = next_chunk;           // static: wave w of W owns chunks w, w+W, w+2W, ...
+                    next_chunk += n_waves;
+                }
+                const uint32_t base = cidx < 0x4000000u ? cidx * CHUNK : total;
                 chunk_next = base;
                 chunk_end = base + CHUNK < total ? base + CHUNK : total;
                 if (base >= total) { exhausted = true; chunk_end = chunk_next; }
