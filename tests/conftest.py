@@ -23,7 +23,12 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def capi():
+    """The ctypes binding of the product library.  If the in-tree .so has not been built yet (fresh checkout:
+    `make` / `__graft_entry__.build()` not run), build it here -- hipcc cross-compiles gfx950 without a GPU."""
     from dxrexperiments_amd import capi
+    if not os.environ.get("DXR_AMD_LIB") and not os.path.exists(os.path.join(ROOT, "dxrexperiments_amd", "lib", "libdxrexperiments_amd.so")):
+        import subprocess
+        subprocess.run(["make", "-C", ROOT, "-j4"], check=True, stdout=subprocess.DEVNULL)
     capi.lib()
     return capi
 
