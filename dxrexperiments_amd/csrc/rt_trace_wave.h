@@ -3,23 +3,27 @@
 //
 // Design (MI355X-first; nothing here comes from the Fallback Layer, whose source is
 // not in the reference checkout):
-//   * one ray per lane, 4 waves per workgroup, as many workgroups as stay resident;
-//     each wave keeps pulling rays from a global pool: when at least REFILL lanes
-//     of the wave are idle (their ray finished) one lane does ONE atomicAdd for the
-//     whole wave (ballot + popcount prefix sum hands out the indices) and the idle
-//     lanes load the next rays -- on wave64 incoherent rays otherwise leave most of
-//     a wave's 64 lanes parked while the longest ray finishes;
-//   * "while-while" order: all lanes walk internal nodes until every live lane
-//     stands on a leaf, then all leaves are processed together, so the (short)
-//     triangle code is not serialised against the (long) node code;
+//   * one ray per lane, 4 waves per workgroup, as many workgroups as stay resident
+//     (persistent).  A wave takes 64-ray chunks of its queue -- through one of 32
+//     counters per launch, shared by a group of workgroups on one XCD -- and refills
+//     its idle lanes from the chunk once REFILL of them are idle (ballot + popcount
+//     prefix sum hands out the indices): on wave64, incoherent rays otherwise leave
+//     most of a wave's 64 lanes parked while the longest ray finishes;
+//   * "while-while" order with a straggler exit: lanes walk internal nodes until they
+//     stand on a leaf; once those still walking are fewer than half of those waiting,
+//     the wave turns to the leaves, so the (short) triangle code is not serialised
+//     against the (long) node code and neither waits for the slowest lane;
 //   * internal nodes are 64-B slabs holding BOTH child boxes: four 16-B loads from
-//     one half cache line through explicitly global (address-space 1) pointers;
+//     one half cache line through explicitly global (address-space 1) pointers; the
+//     first 192 nodes of a single-level tree (breadth-first) are read from LDS;
 //   * the step is branch free: both children are slab-tested, the nearer hit child
-//     is entered, the farther one is written to the stack slot above the top
-//     unconditionally (it only counts if the top moves), the slot below the top is
-//     read speculatively (it only counts if both children miss);
-//   * the stack is LDS resident, stack[level][lane-in-block]: one dword per lane per
-//     level, bank = lane mod 32, conflict free for both halves of a wave.
+//     is entered (any-hit rays: slot 0, where the builders put the larger child), the
+//     other one is written to the stack slot above the top unconditionally (it only
+//     counts if the top moves), the slot below the top is read speculatively (it only
+//     counts if both children miss);
+//   * the stack is LDS resident, stack[row][lane-in-block]: one dword per lane per
+//     row, bank = lane mod 32, conflict free for both halves of a wave; a fixed
+//     number of rows whatever the tree, the rare deeper walk continues in global rows.
 //
 // Exactness: culling uses the same monotone slab test as the oracle and candidates
 // are validated exactly as the canonical definition prescribes (rt_trace_device.h),

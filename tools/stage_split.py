@@ -1,4 +1,10 @@
-import sys; sys.path.insert(0, '.')
+#!/usr/bin/env python3
+"""Where the level-1 stage spends its time (run on the GPU box): the bench scene rendered with both secondary
+batches, with the specular batch only (noIndirectDiffuse) and with the diffuse batch only (material type 0)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
 from dxrexperiments_amd import capi, rtypes as T, scenes
 W, H = 1920, 1080
