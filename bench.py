@@ -82,9 +82,21 @@ def cpu_baseline(verts, tris, mat, env, pfc, W, H, budget_s):
         if done:
             break
     dt = time.perf_counter() - t0
+    # the same scalar code on ONE thread (SURVEY 8(d) asks for both): a few bands, ~2 s
+    t1 = time.perf_counter()
+    rays1 = bands1 = 0
+    for b in np.random.default_rng(99).permutation(H // band):
+        _, st = sc.render(mat, pfc, W, H, accum=acc, env_faces=env, tile=(0, int(b) * band, W, int(b + 1) * band), nthreads=1)
+        rays1 += st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]
+        bands1 += 1
+        if time.perf_counter() - t1 >= min(2.0, budget_s / 4):
+            break
+    dt1 = time.perf_counter() - t1
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": "%d random %d-row bands of the same 1920x1080 frame (%d rays, all ray types) in %.1f s; BVH build %.2f s"
-                      % (bands, band, rays, dt, build_s)}
+                      % (bands, band, rays, dt, build_s),
+            "single_thread": {"value": rays1 / dt1 / 1e6, "unit": "Mrays/s", "cores": 1,
+                              "sample": "%d bands (%d rays) in %.1f s" % (bands1, rays1, dt1)}}
 
 
 def measured_traffic(kernel):
