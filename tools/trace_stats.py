@@ -2,7 +2,7 @@
 """SIMD utilisation of the traversal engine on the bench workload (instrumentation build only).
 
   tools/build_variant.sh stats -DRT_TRACE_STATS [other -D flags]
-  DXR_AMD_LIB=$PWD/dxrexperiments_amd/lib/variants/libstats.so python tools/trace_stats.py
+  DXR_AMD_LIB=$PWD/dxrexperiments_amd/lib/variants/libstats.so python tools/trace_stats.py [instances]
 
 Prints, per stage (primary / secondary / shadow): wave-level node steps, the fraction of the 64 lanes
 doing useful work in them, leaf phases and triangle iterations likewise."""
@@ -18,17 +18,25 @@ from dxrexperiments_amd import capi, rtypes as T, scenes
 def main():
     W, H = 1920, 1080
     ctx = capi.Context(0)
-    verts, tris = scenes.sponza_class(seed=42)
     scene = capi.Scene(ctx)
-    scene.add_model(capi.Model(ctx, verts, tris))
     pipe = capi.Pipeline(ctx)
+    if len(sys.argv) > 1 and sys.argv[1] == "instances":        # BASELINE config 4's scene: 4096 instances, two-level walks
+        model = capi.Model(ctx, *scenes.blob_mesh(level=3))
+        xf = scenes.instance_grid(64)
+        for k in range(xf.shape[0]):
+            scene.add_model(model, xf[k])
+            pipe.add_material(T.default_material())
+        c = dict(eye=(0.0, 30.0, 110.0), at=(0.0, 0.0, 0.0), up=(0, 1, 0), fov=0.9)
+    else:
+        verts, tris = scenes.sponza_class(seed=42)
+        scene.add_model(capi.Model(ctx, verts, tris))
+        pipe.add_material(T.default_material())
+        c = scenes.sponza_camera()
     pipe.set_scene(scene)
-    pipe.add_material(T.default_material())
     pipe.set_environment_cube(scenes.sky_cubemap(64))
     pipe.create_output(W, H)
     pipe.build_acceleration_structures()
     host = capi.ProgressiveHost(1234)
-    c = scenes.sponza_camera()
     cam = capi.camera_array(c["eye"], c["at"], c["up"], c["fov"], W / H)
     lib = capi.lib()
     fn = lib.rt_debug_trace_stats
