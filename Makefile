@@ -17,7 +17,7 @@ SRCS = $(CSRC)/rt_api.hip $(CSRC)/rt_bvh_build.hip $(CSRC)/rt_bvh_ploc.hip $(CSR
 HDRS = $(wildcard $(CSRC)/*.h) include/dxr_amd.h include/dxr_amd_types.h
 OBJS = $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
 
-BIN = $(LIBDIR)/progressive $(LIBDIR)/test_wrapper
+BIN = $(LIBDIR)/progressive $(LIBDIR)/realtime_denoise $(LIBDIR)/test_wrapper
 CXX ?= g++
 HOSTFLAGS = -O2 -std=c++17 -Wall -Iinclude -Idxrexperiments_amd/include
 HOSTLINK = -L$(LIBDIR) -ldxrexperiments_amd -L/opt/rocm/lib -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib
@@ -26,6 +26,9 @@ all: $(LIB) $(BIN)
 
 # host programs written against the reference-shaped C++ API (no HIP needed to compile them)
 $(LIBDIR)/progressive: examples/progressive.cpp $(LIB) $(wildcard dxrexperiments_amd/include/*.h)
+	$(CXX) $(HOSTFLAGS) $< -o $@ $(HOSTLINK)
+
+$(LIBDIR)/realtime_denoise: examples/realtime_denoise.cpp $(LIB) $(wildcard dxrexperiments_amd/include/*.h)
 	$(CXX) $(HOSTFLAGS) $< -o $@ $(HOSTLINK)
 
 $(LIBDIR)/test_wrapper: tests/cpp/test_wrapper.cpp $(LIB) $(wildcard dxrexperiments_amd/include/*.h)
