@@ -206,6 +206,12 @@ own = torch.zeros(64, dtype=torch.int32)
 for y0, y1 in rows: own[y0:y1] += 1
 dist.all_reduce(own)
 assert bool((own == 1).all())             # tile partition covers every row exactly once
+# partitioning B end to end: every rank renders only its bands into a zero buffer, combine_tiles gathers them
+tiled = np.zeros((64, 64, 4), np.float32)
+for y0, y1 in rows:
+    sc.render(T.default_material(), g["pfc"][0], 64, 64, accum=tiled, env_constant=(0.5, 0.5, 0.5), tile=(0, y0, 64, y1))
+whole = D.combine_tiles(torch.from_numpy(tiled)).numpy()
+assert np.array_equal(whole, g["images"][0]), "tiled frame differs from the golden frame"
 dist.barrier(); dist.destroy_process_group()
 open(os.path.join(sys.argv[2], "ok_%d" % rank), "w").write("%s %g" % (mine, rms))
 '''
