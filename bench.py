@@ -65,7 +65,10 @@ def cpu_baseline(verts, tris, mat, env, pfc, W, H, budget_s):
     t0 = time.perf_counter()
     sc.build()
     build_s = time.perf_counter() - t0
+    # the oracle splits a tile by rows, statically: a band needs a few rows per thread or most threads idle
     band = 8
+    while band < 4 * cores and band * 2 <= H // 2:
+        band *= 2
     acc = np.zeros((H, W, 4), np.float32)
     rays = 0
     bands = 0
