@@ -16,6 +16,8 @@ Fixtures are DATA (inputs and expected outputs), never reference source:
                          image after each of 4 frames.
   host_update_golden.npz the 188-byte constant buffers the host update logic produces
                          for a fixed camera / seed (6 frames incl. a camera move).
+  cornell64_structures.npz  the canonical LBVH of the Cornell mesh (nodes, keys, parents, depth),
+                         the two realtime AOVs of one 64x64 frame and their denoised composite.
 """
 import json
 import os
@@ -117,6 +119,22 @@ def main():
         seq.append(host.update(cm, 0.5 * i, 10 + i, 1920, 1080).copy())
     np.savez_compressed(os.path.join(HERE, "host_update_golden.npz"), cams=np.stack([camA, camA, camA, camB, camB, camA]),
                         pfc=np.stack(seq), seed=99)
+    # --- Cornell BVH arrays, realtime AOVs, denoised image (the GPU box checks these without the oracle) -----
+    nodes, keys, parents, depth = sc.bvh(0)
+    # RealtimeRaytracingPipeline::update = the progressive update with accumCount 0 and options {environmentStrength 1}
+    rpfc = np.frombuffer(bytearray(O.Progressive(77).update(cam, 0.0, 1, W, H).tobytes()), T.PER_FRAME_CONSTANTS).copy()
+    rpfc["cameraParams"]["accumCount"] = 0
+    opt = np.zeros((), T.DEBUG_OPTIONS)
+    opt["environmentStrength"] = 1.0
+    rpfc["options"] = opt
+    direct, indirect, rst = sc.render_realtime(mat, rpfc, W, H, env_constant=(0.5, 0.5, 0.5))
+    dparams = np.zeros((), O.DENOISE_PARAMS)
+    dparams["exposure"], dparams["gamma"], dparams["tonemap"], dparams["gammaCorrect"], dparams["maxKernelSize"] = 1.0, 2.2, 1, 1, 12
+    _, denoised = O.denoise(direct, indirect, dparams)
+    np.savez_compressed(os.path.join(HERE, "cornell64_structures.npz"),
+                        bvh_nodes=np.frombuffer(np.ascontiguousarray(nodes).tobytes(), np.uint8), bvh_keys=keys, bvh_parents=parents, bvh_depth=depth,
+                        realtime_pfc=rpfc, direct=direct, indirect=indirect, denoise_params=np.frombuffer(dparams.tobytes(), np.uint8),
+                        denoised=denoised)
     print("fixtures written to", HERE)
 
 

@@ -166,3 +166,33 @@ def test_realtime_then_denoise_1080p(gpu, capi):
     st = p.stats()
     assert st["rays_secondary"] <= st["primary_hits"] and st["rays_shadow"] == 2 * st["primary_hits"] + 2 * st["secondary_hits"]
     print("realtime frame %.3f ms, denoise %.3f ms" % (st["ms_total"], dn.last_ms()))
+
+
+def test_structures_fixture_without_the_oracle(gpu, capi):
+    """The committed fixture (tests/golden/cornell64_structures.npz) against the library alone: canonical LBVH arrays
+    index-exact, both realtime AOVs and the denoised composite bit-exact."""
+    import os
+    from util import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "cornell64_structures.npz"))
+    sc = capi.Scene(gpu)
+    sc.add_model(capi.Model(gpu, path=CORNELL_OBJ))
+    p = capi.Pipeline(gpu, capi.PIPELINE_REALTIME)
+    p.set_scene(sc)
+    p.add_material(T.default_material())
+    p.set_environment_constant((0.5, 0.5, 0.5))
+    p.create_output(64, 64)
+    p.build_acceleration_structures()
+    nodes, keys, parents, depth = sc.bvh(0)
+    assert np.ascontiguousarray(nodes).tobytes() == g["bvh_nodes"].tobytes()
+    assert np.array_equal(keys, g["bvh_keys"]) and np.array_equal(parents, g["bvh_parents"]) and depth == int(g["bvh_depth"])
+    p.update(g["realtime_pfc"])
+    p.render()
+    assert np.array_equal(p.read_output(0), g["direct"]) and np.array_equal(p.read_output(1), g["indirect"])
+    dn = capi.Denoiser(gpu)
+    prm = dn.params
+    want = np.frombuffer(g["denoise_params"].tobytes(), prm.dtype)[0]
+    for name in prm.dtype.names:
+        prm[name] = want[name]
+    dn.create_output(64, 64)
+    dn.dispatch(p.output_device_ptr(0), p.output_device_ptr(1))
+    assert np.array_equal(dn.read_output(), g["denoised"])

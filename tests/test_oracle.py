@@ -268,3 +268,20 @@ def test_oracle_selftest_under_sanitizers():
     for exe in ("selftest_asan", "selftest_tsan"):
         r = subprocess.run([os.path.join(odir, exe), obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert r.returncode == 0 and "oracle selftest ok" in r.stdout, r.stdout[-3000:]
+
+
+def test_structures_fixture_reproduced(oracle):
+    """cornell64_structures.npz: canonical LBVH arrays, realtime AOVs and the denoised composite."""
+    g = np.load(os.path.join(GOLDEN, "cornell64_structures.npz"))
+    v, i = oracle.obj_load(CORNELL_OBJ)
+    sc = oracle.Scene()
+    sc.add_instance(sc.add_model(v, i))
+    sc.build()
+    nodes, keys, parents, depth = sc.bvh(0)
+    assert np.ascontiguousarray(nodes).tobytes() == g["bvh_nodes"].tobytes()
+    assert np.array_equal(keys, g["bvh_keys"]) and np.array_equal(parents, g["bvh_parents"]) and depth == int(g["bvh_depth"])
+    d, ind, _ = sc.render_realtime(T.default_material(), g["realtime_pfc"], 64, 64, env_constant=(0.5, 0.5, 0.5))
+    assert np.array_equal(d, g["direct"]) and np.array_equal(ind, g["indirect"])
+    prm = np.frombuffer(g["denoise_params"].tobytes(), oracle.DENOISE_PARAMS)[0]
+    _, out = oracle.denoise(g["direct"], g["indirect"], prm)
+    assert np.array_equal(out, g["denoised"])
