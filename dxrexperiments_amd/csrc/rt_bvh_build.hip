@@ -556,6 +556,16 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
         k_decode_bounds<<<1, 64, 0, st>>>(enc.as<uint32_t>(), bounds.as<float>());
         if ((rc = lbvh_from_boxes(ctx, s->tlas, boxes.as<Box6>(), n, bounds.as<float>(), true, tkeys, tsort, tenc, tdepth)) != RT_OK) break;
         s->tlas.root_code = (n == 1) ? ~(int)0 : 0;     // single instance: root is the leaf of instance 0
+        if ((rc = s->tlas.top.reserve(sizeof(Slab) * RT_TOP_NODES + sizeof(uint32_t))) != RT_OK) break;
+        {
+            uint32_t *d_n = (uint32_t *)(s->tlas.top.as<Slab>() + RT_TOP_NODES);
+            k_top_table<<<1, 64, 0, st>>>(s->tlas.slabs.as<Slab>(), s->tlas.root_code, s->tlas.top.as<Slab>(), d_n);
+            if (hipMemcpyAsync(&s->tlas.top_n, d_n, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                rt_set_error("TLAS top table build failed: %s", hipGetErrorString(hipGetLastError()));
+                rc = RT_ERR_HIP;
+                break;
+            }
+        }
         // one pending entry per internal node on the current path; two-level walks add the
         // TLAS path and the sentinel that marks the bottom of a BLAS walk
         s->two_level = !(n == 1 && (s->h_inst[0].flags & RT_INST_IDENTITY));

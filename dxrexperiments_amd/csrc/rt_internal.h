@@ -240,10 +240,10 @@ static inline unsigned rt_persistent_grid(const rt_context *ctx, K kernel, int b
 static inline int rt_scene_dev_for_launch(rt_context *ctx, const rt_scene *s, uint32_t lds_rows, size_t threads, SceneDev *out)
 {
     *out = s->dev();
-    if (!s->two_level && ctx->lds_top) {          // one identity instance: rays walk its BLAS directly
-        const rt_model *m = s->inst[0].model;
-        out->top = m->blas.top.as<Slab>();
-        out->top_n = m->blas.top_n;
+    if (ctx->lds_top) {          // one identity instance: rays walk its BLAS directly; otherwise the top of the TLAS
+        const BvhDev &bv = s->two_level ? s->tlas : s->inst[0].model->blas;
+        out->top = bv.top.as<Slab>();
+        out->top_n = bv.top_n;
     }
     const uint32_t bound = s->stack_need + 2;
     if (bound <= lds_rows) return RT_OK;
@@ -254,7 +254,8 @@ static inline int rt_scene_dev_for_launch(rt_context *ctx, const rt_scene *s, ui
 static inline uint32_t rt_lds_stack_rows(const rt_context *ctx, bool two_level)
 {
     const uint32_t rows = ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST ? RT_LDS_STACK_ROWS_TEST : RT_LDS_STACK_ROWS;
-    return two_level ? rows + RT_TOP_ROWS(256) : rows;
+    (void)two_level;
+    return rows;
 }
 
 // rt_bvh_ploc.hip

@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(PBLOCK) k_primary(PipeDev pd)
     __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     PrimarySrc src = {pd};
     PrimarySink sink = {pd};
-    trace_wave<TWO_LEVEL ? STACK + RT_TOP_ROWS(PBLOCK) : STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, nullptr, smem, nullptr);   // one 8x8 tile per wave, dealt by the hardware dispatcher
+    trace_wave<STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, nullptr, smem, nullptr);   // one 8x8 tile per wave, dealt by the hardware dispatcher
 }
 
 // Compaction of the hits of level L (they get shaded): ballot + popcount prefix sums, one atomic per block.
@@ -605,7 +605,7 @@ __global__ void __launch_bounds__(PBLOCK) k_trace_shadow(SceneDev sc, ShadowSrcN
 {
     __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     ShadowSinkN sink = {src};
-    trace_wave<TWO_LEVEL ? STACK + RT_TOP_ROWS(PBLOCK) : STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK, RT_SHADOW_UNORDERED != 0>(sc, src, sink, pool, smem, stat);
+    trace_wave<STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK, RT_SHADOW_UNORDERED != 0>(sc, src, sink, pool, smem, stat);
 }
 
 template <int STACK, bool TWO_LEVEL>
@@ -613,7 +613,7 @@ __global__ void __launch_bounds__(PBLOCK) k_trace_secondary(SceneDev sc, QueueSr
 {
     __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     SecondarySink sink = {src, hit1, inst1};
-    trace_wave<TWO_LEVEL ? STACK + RT_TOP_ROWS(PBLOCK) : STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem, stat);
+    trace_wave<STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem, stat);
 }
 
 template <int MAXL>

@@ -56,7 +56,7 @@ template <int STACK, bool TWO_LEVEL>
 __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(SceneDev sc, BatchSrc src, BatchSink sink, uint32_t *pool)
 {
     __shared__ int smem[(STACK + RT_TOP_ROWS(TRACE_BLOCK)) * TRACE_BLOCK];
-    trace_wave<TWO_LEVEL ? STACK + RT_TOP_ROWS(TRACE_BLOCK) : STACK, TRACE_BLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem, nullptr);
+    trace_wave<STACK, TRACE_BLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem, nullptr);
 }
 
 template <int STACK>

@@ -164,13 +164,13 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
     const TriRec *tris0 = TWO_LEVEL ? nullptr : in0->tris;
     // the LDS-resident top of the tree (single-level walks): smem rows STACK .. STACK + RT_TOP_ROWS - 1
     int *topl = smem + STACK * BLOCK;
-    const bool have_top = !TWO_LEVEL && sc.top_n != 0;
+    const bool have_top = sc.top_n != 0;          // single-level: top of the BLAS; two-level: top of the TLAS
     if (have_top) {
         const int *src_top = (const int *)sc.top;
         for (uint32_t i = threadIdx.x; i < sc.top_n * 16u; i += BLOCK) topl[i] = src_top[i];
         __syncthreads();
     }
-    const int root0 = TWO_LEVEL ? sc.tlas_root_code : (have_top ? RT_NODE_TOP : in0->root_code);
+    const int root0 = have_top ? RT_NODE_TOP : (TWO_LEVEL ? sc.tlas_root_code : in0->root_code);
 
     bool alive = false;
     bool exhausted = false;          // wave-uniform: the global pool has nothing left
@@ -260,7 +260,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 #endif
         while (alive && node_is_internal(node) && sp < STACK) {
             RT_STAT_WAVE(0); RT_STAT_LANE(0);
-            node_step<false, !TWO_LEVEL, ANYHIT>(slabs, topl, cur.ri, r.tmin, best.t, st, node, sp);
+            node_step<false, true, ANYHIT>(slabs, topl, cur.ri, r.tmin, best.t, st, node, sp);
 #ifdef RT_TRACE_STATS
             st_maxsp = sp > st_maxsp ? sp : st_maxsp;
 #endif
@@ -271,7 +271,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 #endif
         }
         // lanes whose stack has outgrown the LDS rows walk on with the global rows until it fits again
-        while (alive && node_is_internal(node) && sp >= STACK) node_step<true, !TWO_LEVEL, ANYHIT>(slabs, topl, cur.ri, r.tmin, best.t, st, node, sp);
+        while (alive && node_is_internal(node) && sp >= STACK) node_step<true, true, ANYHIT>(slabs, topl, cur.ri, r.tmin, best.t, st, node, sp);
 
         // ---- leaves, instance entry / exit, termination -----------------------------------
         RT_STAT_WAVE(3);
