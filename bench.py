@@ -28,7 +28,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+L2_PEAK_GBS = 34500.0          # aggregate L2 bandwidth of the 8 XCDs (MI355X_MICROARCH.md, "L2 (per XCD)")
 RAY_BYTES, NODE_BYTES, TRI_BYTES = 48, 32, 36   # 32 B ray in + 16 B hit out; node; triangle
+# what the production kernels request from the memory system per unit: one 64-B slab per
+# node step that is not served by the LDS top table, one 48-B record per triangle test, one 112-B instance record
+# per instance entry, and the ray in / result out of the stage
+SLAB_BYTES, TRIREC_BYTES, INSTANCE_BYTES = 64, 48, 112
+STAGE_IO_BYTES = {"primary": 0 + 20, "secondary": 32 + 20, "shadow": 32 + 4}
 # stage -> (rt_stats time fields, kernel, rt_pipeline_count_work stages whose rays the launch traces)
 TRACE_STAGES = {"primary": (("ms_primary",), "k_primary", ("primary",)),
                 "secondary": (("ms_trace_secondary",), "k_trace_secondary", ("secondary",)),
@@ -44,6 +50,9 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget (rank 0, N=1 only); 0 = skip")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--hbm-frames", type=int, default=8, help="frames of the HBM-bound 10 M-triangle 4K workload timed for roofline_hbm "
+                    "(rank 0, N=1 only); 0 = skip")
+    ap.add_argument("--workload", choices=("c2", "c5"), default="c2", help="c5: ONLY the 10 M-triangle workload (profiling passes)")
     return ap.parse_args()
 
 
@@ -127,19 +136,100 @@ def cpu_baseline(verts, tris, mat, env, pfc, W, H, budget_s):
                               "sample": "%d bands (%d rays) in %.1f s" % (bands1, rays1, dt1)}}
 
 
-def measured_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE need separate passes, so they cannot be taken inside this run): profiles/<round>/traffic.json,
-    written by tools/traffic_from_pmc.py with the gfx950 FETCH_SIZE correction applied.  None if absent."""
+def committed_profile(workload):
+    """The newest committed rocprofv3 summary for `workload` ("c2" / "c5"): profiles/<round>/traffic.json, written by
+    tools/traffic_from_pmc.py from PMC passes around this same bench command (FETCH_SIZE, WRITE_SIZE and the SQ / TCC
+    counters need separate passes, so they cannot be taken inside this run).  {} if absent."""
     here = os.path.dirname(os.path.abspath(__file__))
     for rnd in sorted(os.listdir(os.path.join(here, "profiles")), reverse=True) if os.path.isdir(os.path.join(here, "profiles")) else []:
         path = os.path.join(here, "profiles", rnd, "traffic.json")
         if os.path.isfile(path):
             with open(path) as f:
-                k = json.load(f).get("kernels", {}).get(kernel)
-            if k:
-                return k["bytes_per_launch"]
-    return None
+                d = json.load(f)
+            w = d.get("workloads", {}).get(workload)
+            if w:
+                return dict(w, commit=d.get("commit"), source=path[len(here) + 1:])
+    return {}
+
+
+def walk_bytes(stage, w):
+    """Bytes a traversal stage requests from L2 and beyond, from the production-walk tallies of rt_pipeline_count_walk."""
+    return (SLAB_BYTES * w["slabs_global"] + TRIREC_BYTES * w["tris"] + INSTANCE_BYTES * w["instance_entries"]
+            + STAGE_IO_BYTES[stage] * w["rays"])
+
+
+def stage_table(pipe, tot, with_canonical=True):
+    """Per traversal stage: HIP-event time (average over the timed launches), rays, the production walk's requested bytes
+    and -- as SURVEY 8(d)'s layout-independent contract figure -- the canonical-LBVH counters' algorithmic bytes."""
+    walk = pipe.count_walk()
+    work = pipe.count_work() if with_canonical else None
+    n_t = max(int(tot["frames"]), 1)
+    stages = {}
+    for name, (keys, kernel, parts) in TRACE_STAGES.items():
+        wk = {k: sum(walk[p][k] for p in parts) for k in ("rays", "slabs_global", "slabs_lds", "tris", "instance_entries")}
+        ms = sum(tot[k] for k in keys) / n_t
+        rb = walk_bytes(name, wk)
+        st = {"kernel": kernel, "avg_ms": ms, "rays": wk["rays"], "requested_bytes": rb,
+              "requested_GBps": rb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+              "slabs_global_per_ray": wk["slabs_global"] / max(wk["rays"], 1), "slabs_lds_per_ray": wk["slabs_lds"] / max(wk["rays"], 1),
+              "tris_per_ray": wk["tris"] / max(wk["rays"], 1), "instance_entries_per_ray": wk["instance_entries"] / max(wk["rays"], 1),
+              "Mrays_per_s": wk["rays"] / (ms * 1e-3) / 1e6 if ms > 0 else 0.0}
+        if work is not None:
+            w = {k: sum(work[p][k] for p in parts) for k in ("rays", "nodes", "tris")}
+            b = RAY_BYTES * w["rays"] + NODE_BYTES * w["nodes"] + TRI_BYTES * w["tris"]
+            st["canonical"] = {"algorithmic_bytes": b, "nodes_per_ray": w["nodes"] / max(w["rays"], 1), "tris_per_ray": w["tris"] / max(w["rays"], 1),
+                               "GBps": b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}
+        stages[name] = st
+    for key in ("ms_shade0", "ms_shade1", "ms_resolve", "ms_total"):
+        stages[key] = tot[key] / n_t
+    return stages, n_t
+
+
+def hbm_workload(ctx, capi, T, scenes, frames, warm):
+    """The one configuration whose traversal working set (~0.8 GB of slabs + triangle records) does not fit the 256 MB
+    Infinity Cache: BASELINE configs[4], the 10 M-triangle mesh at 3840x2160 with 4 radiance bounces (SURVEY 7 "Roofline
+    honesty").  Rendered on the same context after the headline measurement; returns the stage table of `frames` frames."""
+    import numpy as np
+    W, H = 3840, 2160
+    t0 = time.perf_counter()
+    v, tri = scenes.displaced_grid(2236, seed=7)
+    gen_s = time.perf_counter() - t0
+    model = capi.Model(ctx, v, tri)
+    scene = capi.Scene(ctx)
+    scene.add_model(model)
+    pipe = capi.Pipeline(ctx)
+    pipe.set_scene(scene)
+    mat = T.default_material()
+    mat["type"] = 2
+    mat["reflectivity"] = 0.6
+    mat["roughness"] = 0.3
+    pipe.add_material(mat)
+    pipe.set_depth_limits(4, 2)
+    pipe.set_environment_cube(scenes.sky_cubemap(32))
+    pipe.create_output(W, H)
+    pipe.build_acceleration_structures()
+    host = capi.ProgressiveHost(3)
+    host.options["maxIterations"] = 1 << 20
+    cam = capi.camera_array((0.0, 6.0, 19.0), (0.0, -4.0, 0.0), (0, 1, 0), 0.8, W / H)
+    for f in range(warm):
+        pipe.update(host.update(cam, 0.0, f + 1, W, H))
+        pipe.render()
+    ctx.synchronize()
+    pipe.enable_timing(frames)
+    pipe.reset_totals()
+    t0 = time.perf_counter()
+    for f in range(warm, warm + frames):
+        pipe.update(host.update(cam, 0.0, f + 1, W, H))
+        pipe.render()
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    tot = pipe.totals()
+    stages, n_t = stage_table(pipe, tot, with_canonical=False)
+    rays = tot["rays_primary"] + tot["rays_secondary"] + tot["rays_shadow"]
+    return {"workload": "BASELINE configs[4] on one GPU: displaced-grid mesh (seed 7, %d triangles), %dx%d, 4 radiance bounces, "
+                        "1 spp/frame" % (tri.shape[0], W, H),
+            "frames": frames, "ms_per_frame": dt / frames * 1e3, "Mrays_per_s": rays / dt / 1e6, "rays_per_frame": rays / frames,
+            "bvh_build_ms": scene.build_ms(), "generate_s": gen_s, "stages": stages, "launches_timed": n_t}
 
 
 def main():
@@ -171,6 +261,14 @@ def main():
             dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm: xGMI between the GPUs of the node
         else:
             dist.init_process_group(backend)
+
+    if args.workload == "c5":            # profiling passes: only the HBM-bound workload, one JSON line of its own
+        assert world == 1, "--workload c5 is a single-GPU profiling mode"
+        ctx = capi.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        h = hbm_workload(ctx, capi, T, scenes, max(args.hbm_frames, 1), 2)
+        print(json.dumps({"metric": "Mrays/s, 10 M triangles 4K 4-bounce (roofline workload)", "value": h["Mrays_per_s"], "unit": "Mrays/s",
+                          "n_gpus": 1, "roofline_hbm": h}))
+        return
 
     W, H, K, Wu = args.width, args.height, args.steps, args.warmup
     verts, tris = scenes.sponza_class(seed=42)
@@ -259,29 +357,54 @@ def main():
             "bvh_build_ms": build_ms, "bvh_rebuild_ms": rebuild_ms,
         }
         if not args.no_roofline:
-            work = pipe.count_work()                       # canonical counters of the last frame's queues
-            n_t = max(int(tot["frames"]), 1)
-            stages = {}
-            for name, (keys, kernel, parts) in TRACE_STAGES.items():
-                w = {k: sum(work[p][k] for p in parts) for k in ("rays", "nodes", "tris")}
-                b = RAY_BYTES * w["rays"] + NODE_BYTES * w["nodes"] + TRI_BYTES * w["tris"]
-                ms = sum(tot[k] for k in keys) / n_t
-                stages[name] = {"kernel": kernel, "avg_ms": ms, "rays": w["rays"], "algorithmic_bytes": b,
-                                "nodes_per_ray": w["nodes"] / max(w["rays"], 1), "tris_per_ray": w["tris"] / max(w["rays"], 1),
-                                "GBps": b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
-                                "Mrays_per_s": w["rays"] / (ms * 1e-3) / 1e6 if ms > 0 else 0.0}
-            for key in ("ms_shade0", "ms_shade1", "ms_resolve", "ms_total"):
-                stages[key] = tot[key] / n_t
+            stages, n_t = stage_table(pipe, tot)
             dom = max(TRACE_STAGES, key=lambda s: stages[s]["avg_ms"])
-            out["roofline"] = {"bound": "hbm", "kernel": stages[dom]["kernel"], "stage": dom,
-                               "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": stages[dom]["GBps"] / HBM_PEAK_GBS, "traffic": measured_traffic(stages[dom]["kernel"]),
-                               "algorithmic_bytes_per_launch": stages[dom]["algorithmic_bytes"],
-                               "avg_launch_ms": stages[dom]["avg_ms"], "launches_timed": n_t}
-            tb = sum(stages[s]["algorithmic_bytes"] for s in TRACE_STAGES)
-            tm = sum(stages[s]["avg_ms"] for s in TRACE_STAGES)
-            out["roofline"]["all_traversal_frac"] = tb / (tm * 1e-3) / 1e9 / HBM_PEAK_GBS if tm > 0 else 0.0
+            d = stages[dom]
+            prof = committed_profile("c2").get("kernels", {}).get(d["kernel"], {})
+            # The C2 working set (~23 MB of slabs + triangle records) is cache resident, so HBM cannot bound these
+            # kernels; what they stress is the rate of 64-B / 48-B requests into the XCD L2s (and, behind them, the
+            # Infinity Cache).  achieved = bytes the production walk requests per launch / measured launch time.
+            out["roofline"] = {"bound": "l2", "kernel": d["kernel"], "stage": dom,
+                               "achieved": d["requested_GBps"], "peak": L2_PEAK_GBS, "unit": "GB/s",
+                               "frac": d["requested_GBps"] / L2_PEAK_GBS,
+                               "traffic": prof.get("bytes_per_launch"),
+                               "bytes_per_launch": d["requested_bytes"], "avg_launch_ms": d["avg_ms"], "launches_timed": n_t,
+                               "definition": "bytes = 64 B x slabs fetched from global memory + 48 B x triangle records + 112 B x instance "
+                                             "entries + ray in / result out, tallied per lane by a counting instantiation of the timed "
+                                             "kernel (rt_pipeline_count_walk) on the last frame's queues; node steps served by the LDS top "
+                                             "table are excluded; peak = aggregate L2 bandwidth; traffic = memory-side bytes (2 x "
+                                             "FETCH_SIZE + WRITE_SIZE) of the committed PMC pass",
+                               "pmc": {k: prof.get(k) for k in ("TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "SQ_INSTS_VALU", "SQ_WAIT_ANY",
+                                                               "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "avg_us") if k in prof},
+                               "pmc_source": committed_profile("c2").get("source"), "pmc_commit": committed_profile("c2").get("commit"),
+                               # SURVEY 8(d)'s layout-independent contract figure, kept for reference: canonical-LBVH counters x
+                               # (32 B node, 36 B triangle, 48 B ray) against HBM peak.  NOT a physical bound for this cache-resident
+                               # working set (the timed kernel walks a different tree and its bytes never leave the caches).
+                               "contract_8d_hbm": {"algorithmic_bytes_per_launch": d["canonical"]["algorithmic_bytes"],
+                                                   "GBps": d["canonical"]["GBps"], "over_hbm_peak": d["canonical"]["GBps"] / HBM_PEAK_GBS}}
+            tb = sum(stages[s]["requested_bytes"] for s in TRACE_STAGES)
+            out["roofline"]["all_stages_GBps_over_step"] = tb / (out["ms_per_step"] * 1e-3) / 1e9
             out["stages"] = stages
+        if world == 1 and args.hbm_frames > 0 and not args.no_roofline:
+            del pipe, scene, model
+            h = hbm_workload(ctx, capi, T, scenes, args.hbm_frames, 2)
+            dom = max(TRACE_STAGES, key=lambda s: h["stages"][s]["avg_ms"])
+            d = h["stages"][dom]
+            prof5 = committed_profile("c5")
+            k5 = prof5.get("kernels", {}).get(d["kernel"], {})
+            traffic = k5.get("bytes_per_launch")
+            prof_us = k5.get("avg_us")
+            h["roofline"] = {"bound": "hbm", "kernel": d["kernel"], "stage": dom,
+                             # HBM-side bytes per launch (PMC, committed pass of this same workload) / the duration rocprofv3
+                             # measured for the same launches; live HIP-event duration alongside
+                             "achieved": traffic / (prof_us * 1e-6) / 1e9 if traffic and prof_us else None,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": traffic / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS if traffic and prof_us else None,
+                             "traffic": traffic, "profiled_avg_us": prof_us,
+                             "requested_bytes_per_launch": d["requested_bytes"], "avg_launch_ms": d["avg_ms"],
+                             "requested_GBps": d["requested_GBps"], "launches_timed": h["launches_timed"],
+                             "pmc_source": prof5.get("source"), "pmc_commit": prof5.get("commit")}
+            out["roofline_hbm"] = h
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(verts, tris, mat, env, pfcs[mine[Wu]], W, H, args.cpu_seconds)
     if world > 1:

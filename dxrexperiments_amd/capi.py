@@ -36,9 +36,15 @@ class StageWork(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes", C.c_uint64), ("tris", C.c_uint64)]
 
 
+class StageWalk(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("slabs_global", C.c_uint64), ("slabs_lds", C.c_uint64), ("tris", C.c_uint64),
+                ("instance_entries", C.c_uint64), ("longest_walk", C.c_uint64), ("longest_walk_ray", C.c_uint64)]
+
+
 STAGES = ("primary", "secondary", "shadow0", "shadow1")
 
 PIPELINE_PROGRESSIVE, PIPELINE_REALTIME = 0, 1
+CUBE_SEAMLESS, CUBE_FACE_CLAMP = 0, 1
 DENOISER_PARAMS = np.dtype([("exposure", "<f4"), ("gamma", "<f4"), ("tonemap", "<u4"), ("gammaCorrect", "<u4"),
                             ("maxKernelSize", "<i4"), ("debugVisualize", "<u4")])
 
@@ -118,6 +124,8 @@ SIGNATURES = {
     "rt_pipeline_get_totals": (_i, [_p, C.POINTER(Stats)]),
     "rt_pipeline_reset_totals": (_i, [_p]),
     "rt_pipeline_count_work": (_i, [_p, C.POINTER(StageWork)]),
+    "rt_pipeline_count_walk": (_i, [_p, C.POINTER(StageWalk)]),
+    "rt_debug_read_secondary_ray": (_i, [_p, _u32, _p, _p]),
     "rt_camera_look": (_i, [_p, _p, _p, _p, _p]),
     "rt_camera_basis": (_i, [_p, _p, _f, _f, _p, _p, _p]),
     "rt_progressive_host_create": (_i, [_u32, _pp]),
@@ -132,7 +140,10 @@ SIGNATURES = {
     "rt_progressive_host_update": (_i, [_p, _p, _f, _u32, _u32, _u32, _p]),
     "rt_debug_math": (_i, [_p, _i, _p, _p, _p, _sz]),
     "rt_debug_sample": (_i, [_p, _i, _p, _p, _f, _p, _p, _p, _sz]),
-    "rt_debug_sample_cube": (_i, [_p, _p, _u32, _p, _p, _sz]),
+    "rt_debug_sample_cube": (_i, [_p, _p, _u32, _u32, _p, _p, _sz]),
+    "rt_pipeline_set_environment_filter": (_i, [_p, _u32]),
+    "rt_dds_read_cube": (_i, [C.c_char_p, _p, _sz, C.POINTER(C.c_uint32)]),
+    "rt_obj_read": (_i, [C.c_char_p, _p, _u32, _p, _u32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }
 
 
@@ -226,11 +237,12 @@ class Context:
         _check(lib().rt_debug_sample(self.h, kind, _ptr(seeds), _ptr(vecs), exponent, _ptr(out), _ptr(pb), _ptr(so), n))
         return out, pb, so
 
-    def sample_cube(self, faces, dirs):
+    def sample_cube(self, faces, dirs, seamless=True):
         faces = _f32(faces)
         dirs = _f32(dirs, (-1, 3))
         out = np.empty_like(dirs)
-        _check(lib().rt_debug_sample_cube(self.h, _ptr(faces), faces.shape[1], _ptr(dirs), _ptr(out), dirs.shape[0]))
+        _check(lib().rt_debug_sample_cube(self.h, _ptr(faces), faces.shape[1], CUBE_SEAMLESS if seamless else CUBE_FACE_CLAMP,
+                                          _ptr(dirs), _ptr(out), dirs.shape[0]))
         return out
 
 
@@ -401,6 +413,10 @@ class Pipeline:
         assert f.ndim == 4 and f.shape[0] == 6 and f.shape[1] == f.shape[2] and f.shape[3] == 4
         _check(lib().rt_pipeline_set_environment_cube(self.h, _ptr(f), f.shape[1]))
 
+    def set_environment_filter(self, seamless=True):
+        """Cube-map filtering: seamless (cross-face taps, what D3D12 hardware does; default) or clamped to the face."""
+        _check(lib().rt_pipeline_set_environment_filter(self.h, CUBE_SEAMLESS if seamless else CUBE_FACE_CLAMP))
+
     def set_environment_constant(self, rgb):
         c = _f32(rgb, 3)
         _check(lib().rt_pipeline_set_environment_constant(self.h, _ptr(c)))
@@ -487,6 +503,18 @@ class Pipeline:
         _check(lib().rt_pipeline_count_work(self.h, w))
         return {n: dict(rays=int(w[i].rays), nodes=int(w[i].nodes), tris=int(w[i].tris)) for i, n in enumerate(STAGES)}
 
+    def secondary_ray(self, index):
+        o = np.zeros(4, np.float32); d = np.zeros(4, np.float32)
+        _check(lib().rt_debug_read_secondary_ray(self.h, int(index), _ptr(o), _ptr(d)))
+        return o, d
+
+    def count_walk(self):
+        """What the PRODUCTION traversal fetched for the last frame per stage:
+        {stage: dict(rays, slabs_global, slabs_lds, tris, instance_entries)}."""
+        w = (StageWalk * len(STAGES))()
+        _check(lib().rt_pipeline_count_walk(self.h, w))
+        return {n: {f: int(getattr(w[i], f)) for f, _ in StageWalk._fields_} for i, n in enumerate(STAGES)}
+
     def stats(self):
         s = Stats()
         _check(lib().rt_pipeline_get_stats(self.h, C.byref(s)))
@@ -496,6 +524,26 @@ class Pipeline:
         t = np.empty(n, np.float32); prim = np.empty(n, np.uint32); inst = np.empty(n, np.uint32)
         _check(lib().rt_pipeline_read_primary_hits(self.h, _ptr(t), _ptr(prim), _ptr(inst)))
         return t, prim, inst
+
+
+def dds_read_cube(path):
+    """The product's DDS cube-map reader, no device needed: (6, size, size, 4) float32 faces of mip 0."""
+    n = C.c_uint32(0)
+    _check(lib().rt_dds_read_cube(os.fsencode(path), None, 0, C.byref(n)))
+    faces = np.empty((6, n.value, n.value, 4), np.float32)
+    _check(lib().rt_dds_read_cube(os.fsencode(path), _ptr(faces), faces.size, C.byref(n)))
+    return faces
+
+
+def obj_read(path):
+    """The product's OBJ reader, no device needed: (verts[VERTEX], tris[n,3] uint32)."""
+    from .rtypes import VERTEX
+    nv, nt = C.c_uint32(0), C.c_uint32(0)
+    _check(lib().rt_obj_read(os.fsencode(path), None, 0, None, 0, C.byref(nv), C.byref(nt)))
+    v = np.zeros(nv.value, VERTEX)
+    t = np.zeros((nt.value, 3), np.uint32)
+    _check(lib().rt_obj_read(os.fsencode(path), _ptr(v), nv.value, _ptr(t), nt.value, C.byref(nv), C.byref(nt)))
+    return v, t
 
 
 def camera_look(eye, at, up):

@@ -350,6 +350,7 @@ int rt_scene_add_model(rt_scene *s, rt_model *m, const float transform3x4[12])
     m->refs++;
     s->inst.push_back(in);
     s->built = false;
+    s->generation++;
     return RT_OK;
 }
 
@@ -367,10 +368,11 @@ int rt_scene_build(rt_scene *s, uint32_t hit_group_count)
     RT_REQUIRE(!s->inst.empty(), "scene has no instances");
     rt_context *ctx = s->ctx;
     RT_TRY(use_device(ctx));
-    hipEvent_t e0, e1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, ctx->stream));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); rt_set_error("rt_scene_build: hipEventCreate failed"); return RT_ERR_HIP; }
+    if (hipEventRecord(e0, ctx->stream) != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); rt_set_error("rt_scene_build: hipEventRecord failed"); return RT_ERR_HIP; }
+    s->generation++;          // device arrays are about to be reallocated: pipelines drop what they cached
     int rc = RT_OK;
     for (SceneInstance &in : s->inst)
         if ((rc = rt_build_blas(ctx, in.model)) != RT_OK) break;

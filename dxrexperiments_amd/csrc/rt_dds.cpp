@@ -55,6 +55,12 @@ int rt_dds_load_cube(const char *path, std::vector<float> &faces, uint32_t &size
     const uint32_t height = rd32(&d[12]), width = rd32(&d[16]);
     uint32_t mips = rd32(&d[28]);
     if (mips == 0) mips = 1;
+    // header fields are untrusted: bound them before any size arithmetic (a crafted width such as 2^30 + k would wrap
+    // the byte counts below and pass the truncation check with a tiny payload)
+    if (width > 16384u || height > 16384u || mips > 15u) {
+        rt_set_error("'%s': implausible DDS header (%ux%u, %u mips)", path, width, height, mips);
+        return RT_ERR_UNSUPPORTED;
+    }
     const uint32_t pf_flags = rd32(&d[80]), fourcc = rd32(&d[84]);
     const uint32_t caps2 = rd32(&d[112]);
     size_t off = 128;
@@ -73,7 +79,7 @@ int rt_dds_load_cube(const char *path, std::vector<float> &faces, uint32_t &size
     if (!cube || width != height || width == 0) { rt_set_error("'%s' is not a square cube map", path); return RT_ERR_UNSUPPORTED; }
     size_t face_bytes = 0;
     for (uint32_t m = 0, w = width; m < mips; m++, w = w > 1 ? w / 2 : 1) face_bytes += (size_t)w * w * bpp;
-    if (d.size() < off + 6 * face_bytes) { rt_set_error("'%s': truncated texel data", path); return RT_ERR_IO; }
+    if (d.size() < off || 6 * face_bytes > d.size() - off) { rt_set_error("'%s': truncated texel data", path); return RT_ERR_IO; }
     size = width;
     faces.resize((size_t)6 * width * width * 4);
     for (int face = 0; face < 6; face++) {
@@ -83,5 +89,18 @@ int rt_dds_load_cube(const char *path, std::vector<float> &faces, uint32_t &size
         if (bpp == 16) memcpy(dst, src, n * 4);
         else for (size_t i = 0; i < n; i++) dst[i] = half_to_float((uint16_t)(src[2 * i] | (src[2 * i + 1] << 8)));
     }
+    return RT_OK;
+}
+
+extern "C" int rt_dds_read_cube(const char *path, float *faces_rgba32f, size_t capacity_floats, uint32_t *size)
+{
+    RT_REQUIRE(path && size, "null argument");
+    std::vector<float> faces;
+    uint32_t n = 0;
+    RT_TRY(rt_dds_load_cube(path, faces, n));
+    *size = n;
+    if (!faces_rgba32f) return RT_OK;
+    RT_REQUIRE(capacity_floats >= faces.size(), "buffer too small for 6 x size x size x 4 floats");
+    memcpy(faces_rgba32f, faces.data(), faces.size() * sizeof(float));
     return RT_OK;
 }

@@ -16,20 +16,22 @@
 
 namespace {
 
-uint32_t crc_table[256];
-bool crc_ready = false;
-uint32_t crc32(uint32_t crc, const uint8_t *p, size_t n)
-{
-    if (!crc_ready) {
+struct CrcTable {          // built once by the static initialiser (contexts on different threads may write images)
+    uint32_t t[256];
+    CrcTable()
+    {
         for (uint32_t i = 0; i < 256; i++) {
             uint32_t c = i;
             for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-            crc_table[i] = c;
+            t[i] = c;
         }
-        crc_ready = true;
     }
+};
+const CrcTable crc_table;
+uint32_t crc32(uint32_t crc, const uint8_t *p, size_t n)
+{
     crc = ~crc;
-    for (size_t i = 0; i < n; i++) crc = crc_table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+    for (size_t i = 0; i < n; i++) crc = crc_table.t[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
     return ~crc;
 }
 
@@ -87,9 +89,10 @@ int rt_image_write_png(const char *path, const float *rgba32f, uint32_t width, u
             for (int c = 0; c < 3; c++) {
                 float v = src[4 * x + c] * exposure;
                 if (!(v > 0.0f)) v = 0.0f;                              // negatives and NaN -> black
-                if (tonemap) v = v / (1.0f + v);                        // Reinhard
+                if (tonemap) v = v > 3.0e38f ? 1.0f : v / (1.0f + v);   // Reinhard; +inf (or an overflowed sum) -> white, not inf/inf
                 v = powf(v, 1.0f / gamma);
-                if (v > 1.0f) v = 1.0f;
+                if (!(v <= 1.0f)) v = 1.0f;                             // also catches a NaN from powf
+                if (!(v >= 0.0f)) v = 0.0f;
                 *dst++ = (uint8_t)(v * 255.0f + 0.5f);
             }
     }

@@ -181,6 +181,7 @@ struct rt_scene {
     DevBuf d_inst;
     BvhDev tlas;
     bool built = false;
+    uint32_t generation = 0;     // bumped by every add_model / build: device pointers cached from an older one are stale
     float build_ms = 0.0f;
     uint32_t stack_need = 0;     // traversal stack entries a ray can hold at once
     bool two_level = true;       // false: one identity instance, rays walk its BLAS directly
@@ -231,8 +232,8 @@ static inline unsigned rt_persistent_grid(const rt_context *ctx, K kernel, int b
 }
 
 #ifndef RT_LDS_STACK_ROWS
-#define RT_LDS_STACK_ROWS 14            // LDS stack rows of the single-level kernels; with the 12-row top table 26 KiB per
-#endif                                  // 256-thread block = 6 blocks per CU.  Two-level kernels have no top table and use all 26 rows
+#define RT_LDS_STACK_ROWS 14            // LDS stack rows of the traversal kernels; with the 12-row top table (top of the BLAS for
+#endif                                  // single-level walks, top of the TLAS for two-level ones) 26 KiB per 256-thread block = 6 blocks per CU
 #define RT_LDS_STACK_ROWS_TEST 6        // second instantiation (env RT_LDS_STACK_ROWS=6): tests force rays onto the global rows
 
 // The scene as the traversal kernels see it, with the global stack rows a launch of `threads` threads whose
@@ -251,11 +252,9 @@ static inline int rt_scene_dev_for_launch(rt_context *ctx, const rt_scene *s, ui
     out->deep_stack = ctx->deep_stack.as<int>();
     return RT_OK;
 }
-static inline uint32_t rt_lds_stack_rows(const rt_context *ctx, bool two_level)
+static inline uint32_t rt_lds_stack_rows(const rt_context *ctx)
 {
-    const uint32_t rows = ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST ? RT_LDS_STACK_ROWS_TEST : RT_LDS_STACK_ROWS;
-    (void)two_level;
-    return rows;
+    return ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST ? RT_LDS_STACK_ROWS_TEST : RT_LDS_STACK_ROWS;
 }
 
 // rt_bvh_ploc.hip

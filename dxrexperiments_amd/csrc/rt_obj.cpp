@@ -25,6 +25,21 @@ namespace {
 
 struct P3 { float x, y, z; };
 struct Corner { int p, n; };
+constexpr int RT_BAD_INDEX = 0x7fffffff;
+
+// one whole line of the file whatever its length (n-gon records and exporter-wrapped lines exceed any fixed buffer)
+bool read_line(FILE *f, std::vector<char> &line)
+{
+    line.clear();
+    int c;
+    while ((c = fgetc(f)) != EOF) {
+        if (c == '\n') break;
+        line.push_back((char)c);
+    }
+    if (c == EOF && line.empty()) return false;
+    line.push_back(0);
+    return true;
+}
 
 inline bool is_blank(char c) { return c == ' ' || c == '\t'; }
 
@@ -48,8 +63,12 @@ bool parse_corner(char *&s, size_t npos, size_t nnrm, Corner &out)
             s = e;
         }
     }
-    out.p = (int)(pi < 0 ? (long)npos + pi : pi - 1);
-    out.n = has_n ? (int)(ni < 0 ? (long)nnrm + ni : ni - 1) : -1;
+    // 1-based, or negative = relative to the end of the list read so far.  An index that resolves below 0 must not
+    // collide with -1 ("no normal"): it becomes RT_BAD_INDEX and fails the range check after parsing.
+    const long p = pi < 0 ? (long)npos + pi : pi - 1;
+    const long n = has_n ? (ni < 0 ? (long)nnrm + ni : ni - 1) : -1;
+    out.p = p < 0 || p > 0x7ffffff0L ? RT_BAD_INDEX : (int)p;
+    out.n = !has_n ? -1 : (n < 0 || n > 0x7ffffff0L ? RT_BAD_INDEX : (int)n);
     return true;
 }
 
@@ -65,9 +84,9 @@ int rt_obj_parse(const char *path, std::vector<rt_vertex> &verts, std::vector<ui
     std::vector<P3> pos, nrm;
     std::vector<Corner> corners;
     std::vector<Corner> poly;
-    char line[4096];
-    while (fgets(line, sizeof line, f)) {
-        char *s = line;
+    std::vector<char> line;
+    while (read_line(f, line)) {
+        char *s = line.data();
         while (is_blank(*s)) s++;
         if (s[0] == 'v' && is_blank(s[1])) {
             char *e = s + 1;
@@ -94,7 +113,7 @@ int rt_obj_parse(const char *path, std::vector<rt_vertex> &verts, std::vector<ui
     fclose(f);
     bool need_gen = false;
     for (const Corner &c : corners) {
-        if (c.p < 0 || c.p >= (int)pos.size() || c.n >= (int)nrm.size()) {
+        if (c.p < 0 || c.p >= (int)pos.size() || c.n >= (int)nrm.size() || c.n < -1) {
             rt_set_error("OBJ file '%s': face index out of range", path);
             return RT_ERR_IO;
         }
@@ -146,5 +165,21 @@ int rt_obj_parse(const char *path, std::vector<rt_vertex> &verts, std::vector<ui
         joined[key] = id;
         idx.push_back(id);
     }
+    return RT_OK;
+}
+
+extern "C" int rt_obj_read(const char *path, rt_vertex *verts, uint32_t capacity_verts, uint32_t *indices, uint32_t capacity_tris,
+                           uint32_t *n_verts, uint32_t *n_tris)
+{
+    RT_REQUIRE(path && n_verts && n_tris, "null argument");
+    std::vector<rt_vertex> v;
+    std::vector<uint32_t> idx;
+    RT_TRY(rt_obj_parse(path, v, idx));
+    *n_verts = (uint32_t)v.size();
+    *n_tris = (uint32_t)(idx.size() / 3);
+    if (!verts && !indices) return RT_OK;
+    RT_REQUIRE(verts && indices && capacity_verts >= v.size() && capacity_tris >= idx.size() / 3, "buffers too small");
+    memcpy(verts, v.data(), v.size() * sizeof(rt_vertex));
+    memcpy(indices, idx.data(), idx.size() * sizeof(uint32_t));
     return RT_OK;
 }

@@ -76,6 +76,7 @@ struct PipeDev {
     uint32_t nmats;
     const float4 *env;
     uint32_t env_size;
+    uint32_t env_filter;                // RT_CUBE_SEAMLESS / RT_CUBE_FACE_CLAMP
     float env_const[3];
     uint32_t width, height;
     uint32_t x0, y0, tw, th, cap;       // tile rectangle; cap = tiles_x * tiles_y * 64 pixel slots
@@ -96,6 +97,45 @@ constexpr size_t POOL_OFFSET_WORDS = 64;      // the pools start on a 256-B boun
 RT_DEV uint32_t hcap(const PipeDev &pd, int L) { return L == 0 ? pd.cap : 2u * pd.cap; }
 
 // ---- environment: TextureCube.SampleLevel(linear, dir, 0), RaytracingCommon.hlsli:149-159
+// The sampler is MIN_MAG_LINEAR (ProgressiveRaytracingPipeline.cpp:48-55).  On D3D10+ hardware cube maps are
+// always filtered seamlessly: a bilinear tap that falls off the selected face comes from the face across that
+// edge.  RT_CUBE_SEAMLESS (default) models that with the cube's face-adjacency table; a tap off a CORNER has no
+// texel (three faces meet there) and takes the mean of the footprint's other three, the D3D11 functional
+// spec's suggestion.  RT_CUBE_FACE_CLAMP clamps taps to the selected face (round 1's behaviour).
+//
+// Face f = +X -X +Y -Y +Z -Z, edge e = x<0, x>=N, y<0, y>=N -> the face across the edge and where the texel at
+// position k along the edge lands there: bit 0 set: x' is the fixed coordinate (else y'), bit 1: fixed = N-1
+// (else 0), bit 2: the running coordinate is N-1-k (else k).  Derived from the D3D face parameterisation above.
+__constant__ const unsigned char kCubeEdge[24] = {
+    (4 << 3) | 3, (5 << 3) | 1, (2 << 3) | 7, (3 << 3) | 3,      // +X
+    (5 << 3) | 3, (4 << 3) | 1, (2 << 3) | 1, (3 << 3) | 5,      // -X
+    (1 << 3) | 0, (0 << 3) | 4, (5 << 3) | 4, (4 << 3) | 0,      // +Y
+    (1 << 3) | 6, (0 << 3) | 2, (4 << 3) | 2, (5 << 3) | 6,      // -Y
+    (1 << 3) | 3, (0 << 3) | 1, (2 << 3) | 2, (3 << 3) | 0,      // +Z
+    (0 << 3) | 3, (1 << 3) | 1, (2 << 3) | 4, (3 << 3) | 6};     // -Z
+
+// texel (x, y) of `face`, x and y in [-1, N]; false: the tap hangs over a cube corner
+RT_DEV bool cube_tap(const PipeDev &pd, int face, int x, int y, float4 &out)
+{
+    const int m = (int)pd.env_size - 1;
+    const bool ox = x < 0 || x > m, oy = y < 0 || y > m;
+    if (pd.env_filter == RT_CUBE_FACE_CLAMP) {
+        x = min(max(x, 0), m); y = min(max(y, 0), m);
+    } else if (ox && oy) {
+        return false;
+    } else if (ox || oy) {
+        const int e = ox ? (x < 0 ? 0 : 1) : (y < 0 ? 2 : 3);
+        const int k = ox ? y : x;
+        const unsigned code = kCubeEdge[face * 4 + e];
+        const int fixed = (code & 2u) ? m : 0, run = (code & 4u) ? m - k : k;
+        face = (int)(code >> 3);
+        x = (code & 1u) ? fixed : run;
+        y = (code & 1u) ? run : fixed;
+    }
+    out = pd.env[((size_t)face * pd.env_size + (size_t)y) * pd.env_size + (size_t)x];
+    return true;
+}
+
 RT_DEV f3 sample_cube(const PipeDev &pd, f3 d)
 {
     if (pd.env_size == 0) return mk3(pd.env_const[0], pd.env_const[1], pd.env_const[2]);
@@ -111,14 +151,21 @@ RT_DEV f3 sample_cube(const PipeDev &pd, f3 d)
     const float fx = u * n - 0.5f, fy = v * n - 0.5f;
     const float x0f = __builtin_floorf(fx), y0f = __builtin_floorf(fy);
     const float wx = fx - x0f, wy = fy - y0f;
-    const int m = (int)pd.env_size - 1;
-    int x0 = (int)x0f, y0 = (int)y0f;
-    int x1 = x0 + 1, y1 = y0 + 1;
-    x0 = min(max(x0, 0), m); x1 = min(max(x1, 0), m);
-    y0 = min(max(y0, 0), m); y1 = min(max(y1, 0), m);
-    const float4 *f = pd.env + (size_t)face * pd.env_size * pd.env_size;
-    const float4 c00 = f[(size_t)y0 * pd.env_size + x0], c10 = f[(size_t)y0 * pd.env_size + x1];
-    const float4 c01 = f[(size_t)y1 * pd.env_size + x0], c11 = f[(size_t)y1 * pd.env_size + x1];
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    float4 c[4];
+    bool have[4];
+    have[0] = cube_tap(pd, face, x0, y0, c[0]);
+    have[1] = cube_tap(pd, face, x0 + 1, y0, c[1]);
+    have[2] = cube_tap(pd, face, x0, y0 + 1, c[2]);
+    have[3] = cube_tap(pd, face, x0 + 1, y0 + 1, c[3]);
+    for (int k = 0; k < 4; k++) {
+        if (have[k]) continue;                    // at most one tap of a footprint hangs over a corner
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        for (int j = 0; j < 4; j++)
+            if (j != k) { sx = sx + c[j].x; sy = sy + c[j].y; sz = sz + c[j].z; }
+        c[k] = make_float4(sx / 3.0f, sy / 3.0f, sz / 3.0f, 1.0f);
+    }
+    const float4 c00 = c[0], c10 = c[1], c01 = c[2], c11 = c[3];
     const float tx = c00.x + (c10.x - c00.x) * wx, bx = c01.x + (c11.x - c01.x) * wx;
     const float ty = c00.y + (c10.y - c00.y) * wx, by = c01.y + (c11.y - c01.y) * wx;
     const float tz = c00.z + (c10.z - c00.z) * wx, bz = c01.z + (c11.z - c01.z) * wx;
@@ -616,6 +663,33 @@ __global__ void __launch_bounds__(PBLOCK) k_trace_secondary(SceneDev sc, QueueSr
     trace_wave<STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem, stat);
 }
 
+// ---- walk counting (rt_pipeline_count_walk): the production walk over the last frame's queues with per-lane
+// tallies of what it fetches; results are not stored (the frame already holds them)
+struct NullSink { RT_DEV void store(uint32_t, const HitD &, bool) const {} };
+
+template <bool TWO_LEVEL>
+__global__ void __launch_bounds__(PBLOCK) k_walk_primary(PipeDev pd, unsigned long long *walk)
+{
+    __shared__ int smem[(RT_LDS_STACK_ROWS + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
+    PrimarySrc src = {pd};
+    NullSink sink;
+    trace_wave<RT_LDS_STACK_ROWS, PBLOCK, TWO_LEVEL, 64u, false, true>(pd.sc, src, sink, nullptr, smem, nullptr, walk);
+}
+template <bool TWO_LEVEL>
+__global__ void __launch_bounds__(PBLOCK) k_walk_queue(SceneDev sc, QueueSrc src, unsigned long long *walk)
+{
+    __shared__ int smem[(RT_LDS_STACK_ROWS + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
+    NullSink sink;
+    trace_wave<RT_LDS_STACK_ROWS, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK, false, true>(sc, src, sink, nullptr, smem, nullptr, walk);
+}
+template <bool TWO_LEVEL>
+__global__ void __launch_bounds__(PBLOCK) k_walk_shadow(SceneDev sc, QueueSrc src, unsigned long long *walk)
+{
+    __shared__ int smem[(RT_LDS_STACK_ROWS + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
+    NullSink sink;
+    trace_wave<RT_LDS_STACK_ROWS, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK, RT_SHADOW_UNORDERED != 0, true>(sc, src, sink, nullptr, smem, nullptr, walk);
+}
+
 template <int MAXL>
 __global__ void __launch_bounds__(PBLOCK) k_resolve(PipeDev pd)
 {
@@ -748,6 +822,7 @@ struct rt_pipeline {
     bool mats_dirty = true;
     DevBuf d_env;
     uint32_t env_size = 0;
+    uint32_t env_filter = RT_CUBE_SEAMLESS;
     float env_const[3] = {0.5f, 0.5f, 0.5f};
     uint32_t width = 0, height = 0, format = RT_FORMAT_R32G32B32A32_FLOAT;
     DevBuf accum_own;
@@ -770,6 +845,7 @@ struct rt_pipeline {
     rt_stats stats;
     uint32_t last_tile[4] = {0, 0, 0, 0};
     bool rendered = false;
+    uint32_t last_scene_gen = 0;       // generation of the scene last_pd was filled from
 };
 
 namespace {
@@ -859,6 +935,29 @@ void launch_frame_any(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
     else launch_frame<STACK, false>(p, pd, shadow_slots);
 }
 
+template <bool TWO_LEVEL>
+static int count_walk_launch(rt_pipeline *p, unsigned long long *w)
+{
+    hipStream_t st = p->ctx->stream;
+    const rt_context *ctx = p->ctx;
+    const PipeDev &pd = p->last_pd;
+    const uint32_t cap = pd.cap, ss = p->last_shadow_slots;
+    const uint32_t any = RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH | RT_RAY_FLAG_SKIP_CLOSEST_HIT_SHADER;
+    k_walk_primary<TWO_LEVEL><<<rt_persistent_grid(ctx, k_walk_primary<TWO_LEVEL>, PBLOCK, cap), PBLOCK, 0, st>>>(pd, w + 6 * RT_STAGE_PRIMARY);
+    const unsigned gq = rt_persistent_grid(ctx, k_walk_queue<TWO_LEVEL>, PBLOCK, (size_t)cap * 2);
+    const unsigned gs = rt_persistent_grid(ctx, k_walk_shadow<TWO_LEVEL>, PBLOCK, (size_t)cap * 2);
+    k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any}, w + 6 * RT_STAGE_SHADOW0);
+    const uint32_t levels = pd.max_rad < (uint32_t)MAXD ? pd.max_rad : (uint32_t)MAXD;
+    for (uint32_t l = 1; l <= levels; l++) {
+        k_walk_queue<TWO_LEVEL><<<gq, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE},
+                                                       w + 6 * RT_STAGE_SECONDARY);
+        if (l < pd.max_shadow)
+            k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any}, w + 6 * RT_STAGE_SHADOW1);
+    }
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -910,6 +1009,7 @@ int rt_pipeline_set_scene(rt_pipeline *p, rt_scene *s)
     rt_scene_retain(s);
     if (p->scene) rt_scene_destroy(p->scene);
     p->scene = s;
+    p->rendered = false;        // last_pd holds device pointers of the previous scene
     return RT_OK;
 }
 
@@ -918,6 +1018,7 @@ int rt_pipeline_add_material(rt_pipeline *p, const rt_material_params *m)
     RT_REQUIRE(p && m, "null argument");
     p->mats.push_back(*m);
     p->mats_dirty = true;
+    p->rendered = false;        // d_mats may be reallocated by the next render
     return RT_OK;
 }
 
@@ -927,6 +1028,7 @@ int rt_pipeline_set_material(rt_pipeline *p, uint32_t index, const rt_material_p
     RT_REQUIRE(index < p->mats.size(), "material index out of range");
     p->mats[index] = *m;
     p->mats_dirty = true;
+    p->rendered = false;
     return RT_OK;
 }
 
@@ -950,6 +1052,14 @@ int rt_pipeline_set_environment_constant(rt_pipeline *p, const float rgb[3])
     return RT_OK;
 }
 
+int rt_pipeline_set_environment_filter(rt_pipeline *p, uint32_t filter)
+{
+    RT_REQUIRE(p, "null pipeline");
+    RT_REQUIRE(filter == RT_CUBE_SEAMLESS || filter == RT_CUBE_FACE_CLAMP, "unknown cube-map filter");
+    p->env_filter = filter;
+    return RT_OK;
+}
+
 int rt_pipeline_load_environment_dds(rt_pipeline *p, const char *path)
 {
     RT_REQUIRE(p && path, "null argument");
@@ -969,6 +1079,7 @@ int rt_pipeline_create_output(rt_pipeline *p, uint32_t format, uint32_t width, u
     if (p->kind == RT_PIPELINE_REALTIME) RT_TRY(p->aov_own.reserve((size_t)width * height * 16));     // kNumOutputResources = 2
     p->accum = p->accum_own.as<float4>();
     p->width = width; p->height = height; p->format = format;
+    p->rendered = false;
     return rt_pipeline_clear_output(p);
 }
 
@@ -979,6 +1090,7 @@ int rt_pipeline_bind_output(rt_pipeline *p, void *device_rgba32f, uint32_t width
     RT_REQUIRE(p->kind == RT_PIPELINE_PROGRESSIVE, "bind_output: only the progressive pipeline renders into caller memory");
     p->accum = (float4 *)device_rgba32f;
     p->width = width; p->height = height; p->format = RT_FORMAT_R32G32B32A32_FLOAT;
+    p->rendered = false;
     return RT_OK;
 }
 
@@ -987,6 +1099,7 @@ int rt_pipeline_build_acceleration_structures(rt_pipeline *p)
     RT_REQUIRE(p, "null pipeline");
     if (!p->scene) { rt_set_error("buildAccelerationStructures: no scene set"); return RT_ERR_STATE; }
     if (p->scene->built) return RT_OK;       // built once, shared between pipelines
+    p->rendered = false;                     // a rebuild reallocates what last_pd points at
     return rt_scene_build(p->scene, 2);
 }
 
@@ -1063,12 +1176,13 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
     }
     PipeDev pd;
     // (threads of the largest launch: the primary stage runs one thread per pixel slot, the persistent stages fewer)
-    RT_TRY(rt_scene_dev_for_launch(ctx, p->scene, rt_lds_stack_rows(ctx, p->scene->two_level), cap > ctx->cu_count * 16u * PBLOCK ? cap : ctx->cu_count * 16u * PBLOCK, &pd.sc));
+    RT_TRY(rt_scene_dev_for_launch(ctx, p->scene, rt_lds_stack_rows(ctx), cap > ctx->cu_count * 16u * PBLOCK ? cap : ctx->cu_count * 16u * PBLOCK, &pd.sc));
     pd.pfc = p->pfc;
     pd.mats = p->d_mats.as<rt_material_params>();
     pd.nmats = (uint32_t)p->mats.size();
     pd.env = p->d_env.as<float4>();
     pd.env_size = p->env_size;
+    pd.env_filter = p->env_filter;
     for (int k = 0; k < 3; k++) pd.env_const[k] = p->env_const[k];
     pd.width = width; pd.height = height;
     pd.x0 = x0; pd.y0 = y0; pd.tw = tw; pd.th = th; pd.cap = cap; pd.tiles_x = tiles_x;
@@ -1089,13 +1203,14 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
     static_assert(C_COUNT <= POOL_OFFSET_WORDS, "scalar counters overlap the chunk pools");
     pd.pools = pd.counters + POOL_OFFSET_WORDS;
     HIP_TRY(hipMemsetAsync(pd.counters, 0, POOL_OFFSET_WORDS * 4 + POOL_BYTES, st));
-    // 24 LDS stack rows = 24 KiB per 256-thread block = 6 resident blocks per CU, whatever the depth of the
-    // tree; the rare deeper walk continues in global rows (rt_trace_wave.h)
+    // 14 LDS stack rows + the 12-row top table = 26 KiB per 256-thread block = 6 resident blocks per CU, whatever
+    // the depth of the tree; the rare deeper walk continues in global rows (rt_trace_wave.h)
     if (ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST) launch_frame_any<RT_LDS_STACK_ROWS_TEST>(p, pd, shadow_slots);
     else launch_frame_any<RT_LDS_STACK_ROWS>(p, pd, shadow_slots);
     HIP_TRY(hipGetLastError());
     p->last_pd = pd;
     p->last_shadow_slots = shadow_slots;
+    p->last_scene_gen = p->scene->generation;
     p->last_tile[0] = x0; p->last_tile[1] = y0; p->last_tile[2] = x1; p->last_tile[3] = y1;
     p->rendered = true;
     return RT_OK;
@@ -1325,10 +1440,10 @@ int rt_pipeline_reset_totals(rt_pipeline *p)
 int rt_pipeline_count_work(rt_pipeline *p, rt_stage_work *out)
 {
     RT_REQUIRE(p && out, "null argument");
-    if (!p->rendered) { rt_set_error("count_work: nothing rendered yet"); return RT_ERR_STATE; }
+    if (!p->rendered || !p->scene->built || p->scene->generation != p->last_scene_gen) { rt_set_error("count_work: nothing rendered since the last change of scene, materials or output"); return RT_ERR_STATE; }
     HIP_TRY(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->stream;
-    RT_TRY(p->work.reserve(RT_STAGE_COUNT * 3 * sizeof(unsigned long long)));
+    RT_TRY(p->work.reserve(RT_STAGE_COUNT * 6 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(p->work.p, 0, RT_STAGE_COUNT * 3 * sizeof(unsigned long long), st));
     unsigned long long *w = p->work.as<unsigned long long>();
     const PipeDev &pd = p->last_pd;
@@ -1351,6 +1466,46 @@ int rt_pipeline_count_work(rt_pipeline *p, rt_stage_work *out)
     HIP_TRY(hipMemcpyAsync(h, w, sizeof h, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (int k = 0; k < RT_STAGE_COUNT; k++) { out[k].rays = h[3 * k]; out[k].nodes = h[3 * k + 1]; out[k].tris = h[3 * k + 2]; }
+    return RT_OK;
+}
+
+int rt_pipeline_count_walk(rt_pipeline *p, rt_stage_walk *out)
+{
+    RT_REQUIRE(p && out, "null argument");
+    if (!p->rendered || !p->scene->built || p->scene->generation != p->last_scene_gen) { rt_set_error("count_walk: nothing rendered since the last change of scene, materials or output"); return RT_ERR_STATE; }
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    const size_t bytes = RT_STAGE_COUNT * 6 * sizeof(unsigned long long);
+    RT_TRY(p->work.reserve(bytes));
+    HIP_TRY(hipMemsetAsync(p->work.p, 0, bytes, st));
+    unsigned long long *w = p->work.as<unsigned long long>();
+    if (p->scene->two_level) RT_TRY(count_walk_launch<true>(p, w));
+    else RT_TRY(count_walk_launch<false>(p, w));
+    unsigned long long h[RT_STAGE_COUNT * 6];
+    HIP_TRY(hipMemcpyAsync(h, w, sizeof h, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int k = 0; k < RT_STAGE_COUNT; k++) {
+        out[k].rays = h[6 * k]; out[k].slabs_global = h[6 * k + 1]; out[k].slabs_lds = h[6 * k + 2];
+        out[k].tris = h[6 * k + 3]; out[k].instance_entries = h[6 * k + 4];
+        out[k].longest_walk = h[6 * k + 5] >> 32;
+        out[k].longest_walk_ray = (uint32_t)h[6 * k + 5];
+    }
+    return RT_OK;
+}
+
+// debugging aid for rt_stage_walk.longest_walk_ray: ray `index` of the level-1 radiance queue (diffuse batch, then specular batch)
+int rt_debug_read_secondary_ray(rt_pipeline *p, uint32_t index, float origin_tmin[4], float dir_tmax[4])
+{
+    RT_REQUIRE(p && origin_tmin && dir_tmax, "null argument");
+    if (!p->rendered) { rt_set_error("nothing rendered yet"); return RT_ERR_STATE; }
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    uint32_t n = 0;
+    HIP_TRY(hipMemcpy(&n, p->last_pd.counters + C_NHIT, 4, hipMemcpyDeviceToHost));
+    RT_REQUIRE(n > 0 && index < 2 * n, "ray index out of range");
+    const size_t slot = (size_t)(index / n) * p->last_pd.cap + index % n;
+    HIP_TRY(hipMemcpy(origin_tmin, p->last_pd.lv[1].O + slot, 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dir_tmax, p->last_pd.lv[1].D + slot, 16, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
@@ -1393,9 +1548,10 @@ int rt_debug_trace_stats(unsigned long long out[8 + 64])
 }
 #endif
 
-int rt_debug_sample_cube(rt_context *ctx, const float *faces, uint32_t size, const float *dirs, float *out, size_t n)
+int rt_debug_sample_cube(rt_context *ctx, const float *faces, uint32_t size, uint32_t filter, const float *dirs, float *out, size_t n)
 {
     RT_REQUIRE(ctx && faces && dirs && out && size > 0, "bad argument");
+    RT_REQUIRE(filter == RT_CUBE_SEAMLESS || filter == RT_CUBE_FACE_CLAMP, "unknown cube-map filter");
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     DevBuf *sb = ctx->scratch;
@@ -1407,6 +1563,7 @@ int rt_debug_sample_cube(rt_context *ctx, const float *faces, uint32_t size, con
     memset(&pd, 0, sizeof pd);
     pd.env = sb[0].as<float4>();
     pd.env_size = size;
+    pd.env_filter = filter;
     k_debug_cube<<<blocks(n), PBLOCK, 0, ctx->stream>>>(pd, sb[1].as<float>(), sb[2].as<float>(), n);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, sb[2].p, n * 12, hipMemcpyDeviceToHost, ctx->stream));

@@ -89,7 +89,7 @@ int rt_launch_trace(rt_context *ctx, const rt_scene *s, const float4 *o, const f
         HIP_TRY(hipEventRecord(ctx->ev0, st));
         uint32_t *pool = ctx->pool.as<uint32_t>();
         // a fixed number of LDS stack rows whatever the depth of the tree: deeper walks continue in global rows
-        RT_TRY(rt_scene_dev_for_launch(ctx, s, rt_lds_stack_rows(ctx, s->two_level), (size_t)ctx->cu_count * 16 * TRACE_BLOCK, &sc));
+        RT_TRY(rt_scene_dev_for_launch(ctx, s, rt_lds_stack_rows(ctx), (size_t)ctx->cu_count * 16 * TRACE_BLOCK, &sc));
         if (ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST) launch_fast<RT_LDS_STACK_ROWS_TEST>(ctx, s->two_level, st, sc, src, sink, pool);
         else launch_fast<RT_LDS_STACK_ROWS>(ctx, s->two_level, st, sc, src, sink, pool);
     }

@@ -58,6 +58,10 @@ RT_DEV bool slab_hit(const RayInv &r, float lx, float hx, float ly, float hy, fl
     entry = lo;
     return lo <= hi * RT_SLAB_SLACK;
 }
+// (Plane distances as one fma each, t = fma(plane, inv, -o*inv), were built and measured in round 2: 13.5 % fewer VALU
+// instructions, no change in stage time -- the walk is bound by distinct cache lines per ray, not by VALU issue -- and
+// the rounded -o*inv leaves an ABSOLUTE error that lets rays grazing a tessellated wall pass every box of that wall
+// (4 ms tails) unless every axis carries its own margin.  profiles/r02/fma_slab_experiment.md.)
 
 RT_DEV f3 xform_point(const float *m, f3 p)
 {

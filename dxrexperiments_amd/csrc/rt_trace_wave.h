@@ -141,10 +141,19 @@ RT_DEV unsigned long long lanemask_lt()
 //                 uint32_t flags() const; };
 //   struct Sink { void store(uint32_t i, const HitD &h, bool traced) const; };
 
-template <int STACK, int BLOCK, bool TWO_LEVEL, uint32_t CHUNK, bool ANYHIT = false, class Src, class Sink>
-RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uint32_t *pool, int *smem, uint32_t *traced_counter)
+// COUNT: the walk-counting instantiation (rt_pipeline_count_walk): the same walk, plus per-lane tallies of what it
+// fetches -- 64-B slabs from global memory, slabs from the LDS-resident top, 48-B triangle records, 112-B
+// instance records -- summed into walk[0..4] = rays, global slabs, LDS slabs, triangles, instance entries; walk[5] =
+// max over rays of (node steps << 32 | ray index), the longest single walk (a tail detector).
+// These per-ray numbers depend on the ray and the tree only, not on chunking or lane assignment.
+template <int STACK, int BLOCK, bool TWO_LEVEL, uint32_t CHUNK, bool ANYHIT = false, bool COUNT = false, class Src, class Sink>
+RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uint32_t *pool, int *smem, uint32_t *traced_counter,
+                       unsigned long long *walk = nullptr)
 {
     uint32_t n_traced = 0;           // rays this lane actually traversed (statistics)
+    uint32_t wk_glob = 0, wk_top = 0, wk_tri = 0, wk_inst = 0;
+    uint32_t wk_ray0 = 0;                        // node steps tallied when the lane's current ray started
+    unsigned long long wk_longest = 0;           // (node steps << 32 | ray index) of the lane's longest walk
 #ifdef RT_TRACE_STATS
     unsigned long long st_w[4] = {0, 0, 0, 0}, st_l[4] = {0, 0, 0, 0};   // node steps, leaf phases, triangle iterations, outer iterations
     int st_maxsp = 0;
@@ -242,6 +251,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     if (TWO_LEVEL) { slabs = sc.tlas_slabs; in_blas = false; }
                     alive = true;
                     n_traced++;
+                    if (COUNT) wk_ray0 = wk_glob + wk_top;
                 } else {
                     sink.store(my, best, traced);
                 }
@@ -260,6 +270,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 #endif
         while (alive && node_is_internal(node) && sp < STACK) {
             RT_STAT_WAVE(0); RT_STAT_LANE(0);
+            if (COUNT) { if (node & RT_NODE_TOP) wk_top++; else wk_glob++; }
             node_step<false, true, ANYHIT>(slabs, topl, cur.ri, r.tmin, best.t, st, node, sp);
 #ifdef RT_TRACE_STATS
             st_maxsp = sp > st_maxsp ? sp : st_maxsp;
@@ -271,7 +282,10 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 #endif
         }
         // lanes whose stack has outgrown the LDS rows walk on with the global rows until it fits again
-        while (alive && node_is_internal(node) && sp >= STACK) node_step<true, true, ANYHIT>(slabs, topl, cur.ri, r.tmin, best.t, st, node, sp);
+        while (alive && node_is_internal(node) && sp >= STACK) {
+            if (COUNT) { if (node & RT_NODE_TOP) wk_top++; else wk_glob++; }
+            node_step<true, true, ANYHIT>(slabs, topl, cur.ri, r.tmin, best.t, st, node, sp);
+        }
 
         // ---- leaves, instance entry / exit, termination -----------------------------------
         RT_STAT_WAVE(3);
@@ -286,6 +300,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 sink.store(idx, best, true);
                 alive = false;
                 pop = false;
+                if (COUNT) { const unsigned long long w = ((unsigned long long)(wk_glob + wk_top - wk_ray0) << 32) | idx; wk_longest = w > wk_longest ? w : wk_longest; }
             } else if (TWO_LEVEL && node == RT_NODE_SENTINEL) {
                 in_blas = false;
                 slabs = sc.tlas_slabs;
@@ -293,6 +308,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
             } else if (TWO_LEVEL && !in_blas) {
                 ii = (uint32_t)~node;
                 in = sc.inst + ii;
+                if (COUNT) wk_inst++;
                 bool enter = true;
                 if (sc.n_inst == 1) {      // the lone instance box was never tested as somebody's child
                     float e;
@@ -313,6 +329,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 const uint32_t first_tri = code >> 3, cnt = (code & 7u) + 1u;
                 for (uint32_t k = 0; k < cnt; k++) {
                     RT_STAT_WAVE(2); RT_STAT_LANE(2);
+                    if (COUNT) wk_tri++;
                     const char *tp = (const char *)(tris + first_tri + k);
                     const v4f a = ldg16(tp, 0), b = ldg16(tp, 16), c = ldg16(tp, 32);
                     const uint32_t prim = __float_as_uint(c.y);
@@ -321,6 +338,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                         sink.store(idx, best, true);
                         alive = false;
                         pop = false;
+                        if (COUNT) { const unsigned long long w = ((unsigned long long)(wk_glob + wk_top - wk_ray0) << 32) | idx; wk_longest = w > wk_longest ? w : wk_longest; }
                         break;
                     }
                 }
@@ -337,6 +355,15 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
         if (st_l[k]) atomicAdd(&g_trace_stats[2 * k + 1], st_l[k]);
     }
 #endif
+    if (COUNT && walk) {
+        unsigned long long w5[5] = {n_traced, wk_glob, wk_top, wk_tri, wk_inst};
+        for (int k = 0; k < 5; k++) {
+            unsigned long long v = w5[k];
+            for (int o = 32; o > 0; o >>= 1) v += (unsigned long long)__shfl_xor((long long)v, o, 64);
+            if ((threadIdx.x & 63u) == 0u && v) atomicAdd(&walk[k], v);
+        }
+        atomicMax(&walk[5], wk_longest);
+    }
     if (traced_counter) {            // one no-return atomic per persistent wave
         for (int o = 32; o > 0; o >>= 1) n_traced += (uint32_t)__shfl_xor((int)n_traced, o, 64);
         if ((threadIdx.x & 63u) == 0u && n_traced) atomicAdd(traced_counter, n_traced);

@@ -139,6 +139,9 @@ int rt_pipeline_set_material(rt_pipeline *p, uint32_t index, const rt_material_p
  * 6 x size x size RGBA float32, D3D face order +X -X +Y -Y +Z -Z. */
 int rt_pipeline_set_environment_cube(rt_pipeline *p, const float *faces_rgba32f, uint32_t size);
 int rt_pipeline_set_environment_constant(rt_pipeline *p, const float rgb[3]);
+/* RT_CUBE_SEAMLESS (default: what TextureCube.SampleLevel does on any D3D12 device, RaytracingCommon.hlsli:152) or
+ * RT_CUBE_FACE_CLAMP */
+int rt_pipeline_set_environment_filter(rt_pipeline *p, uint32_t filter);
 /* DDS cube map, DXGI_FORMAT_R16G16B16A16_FLOAT or R32G32B32A32_FLOAT, mip 0 used */
 int rt_pipeline_load_environment_dds(rt_pipeline *p, const char *path);
 /* createOutputResource(format, w, h) (.cpp:127-149); accumulation is always fp32,
@@ -186,6 +189,10 @@ int rt_pipeline_reset_totals(rt_pipeline *p);
  * returns its node / triangle counters per stage: out[RT_STAGE_COUNT].  These are the
  * ALGORITHMIC-bytes inputs of the roofline (32 B per node, 36 B per triangle, 48 B per ray). */
 int rt_pipeline_count_work(rt_pipeline *p, rt_stage_work *out);
+/* Re-walks the ray queues of the LAST rendered frame with a counting instantiation of the PRODUCTION traversal
+ * (same tree, same order, same early exits) and returns what it fetched per stage: out[RT_STAGE_COUNT].  Outputs
+ * of the frame are rewritten with identical values.  Input of the L2-request roofline. */
+int rt_pipeline_count_walk(rt_pipeline *p, rt_stage_walk *out);
 /* per-pixel primary-hit records of the last render (tests): w*h each, may be NULL */
 int rt_pipeline_read_primary_hits(rt_pipeline *p, float *t, uint32_t *prim, uint32_t *inst);
 
@@ -251,7 +258,15 @@ int rt_image_write_png(const char *path, const float *rgba32f, uint32_t width, u
 int rt_debug_math(rt_context *ctx, int fn, const float *x, const float *y, float *out, size_t n);
 int rt_debug_sample(rt_context *ctx, int kind, const uint32_t *seeds, const float *vec3_in, float exponent,
                     float *vec3_out, float *pdf_brdf, uint32_t *seeds_out, size_t n);
-int rt_debug_sample_cube(rt_context *ctx, const float *faces_rgba32f, uint32_t size, const float *dirs, float *out, size_t n);
+int rt_debug_read_secondary_ray(rt_pipeline *p, uint32_t index, float origin_tmin[4], float dir_tmax[4]);   /* tools/longest_walk.py */
+int rt_debug_sample_cube(rt_context *ctx, const float *faces_rgba32f, uint32_t size, uint32_t filter, const float *dirs, float *out, size_t n);
+/* The DDS cube-map reader behind rt_pipeline_load_environment_dds, without a device (tests run it on the reference's
+ * own assets/textures/CathedralRadiance.dds): *size = edge length of mip 0; faces_rgba32f (may be NULL to query the
+ * size) receives 6 x size x size x 4 floats when capacity_floats is large enough, else RT_ERR_INVALID_ARG. */
+int rt_dds_read_cube(const char *path, float *faces_rgba32f, size_t capacity_floats, uint32_t *size);
+/* The OBJ reader behind rt_model_create_from_obj, without a device: counts first (verts / indices NULL), then data. */
+int rt_obj_read(const char *path, rt_vertex *verts, uint32_t capacity_verts, uint32_t *indices, uint32_t capacity_tris,
+                uint32_t *n_verts, uint32_t *n_tris);
 
 #ifdef __cplusplus
 }

@@ -113,6 +113,10 @@ typedef struct rt_bvh_node {
 #define RT_FORMAT_R32G32B32A32_FLOAT  2u   /* DXGI_FORMAT_R32G32B32A32_FLOAT */
 #define RT_FORMAT_R16G16B16A16_FLOAT  10u  /* DXGI_FORMAT_R16G16B16A16_FLOAT */
 
+/* Cube-map filtering of the environment (sampler s0: MIN_MAG_LINEAR_MIP_POINT, ProgressiveRaytracingPipeline.cpp:48-55). */
+#define RT_CUBE_SEAMLESS   0u     /* D3D10+ behaviour: bilinear taps cross face edges (default) */
+#define RT_CUBE_FACE_CLAMP 1u     /* taps clamped to the selected face */
+
 /* Accumulation modes. */
 #define RT_ACCUM_RUNNING_MEAN 0u  /* (n*prev+cur)/(n+1), ProgressiveRaytracing.hlsl:36-38 */
 #define RT_ACCUM_SUM          1u  /* prev+cur; caller divides by count (multi-GPU shards) */
@@ -148,6 +152,19 @@ typedef struct rt_stage_work {
 #define RT_STAGE_SHADOW0   2
 #define RT_STAGE_SHADOW1   3
 #define RT_STAGE_COUNT     4
+
+/* What the PRODUCTION traversal kernels fetch for one stage of the last rendered frame, tallied per lane by a
+ * counting instantiation of the same walk (rt_pipeline_count_walk): these, not the canonical counters above,
+ * are the bytes the timed kernels really request, and the input of bench.py's L2-bound roofline. */
+typedef struct rt_stage_walk {
+    uint64_t rays;               /* rays traversed                                              */
+    uint64_t slabs_global;       /* 64-B internal-node slabs loaded from global memory (L2)      */
+    uint64_t slabs_lds;          /* slabs read from the LDS-resident top table                   */
+    uint64_t tris;               /* 48-B triangle records loaded                                */
+    uint64_t instance_entries;   /* 112-B instance records visited (two-level scenes)           */
+    uint64_t longest_walk;       /* node steps of the stage's longest single ray (persistent kernels end with their slowest lane) */
+    uint64_t longest_walk_ray;   /* ... and that ray's index in its queue (last launch of the stage) */
+} rt_stage_walk;
 
 /* Status codes returned by every export. */
 #define RT_OK                 0

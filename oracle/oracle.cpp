@@ -85,9 +85,14 @@ void orc_fresnel(const float I[3], const float N[3], const float f0[3], float ou
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 
+/* cube-map filter used by orc_sample_cube / orc_render / orc_render_realtime: 1 = seamless (default), 0 = clamp to the face */
+static int g_cube_seamless = 1;
+void orc_set_cube_seamless(int on) { g_cube_seamless = on; }
+
 void orc_sample_cube(const float *faces, int size, const float *dirs, float *out, size_t n)
 {
     Env e; e.faces = faces; e.size = size; e.constant[0] = e.constant[1] = e.constant[2] = 0;
+    e.seamless = g_cube_seamless != 0;
     for (size_t i = 0; i < n; i++) {
         V3 c = sampleCube(e, v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]));
         out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
@@ -316,7 +321,7 @@ int orc_render(const orc_scene *sc, const rt_material_params *mats, uint32_t nma
     RenderCtx rc;
     rc.scene = &sc->s;
     rc.mats = mats; rc.nmats = nmats;
-    rc.env.faces = env_faces; rc.env.size = env_size;
+    rc.env.faces = env_faces; rc.env.size = env_size; rc.env.seamless = g_cube_seamless != 0;
     for (int k = 0; k < 3; k++) rc.env.constant[k] = env_constant ? env_constant[k] : 0.0f;
     rc.pfc = *pfc;
     rc.width = width; rc.height = height;
@@ -375,7 +380,7 @@ int orc_render_realtime(const orc_scene *sc, const rt_material_params *mats, uin
     RenderCtx rc;
     rc.scene = &sc->s;
     rc.mats = mats; rc.nmats = nmats;
-    rc.env.faces = env_faces; rc.env.size = env_size;
+    rc.env.faces = env_faces; rc.env.size = env_size; rc.env.seamless = g_cube_seamless != 0;
     for (int k = 0; k < 3; k++) rc.env.constant[k] = env_constant ? env_constant[k] : 0.0f;
     rc.pfc = *pfc;
     rc.width = width; rc.height = height;

@@ -32,6 +32,7 @@ void     orc_math_batch(int fn, const float *x, const float *y, float *out, size
 void     orc_sample_batch(int kind, const uint32_t *seeds, const float *vec3_in, float exponent,
                           float *vec3_out, float *pdf_brdf, uint32_t *seeds_out, size_t n);
 void     orc_fresnel(const float I[3], const float N[3], const float f0[3], float out[3]);
+void     orc_set_cube_seamless(int on);   /* 1 (default): cross-face bilinear taps; 0: taps clamped to the face */
 void     orc_sample_cube(const float *faces, int size, const float *dirs, float *out, size_t n);
 
 int  orc_obj_load(const char *path, rt_vertex **verts, uint32_t *nv, uint32_t **idx, uint32_t *nt);

@@ -27,6 +27,7 @@ struct Env {
     const float *faces;     /* 6 * size * size * 4 floats, D3D face order +X -X +Y -Y +Z -Z, or NULL */
     int size;
     float constant[3];      /* used when faces == NULL */
+    bool seamless;          /* cross-face bilinear taps (D3D10+ behaviour) */
 };
 
 struct RenderCtx {
@@ -64,9 +65,45 @@ static inline Hit trace(const PixelCtx &pc, const Ray &r, uint32_t flags)
     return h;
 }
 
-/* TextureCube.SampleLevel(linear, dir, 0): D3D major-axis face selection,
- * bilinear inside the selected face, addresses clamped to the face (the
- * cross-face taps of seamless filtering are not modelled; parity unpinned). */
+/* TextureCube.SampleLevel(linear, dir, 0) (RaytracingCommon.hlsli:152; sampler MIN_MAG_LINEAR,
+ * ProgressiveRaytracingPipeline.cpp:48-55): D3D major-axis face selection and bilinear filtering.  D3D10+
+ * devices filter cube maps seamlessly: a tap that falls off the selected face is taken from the face across
+ * that edge (seamless = true, the default); a tap that hangs over a cube CORNER has no texel and takes the
+ * mean of the other three taps of the footprint (D3D11 functional spec's suggestion; hardware differs there,
+ * parity unpinned).  seamless = false clamps the taps to the selected face.
+ *
+ * cube_edge[face][edge] with edge = x<0, x>=N, y<0, y>=N: { face across the edge, which coordinate is fixed
+ * there (0 = x, 1 = y), whether it is fixed at N-1 (else 0), whether the position along the edge is mirrored }. */
+struct CubeEdge { int face, fixed_is_y, at_max, mirrored; };
+static const CubeEdge cube_edge[6][4] = {
+    /* +X */ {{4, 0, 1, 0}, {5, 0, 0, 0}, {2, 0, 1, 1}, {3, 0, 1, 0}},
+    /* -X */ {{5, 0, 1, 0}, {4, 0, 0, 0}, {2, 0, 0, 0}, {3, 0, 0, 1}},
+    /* +Y */ {{1, 1, 0, 0}, {0, 1, 0, 1}, {5, 1, 0, 1}, {4, 1, 0, 0}},
+    /* -Y */ {{1, 1, 1, 1}, {0, 1, 1, 0}, {4, 1, 1, 0}, {5, 1, 1, 1}},
+    /* +Z */ {{1, 0, 1, 0}, {0, 0, 0, 0}, {2, 1, 1, 0}, {3, 1, 0, 0}},
+    /* -Z */ {{0, 0, 1, 0}, {1, 0, 0, 0}, {2, 1, 0, 1}, {3, 1, 1, 1}},
+};
+
+/* texel (x, y) of a face, x and y in [-1, size]; NULL when the tap hangs over a corner of the cube */
+static inline const float *cubeTexel(const Env &env, int face, int x, int y)
+{
+    const int m = env.size - 1;
+    const bool offx = x < 0 || x > m, offy = y < 0 || y > m;
+    if (!env.seamless) {
+        x = x < 0 ? 0 : (x > m ? m : x);
+        y = y < 0 ? 0 : (y > m ? m : y);
+    } else if (offx && offy) {
+        return NULL;
+    } else if (offx || offy) {
+        const CubeEdge &e = cube_edge[face][offx ? (x < 0 ? 0 : 1) : (y < 0 ? 2 : 3)];
+        const int along = offx ? y : x;
+        const int pos = e.mirrored ? m - along : along, edge = e.at_max ? m : 0;
+        face = e.face;
+        if (e.fixed_is_y) { x = pos; y = edge; } else { x = edge; y = pos; }
+    }
+    return env.faces + (((size_t)face * env.size + (size_t)y) * env.size + (size_t)x) * 4;
+}
+
 static inline V3 sampleCube(const Env &env, V3 d)
 {
     if (!env.faces) return v3(env.constant[0], env.constant[1], env.constant[2]);
@@ -84,21 +121,20 @@ static inline V3 sampleCube(const Env &env, V3 d)
     float x0f = floorf(fx), y0f = floorf(fy);
     float wx = fx - x0f, wy = fy - y0f;
     int x0 = (int)x0f, y0 = (int)y0f;
-    int x1 = x0 + 1, y1 = y0 + 1;
-    int m = env.size - 1;
-    x0 = x0 < 0 ? 0 : (x0 > m ? m : x0);
-    x1 = x1 < 0 ? 0 : (x1 > m ? m : x1);
-    y0 = y0 < 0 ? 0 : (y0 > m ? m : y0);
-    y1 = y1 < 0 ? 0 : (y1 > m ? m : y1);
-    const float *f = env.faces + (size_t)face * env.size * env.size * 4;
-    const float *c00 = f + ((size_t)y0 * env.size + x0) * 4;
-    const float *c10 = f + ((size_t)y0 * env.size + x1) * 4;
-    const float *c01 = f + ((size_t)y1 * env.size + x0) * 4;
-    const float *c11 = f + ((size_t)y1 * env.size + x1) * 4;
+    const float *tap[4] = { cubeTexel(env, face, x0, y0), cubeTexel(env, face, x0 + 1, y0),
+                            cubeTexel(env, face, x0, y0 + 1), cubeTexel(env, face, x0 + 1, y0 + 1) };
+    float corner[3] = {0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < 4; k++) {
+        if (tap[k]) continue;
+        for (int j = 0; j < 4; j++)
+            if (j != k) for (int ch = 0; ch < 3; ch++) corner[ch] = corner[ch] + tap[j][ch];
+        for (int ch = 0; ch < 3; ch++) corner[ch] = corner[ch] / 3.0f;
+        tap[k] = corner;
+    }
     float out[3];
     for (int k = 0; k < 3; k++) {
-        float top = c00[k] + (c10[k] - c00[k]) * wx;
-        float bot = c01[k] + (c11[k] - c01[k]) * wx;
+        float top = tap[0][k] + (tap[1][k] - tap[0][k]) * wx;
+        float bot = tap[2][k] + (tap[3][k] - tap[2][k]) * wx;
         out[k] = top + (bot - top) * wy;
     }
     return v3(out[0], out[1], out[2]);

@@ -56,6 +56,7 @@ def lib():
         L.orc_sample_batch.argtypes = [C.c_int, p, p, C.c_float, p, p, p, C.c_size_t]
         L.orc_fresnel.argtypes = [p, p, p, p]
         L.orc_sample_cube.argtypes = [p, C.c_int, p, p, C.c_size_t]
+        L.orc_set_cube_seamless.argtypes = [C.c_int]
         L.orc_obj_load.argtypes = [C.c_char_p, C.POINTER(p), C.POINTER(C.c_uint32), C.POINTER(p), C.POINTER(C.c_uint32)]
         L.orc_free.argtypes = [p]
         L.orc_scene_create.restype = p
@@ -125,6 +126,11 @@ def fresnel(I, N, f0):
     out = np.empty(3, np.float32)
     lib().orc_fresnel(_ptr(I), _ptr(N), _ptr(f0), _ptr(out))
     return out
+
+
+def set_cube_seamless(on=True):
+    """Cube-map filter of sample_cube / render / render_realtime: cross-face taps (default) or clamped to the face."""
+    lib().orc_set_cube_seamless(1 if on else 0)
 
 
 def sample_cube(faces, dirs):

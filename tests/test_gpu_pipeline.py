@@ -348,3 +348,44 @@ def test_sponza_1080p_sample_sharding_sum_equals_mean(sponza_pipeline, capi):
     shard_mean = (total / N).astype(np.float32)
     assert rms(shard_mean, mean) <= 1e-5
     assert np.abs(shard_mean - mean).max() <= 1e-4 * max(1.0, float(mean.max()))
+
+
+def test_count_walk_is_the_production_walk(gpu, capi):
+    """rt_pipeline_count_walk re-walks the last frame's queues with the production traversal: its ray tallies are the
+    frame's ray counts, it is repeatable, it leaves the image untouched, and a change of scene invalidates it."""
+    W, H = 160, 96
+    v, i = triangle_soup(3000, 5)
+    inst = [(0, None)]
+    p = make_gpu_pipeline(capi, gpu, [(v, i)], inst, [T.default_material()], W, H, env=scenes.sky_cubemap(16))
+    host = capi.ProgressiveHost(9)
+    cam = cam_array(dict(eye=(0, 0, 30), at=(0, 0, 0), up=(0, 1, 0), fov=0.8), W / H)
+    p.update(host.update(cam, 0.0, 1, W, H))
+    p.render()
+    img = p.read_output()
+    st = p.stats()
+    w1 = p.count_walk()
+    w2 = p.count_walk()
+    assert w1 == w2
+    assert w1["primary"]["rays"] == st["rays_primary"] == W * H
+    assert w1["secondary"]["rays"] == st["rays_secondary"]
+    assert w1["shadow0"]["rays"] + w1["shadow1"]["rays"] == st["rays_shadow"]
+    for s in w1.values():
+        assert s["instance_entries"] == 0                       # one identity instance: single-level walk
+        assert s["slabs_global"] + s["slabs_lds"] >= s["rays"] // 2 and s["tris"] > 0
+    assert w1["primary"]["slabs_lds"] > 0                       # the top of the tree is LDS resident
+    assert np.array_equal(img, p.read_output())
+    cw = p.count_work()
+    assert cw["primary"]["rays"] == W * H
+    # instanced (two-level) scene: instance entries are counted
+    xf = random_xforms(5, 3)
+    p2 = make_gpu_pipeline(capi, gpu, [(v, i)], [(0, xf[k]) for k in range(5)], [T.default_material()] * 5, W, H)
+    p2.update(host.update(cam, 0.0, 2, W, H))
+    p2.render()
+    w = p2.count_walk()
+    assert w["primary"]["instance_entries"] > 0 and w["primary"]["rays"] == W * H
+    # stale state is refused, not replayed (ADVICE r1: last_pd held raw device pointers)
+    p2.add_material(T.default_material())
+    with pytest.raises(capi.RtError):
+        p2.count_walk()
+    with pytest.raises(capi.RtError):
+        p2.count_work()

@@ -1,13 +1,26 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): kernel-trace stats, then FETCH_SIZE and WRITE_SIZE in
-# separate PMC passes (they do not fit one pass on gfx950), each around the same bench command.
-# usage: tools/run_profiles.sh <tag>     -> gpurun_out/prof_<tag>_{kt,fetch,write}/
-TAG=${1:-r01}
+# Runs on the GPU box (via gpurun): for each workload (c2 = the bench default, c5 = the HBM-bound 10 M-triangle one)
+# a kernel-trace pass and separate PMC passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950; SQ and TCC
+# sets in passes of their own), each around the same bench command.
+# usage: tools/run_profiles.sh <tag> [workloads...]    -> gpurun_out/<tag>/<workload>_<pass>.md (+ .log)
+TAG=${1:-r02}; shift
+WL=${@:-c2 c5}
 R=$PWD
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_kt -o kt --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --cpu-seconds 0 > $R/gpurun_out/prof_${TAG}_kt.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/prof_${TAG}_fetch -o pmc --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-seconds 0 --no-roofline > $R/gpurun_out/prof_${TAG}_fetch.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/prof_${TAG}_write -o pmc --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-seconds 0 --no-roofline > $R/gpurun_out/prof_${TAG}_write.log 2>&1
-cd $R
-for k in kt fetch write; do python3 tools/profile_summary.py gpurun_out/prof_${TAG}_$k "rocprofv3 $k pass: python3 bench.py (1080p Sponza-class)" > gpurun_out/prof_${TAG}_$k.md; rm -f gpurun_out/prof_${TAG}_$k/*/*kernel_trace.csv gpurun_out/prof_${TAG}_$k/*kernel_trace.csv; done
-for f in gpurun_out/prof_${TAG}_*.log; do tail -n 1 $f; done
+for w in $WL; do
+  if [ $w = c2 ]; then ARGS="--steps 8 --warmup 2 --cpu-seconds 0 --hbm-frames 0"; else ARGS="--workload c5 --hbm-frames 4"; fi
+  run() {   # name, rocprof options...
+    n=$1; shift
+    timeout 600 rocprofv3 "$@" -d $OUT/${w}_$n -o p --output-format csv -- python3 $R/bench.py $ARGS > $OUT/${w}_$n.log 2>&1
+    python3 $R/tools/profile_summary.py $OUT/${w}_$n "rocprofv3 $* -- python3 bench.py $ARGS" > $OUT/${w}_$n.md
+    rm -rf $OUT/${w}_$n
+    tail -n 1 $OUT/${w}_$n.log | cut -c 1-300
+  }
+  run kt --kernel-trace --stats
+  run fetch --kernel-trace --pmc FETCH_SIZE
+  run write --kernel-trace --pmc WRITE_SIZE
+  run tcc --kernel-trace --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
+  run sq --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
+done

@@ -1,40 +1,67 @@
 #!/usr/bin/env python3
-"""profiles/<round>/pmc_fetch_size.md + pmc_write_size.md -> profiles/<round>/traffic.json
-(HBM-side bytes per launch of the traversal kernels, the `roofline.traffic` figure bench.py reports).
+"""profiles/<round>/{c2,c5}_{kt,fetch,write,tcc,sq}.md -> profiles/<round>/traffic.json: per workload and traversal kernel
+the memory-side bytes per launch (`roofline.traffic` in bench.py), the rocprofv3 average duration and the SQ / TCC counters.
 
-usage: tools/traffic_from_pmc.py profiles/r01
+usage: tools/traffic_from_pmc.py profiles/r02
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies 128-B read requests at 64 B, so it
 is doubled; WRITE_SIZE is exact; rocprofv3 reports both in KiB; Infinity-Cache hits are included."""
 import json
+import os
 import re
 import subprocess
 import sys
 
+KERNELS = ("k_primary", "k_trace_secondary", "k_trace_shadow")
 
-def val(path, kernel, counter):
+
+def rows(path):
+    """{(kernel, column-or-counter): value} of a profile_summary.py table file."""
+    out = {}
+    if not os.path.isfile(path):
+        return out
     for line in open(path):
-        m = re.match(r"\| %s \| %s \| (\d+) \| ([\d.]+) \|" % (re.escape(kernel), counter), line)
-        if m:
-            return int(m.group(1)), float(m.group(2))
-    raise KeyError((kernel, counter))
+        c = [x.strip() for x in line.strip().strip("|").split("|")]
+        if len(c) == 4 and re.match(r"^[\d.]+$", c[3] or "x"):             # | kernel | counter | dispatches | avg |
+            out[(c[0], c[1])] = float(c[3])
+            out[(c[0], c[1] + ":n")] = float(c[2])
+        elif len(c) == 7 and re.match(r"^[\d.]+$", c[3] or "x"):           # | kernel | calls | total ms | avg us | ...
+            out[(c[0], "avg_us")] = float(c[3])
+            out[(c[0], "calls")] = float(c[1])
+    return out
 
 
 def main():
     d = sys.argv[1].rstrip("/")
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes around `python3 bench.py --steps 4 --warmup 1 "
-                     "--no-roofline` (%s/pmc_fetch_size.md, pmc_write_size.md; tools/run_profiles.sh)" % d,
+    out = {"source": "rocprofv3 passes of tools/run_profiles.sh around `python3 bench.py` (c2: --steps 8; c5: --workload c5 --hbm-frames 4); "
+                     "one .md per pass in %s" % d,
            "correction": "gfx950: FETCH_SIZE counts 128-B read requests as 64 B -> doubled; WRITE_SIZE exact; both KiB; "
                          "Infinity-Cache hits are included (MI355X_MICROARCH.md, HBM section)",
            "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, text=True).stdout.strip(),
-           "kernels": {}}
-    for k in ("k_primary", "k_trace_secondary", "k_trace_shadow"):
-        nf, f = val(d + "/pmc_fetch_size.md", k, "FETCH_SIZE")
-        _, w = val(d + "/pmc_write_size.md", k, "WRITE_SIZE")
-        out["kernels"][k] = {"fetch_size_kib_per_launch": f, "write_size_kib_per_launch": w, "dispatches": nf,
-                             "bytes_per_launch": int((2.0 * f + w) * 1024)}
+           "workloads": {}}
+    for w in ("c2", "c5"):
+        kt, fe, wr = rows("%s/%s_kt.md" % (d, w)), rows("%s/%s_fetch.md" % (d, w)), rows("%s/%s_write.md" % (d, w))
+        tcc, sq = rows("%s/%s_tcc.md" % (d, w)), rows("%s/%s_sq.md" % (d, w))
+        if not fe:
+            continue
+        ks = {}
+        for k in KERNELS:
+            if (k, "FETCH_SIZE") not in fe:
+                continue
+            f, wv = fe[(k, "FETCH_SIZE")], wr.get((k, "WRITE_SIZE"), 0.0)
+            e = {"fetch_size_kib_per_launch": f, "write_size_kib_per_launch": wv, "dispatches": int(fe[(k, "FETCH_SIZE:n")]),
+                 "bytes_per_launch": int((2.0 * f + wv) * 1024)}
+            if (k, "avg_us") in kt:
+                e["avg_us"] = kt[(k, "avg_us")]
+                e["GBps"] = e["bytes_per_launch"] / (e["avg_us"] * 1e-6) / 1e9
+            for src in (tcc, sq):
+                for (kk, c), v in src.items():
+                    if kk == k and not c.endswith(":n"):
+                        e[c] = v
+            ks[k] = e
+        out["workloads"][w] = {"kernels": ks}
     with open(d + "/traffic.json", "w") as fp:
         json.dump(out, fp, indent=1)
-    print(json.dumps(out["kernels"], indent=1))
+    print(json.dumps(out["workloads"], indent=1))
 
 
 main()
