@@ -145,7 +145,7 @@ namespace DXRFramework
         static SharedPtr create() { return SharedPtr(new RtScene()); }
         ~RtScene() { if (mHandle) rt_scene_destroy(mHandle); }
 
-        void addModel(RtModel::SharedPtr model, const Matrix &transform) { mInstances.push_back({model, transform}); mDirty = true; }
+        void addModel(RtModel::SharedPtr model, const Matrix &transform) { mInstances.push_back({model, transform}); }
         RtModel::SharedPtr getModel(uint32_t index) const { return mInstances[index].model; }
         uint32_t getNumInstances() const { return static_cast<uint32_t>(mInstances.size()); }
 
@@ -161,23 +161,25 @@ namespace DXRFramework
     private:
         RtScene() = default;
         struct Node { RtModel::SharedPtr model; Matrix transform; };
+        // ONE rt_scene handle per RtScene for its whole life (a pipeline that was given the handle by setScene keeps
+        // seeing the scene the caller keeps editing, as with the reference's shared RtScene object): instances added
+        // since the last call are appended to it
         void realize(RtContext::SharedPtr context)
         {
-            if (mHandle && !mDirty) return;
-            if (mHandle) { rt_scene_destroy(mHandle); mHandle = nullptr; }
-            ThrowIfFailed(rt_scene_create(context->getHandle(), &mHandle));
-            for (const Node &n : mInstances) {
-                float x[12];
-                n.transform.toInstanceTransform(x);
-                ThrowIfFailed(rt_scene_add_model(mHandle, n.model->getHandle(), x));
+            if (!mHandle) {
+                ThrowIfFailed(rt_scene_create(context->getHandle(), &mHandle));
+                mContext = context;
             }
-            mContext = context;
-            mDirty = false;
+            for (; mRealized < mInstances.size(); mRealized++) {
+                float x[12];
+                mInstances[mRealized].transform.toInstanceTransform(x);
+                ThrowIfFailed(rt_scene_add_model(mHandle, mInstances[mRealized].model->getHandle(), x));
+            }
         }
         std::vector<Node> mInstances;
         RtContext::SharedPtr mContext;
         rt_scene *mHandle = nullptr;
-        bool mDirty = true;
+        size_t mRealized = 0;
     };
 
     // ---- RtProgram (RtProgram.h:17-123): a description of which built-in entry points are used ----
@@ -313,7 +315,13 @@ namespace DXRFramework
             return SharedPtr(new RtBindings(context, program, scene));
         }
 
-        const RtParams::SharedPtr &getHitVars(uint32_t rayID, uint32_t meshID) { return mHitParams[rayID][meshID]; }
+        // (the table grows when instances were added to the scene after the bindings were made)
+        const RtParams::SharedPtr &getHitVars(uint32_t rayID, uint32_t meshID)
+        {
+            auto &perRay = mHitParams.at(rayID);
+            while (perRay.size() <= meshID) perRay.push_back(RtParams::create(32));
+            return perRay[meshID];
+        }
         const RtParams::SharedPtr &getRayGenVars() { return mRayGenParams; }
         const RtParams::SharedPtr &getMissVars(uint32_t rayID) { return mMissParams[rayID]; }
         const RtProgram::SharedPtr &getProgram() { return mProgram; }

@@ -77,6 +77,19 @@ int main(int argc, char **argv)
             std::fwrite(three.data(), 4, three.size(), g);
             std::fclose(g);
         }
+        // addModel AFTER setScene: the pipeline holds the same scene handle, so a rebuild through the
+        // pipeline renders the new instance too (the reference builds through the RtScene object the pipeline holds)
+        {
+            scene->addModel(RtModel::create(context, argv[1]), Matrix::translation(0.6f, 0.0f, 0.0f));
+            if (scene->getNumInstances() != 2) return 9;
+            pipeline->addMaterial(material);
+            pipeline->buildAccelerationStructures();
+            pipeline->update(0.0f, 9, 0, 0, W, H);
+            pipeline->render(0, W, H);
+            std::vector<float> again(image.size());
+            static_cast<ProgressiveRaytracingPipeline *>(pipeline.get())->readOutput(again.data(), again.size() * 4);
+            if (again == image) return 10;
+        }
         std::printf("wrapper ok\n");
     } catch (const std::exception &e) {
         std::fprintf(stderr, "error: %s\n", e.what());

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep (run by hand on a GPU box, not collected by pytest):
+"""Randomised parity sweep.  tests/test_gpu_fuzz.py runs a bounded number of draws of it under `pytest -m gpu`;
+by hand, on a GPU box, for as long as wanted:
 
     python tests/fuzz_parity.py [iterations] [seed]
 
@@ -54,18 +55,18 @@ def draw(r):
     return models, inst, mats
 
 
-def main():
-    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def run(iters, seed, ctx, verbose=True):
+    """Returns None when every draw was bit-exact, else a description of the first mismatch."""
     r = np.random.default_rng(seed)
-    ctx = capi.Context(0)
     for it in range(iters):
         models, inst, mats = draw(r)
         W, H = int(r.integers(8, 200)), int(r.integers(8, 120))
         realtime = r.random() < 0.3
         depth = (int(r.integers(0, 5)), int(r.integers(0, 5)))
         env = scenes.sky_cubemap(int(r.choice([4, 8, 16]))) if r.random() < 0.5 else None
-        desc = dict(it=it, tris=[int(m[1].shape[0]) for m in models], instances=len(inst), size=(W, H), realtime=realtime, depth=depth)
+        seamless = bool(r.random() < 0.7)
+        desc = dict(it=it, tris=[int(m[1].shape[0]) for m in models], instances=len(inst), size=(W, H), realtime=realtime, depth=depth,
+                    seamless=seamless)
         sc = capi.Scene(ctx)
         gm = [capi.Model(ctx, v, i) for v, i in models]
         osc = oracle.Scene()
@@ -81,6 +82,8 @@ def main():
             p.add_material(m)
         if env is not None:
             p.set_environment_cube(env)
+        p.set_environment_filter(seamless)
+        oracle.set_cube_seamless(seamless)
         p.create_output(W, H)
         p.build_acceleration_structures()
         p.set_depth_limits(*depth)
@@ -107,11 +110,23 @@ def main():
             gst = p.stats()
             same = all(gst[k] == ost[k] for k in ("rays_primary", "rays_secondary", "rays_shadow", "primary_hits", "secondary_hits"))
             if not (ok and same):
-                print("MISMATCH", desc, "frame", f, "image equal:", ok, "gpu", {k: gst[k] for k in ost if k in gst}, "oracle", ost)
-                sys.exit(1)
-        if it % 10 == 0:
+                oracle.set_cube_seamless(True)
+                return "MISMATCH %r frame %d image equal: %s gpu %r oracle %r" % (desc, f, ok, {k: gst[k] for k in ost if k in gst}, ost)
+        if verbose and it % 10 == 0:
             print("ok", desc, flush=True)
+    oracle.set_cube_seamless(True)
+    return None
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    bad = run(iters, seed, capi.Context(0))
+    if bad:
+        print(bad)
+        sys.exit(1)
     print("fuzz parity: %d iterations, seed %d, all bit-exact" % (iters, seed))
 
 
-main()
+if __name__ == "__main__":
+    main()

@@ -85,4 +85,19 @@ def test_cube_sampling_bit_exact(gpu, oracle):
     d = r.standard_normal((1 << 16, 3)).astype(np.float32)
     d[:8] = [[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [1, 1, 1], [0, 0, 0]]
     d[8] = [np.nan, 0, 1]
-    assert same_bits(gpu.sample_cube(faces, d), oracle.sample_cube(faces, d))
+    # footprints over edges and corners of the cube, where the two filters differ
+    e = r.uniform(-1, 1, (4096, 3)).astype(np.float32)
+    e[:, 0] = np.where(r.uniform(size=4096) < 0.5, 1.0, -1.0)
+    e[:, 1] = np.sign(e[:, 1]) * (1.0 - r.uniform(0, 0.06, 4096))
+    e[2048:, 2] = np.sign(e[2048:, 2]) * (1.0 - r.uniform(0, 0.06, 2048))
+    e = e[:, r.permutation(3)] if False else np.concatenate([e, e[:, [1, 2, 0]], e[:, [2, 0, 1]]])
+    d = np.concatenate([d, e.astype(np.float32)])
+    import os
+    cath = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cathedral32.npz"))["faces32"]
+    for fc in (faces, cath):
+        for seamless in (True, False):
+            oracle.set_cube_seamless(seamless)
+            want = oracle.sample_cube(fc, d)
+            oracle.set_cube_seamless(True)
+            assert same_bits(gpu.sample_cube(fc, d, seamless=seamless), want), "seamless=%s" % seamless
+    assert not same_bits(gpu.sample_cube(faces, d, seamless=True), gpu.sample_cube(faces, d, seamless=False))

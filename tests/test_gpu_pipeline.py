@@ -389,3 +389,39 @@ def test_count_walk_is_the_production_walk(gpu, capi):
         p2.count_walk()
     with pytest.raises(capi.RtError):
         p2.count_work()
+
+
+def test_cornell_lit_by_the_reference_environment_map(gpu, capi, tmp_path):
+    """A Cornell frame lit by the committed 32^2 down-sample of the reference's CathedralRadiance.dds
+    (ProgressiveRaytracingPipeline.cpp:114-118) against the committed oracle images, for both cube filters, through the
+    array entry point and through a DDS file; no oracle at run time."""
+    import struct
+    g = np.load(GOLDEN + "/cathedral32.npz")
+    faces = g["faces32"]
+    path = str(tmp_path / "cathedral32.dds")
+    hdr = struct.pack("<4sI", b"DDS ", 124) + struct.pack("<IIIIII", 0x1007, 32, 32, 32 * 16, 0, 1) + b"\0" * 44
+    hdr += struct.pack("<II4sIIIII", 32, 4, b"DX10", 0, 0, 0, 0, 0) + struct.pack("<IIIII", 0x1008, 0xFE00, 0, 0, 0)
+    hdr += struct.pack("<IIIII", 2, 3, 4, 1, 0)
+    with open(path, "wb") as f:
+        f.write(hdr + faces.astype(np.float32).tobytes())
+    assert np.array_equal(capi.dds_read_cube(path), faces)
+    m = capi.Model(gpu, path=CORNELL_OBJ)
+    for via_dds in (False, True):
+        sc = capi.Scene(gpu)
+        sc.add_model(m)
+        p = capi.Pipeline(gpu)
+        p.set_scene(sc)
+        p.add_material(T.default_material())
+        if via_dds:
+            p.load_environment_dds(path)
+        else:
+            p.set_environment_cube(faces)
+        p.create_output(64, 64)
+        p.build_acceleration_structures()
+        for seamless, key in ((True, "cornell_lit"), (False, "cornell_lit_clamp")):
+            p.set_environment_filter(seamless)
+            p.clear_output()
+            p.update(g["cornell_pfc"])
+            p.render()
+            assert np.array_equal(p.read_output(), g[key]), "via_dds=%s seamless=%s" % (via_dds, seamless)
+    assert not np.array_equal(g["cornell_lit"], g["cornell_lit_clamp"])

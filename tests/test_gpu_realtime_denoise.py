@@ -196,3 +196,25 @@ def test_structures_fixture_without_the_oracle(gpu, capi):
     dn.create_output(64, 64)
     dn.dispatch(p.output_device_ptr(0), p.output_device_ptr(1))
     assert np.array_equal(dn.read_output(), g["denoised"])
+
+
+def test_denoiser_on_the_reference_mock_inputs(gpu, capi):
+    """The reference's own denoiser test inputs (crops of assets/textures/DirectLighting.PNG and IndirectSpecular.PNG,
+    loaded by DenoiseCompositor::loadResources(loadMockResources), src/DenoiseCompositor.cpp:52-68): both passes equal
+    the committed oracle composite; no oracle at run time."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "denoise_mock.npz"))
+    H, W = g["direct_rgba8"].shape[:2]
+    direct = np.ones((H, W, 4), np.float32)
+    indirect = np.ones((H, W, 4), np.float32)
+    direct[..., :g["direct_rgba8"].shape[2]] = g["direct_rgba8"].astype(np.float32) / np.float32(255.0)
+    indirect[..., :g["indirect_rgba8"].shape[2]] = g["indirect_rgba8"].astype(np.float32) / np.float32(255.0)
+    dn = capi.Denoiser(gpu)
+    dn.create_output(W, H)
+    want = np.frombuffer(g["denoise_params"].tobytes(), capi.DENOISER_PARAMS)[0]
+    for k in capi.DENOISER_PARAMS.names:
+        dn.params[k] = want[k]
+    td, ti = gpu.upload(direct), gpu.upload(indirect)
+    dn.dispatch(td.ptr, ti.ptr)
+    assert np.array_equal(dn.read_intermediate(), g["pass_h"])
+    assert np.array_equal(dn.read_output(), g["composite"])

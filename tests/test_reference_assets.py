@@ -1,0 +1,201 @@
+"""What the reference's own data files can pin.
+
+The reference ships no tests, but it does hold the files its default scene is made of:
+  assets/textures/CathedralRadiance.dds   the environment map (src/ProgressiveRaytracingPipeline.cpp:114-118,
+                                          sampled at assets/shaders/RaytracingCommon.hlsli:152)
+  assets/models/susanne.obj, cornell.obj  meshes for RtModel::create (libs/DXRFramework/RtModel.cpp:24-82)
+  assets/textures/DirectLighting.PNG, IndirectSpecular.PNG   the denoiser's own test inputs
+                                          (DenoiseCompositor::loadResources, src/DenoiseCompositor.cpp:52-68)
+tests/golden/reference_assets.json holds what an INDEPENDENT reading of those files gives (readers written in
+tests/golden/make_fixtures.py, sharing no code with the product or the oracle).  Here the product's device-free
+readers (rt_dds_read_cube, rt_obj_read) and the oracle's are run on the real files when the checkout is present
+(the build container) and, always, on the committed re-emitted meshes."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from util import GOLDEN
+
+REF = "/root/reference/assets"
+have_ref = pytest.mark.skipif(not os.path.isdir(REF), reason="the reference checkout is not on this machine")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def pins():
+    with open(os.path.join(GOLDEN, "reference_assets.json")) as f:
+        return json.load(f)
+
+
+def flat(v):
+    return np.concatenate([v["position"], v["normal"]], 1)
+
+
+@have_ref
+def test_product_dds_reader_on_the_reference_environment_map(capi, pins):
+    p = pins["CathedralRadiance.dds"]
+    faces = capi.dds_read_cube(REF + "/textures/CathedralRadiance.dds")
+    assert faces.shape == (6, p["width"], p["width"], 4) and p["mips"] == 7 and p["dxgi_format"] == 10
+    assert sha(faces) == p["mip0_fp32_sha256"]
+    for f, y, x, *rgba in p["probes"]:
+        assert np.array_equal(faces[f, y, x], np.array(rgba, np.float32))
+    # a second reference-held cube map (128^2, one mip) goes through the same reader
+    irr = capi.dds_read_cube(REF + "/textures/CathedralIrradiance.dds")
+    assert irr.shape == (6, 128, 128, 4) and np.isfinite(irr).all() and irr[..., 3].min() == 1.0
+
+
+@have_ref
+def test_cube_adjacency_against_the_reference_map(capi, oracle, pins):
+    """CathedralRadiance.dds was exported with edge fix-up: every edge row equals the neighbouring face's (checked
+    geometrically by make_fixtures.py: edge_fixup_max_abs_diff = 0).  On such a map seamless filtering -- taps taken
+    from the face across the edge through the oracle's adjacency table -- must equal face-clamped filtering for every
+    direction whose footprint hangs over ONE edge; a wrong table entry would show up as a difference."""
+    assert pins["CathedralRadiance.dds"]["edge_fixup_max_abs_diff"] == 0.0
+    faces = capi.dds_read_cube(REF + "/textures/CathedralRadiance.dds")
+    n = faces.shape[1]
+    r = np.random.default_rng(3)
+    dirs = []
+    for axis in range(3):                      # footprints over every edge: two coordinates nearly equal in magnitude
+        for other in range(3):
+            if other == axis:
+                continue
+            third = 3 - axis - other
+            for sa in (1, -1):
+                for so in (1, -1):
+                    d = np.zeros((400, 3))
+                    d[:, axis] = sa
+                    d[:, other] = so * (1.0 - r.uniform(0.0, 0.9 / n, 400))         # within half a texel of the edge
+                    d[:, third] = r.uniform(-0.97, 0.97, 400)                      # away from the corners
+                    dirs.append(d)
+    dirs = np.concatenate(dirs).astype(np.float32)
+    oracle.set_cube_seamless(True)
+    a = oracle.sample_cube(faces, dirs)
+    oracle.set_cube_seamless(False)
+    b = oracle.sample_cube(faces, dirs)
+    oracle.set_cube_seamless(True)
+    assert np.array_equal(a, b)
+    # ... and on a map WITHOUT fix-up the two filters do differ there (the test above is not vacuous)
+    from dxrexperiments_amd import scenes
+    sky = scenes.sky_cubemap(n)
+    a = oracle.sample_cube(sky, dirs)
+    oracle.set_cube_seamless(False)
+    b = oracle.sample_cube(sky, dirs)
+    oracle.set_cube_seamless(True)
+    assert np.abs(a - b).max() > 1e-4
+
+
+@have_ref
+@pytest.mark.parametrize("name", ["susanne.obj", "cornell.obj"])
+def test_obj_readers_on_the_reference_meshes(capi, oracle, pins, name):
+    p = pins[name]
+    for reader in (capi.obj_read, oracle.obj_load):
+        v, t = reader(REF + "/models/" + name)
+        assert (v.shape[0], t.shape[0]) == (p["n_verts"], p["n_tris"])
+        assert sha(flat(v)) == p["verts_sha256"] and sha(t) == p["indices_sha256"]
+
+
+@pytest.mark.parametrize("name", ["susanne.obj", "cornell.obj"])
+def test_obj_readers_on_the_committed_meshes(capi, oracle, pins, name):
+    """The re-emitted meshes under tests/golden ingest to the same arrays as the reference's files."""
+    p = pins[name]
+    for reader in (capi.obj_read, oracle.obj_load):
+        v, t = reader(os.path.join(GOLDEN, name))
+        assert sha(flat(v)) == p["verts_sha256"] and sha(t) == p["indices_sha256"]
+
+
+def test_obj_reader_edge_cases(capi, tmp_path):
+    """lines longer than any fixed buffer, and relative indices that resolve below zero."""
+    p = tmp_path / "long.obj"
+    n = 3000                                         # one 3000-gon: a single 'f' record of ~40 KB
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    with open(p, "w") as f:
+        for a in ang:
+            f.write("v %.9g %.9g 0\n" % (np.cos(a), np.sin(a)))
+        f.write("vn 0 0 1\n")
+        f.write("f " + " ".join("%d//1" % (k + 1) for k in range(n)) + "\n")
+    v, t = capi.obj_read(str(p))
+    assert t.shape == (n - 2, 3) and v.shape[0] == n
+    assert np.array_equal(t[:, 0], np.zeros(n - 2, np.uint32)) and np.array_equal(t[:, 1], np.arange(1, n - 1, dtype=np.uint32))
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//-5 2//1 3//1\n")       # -5 resolves below the first normal
+    with pytest.raises(capi.RtError):
+        capi.obj_read(str(bad))
+    bad.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf -9 2 3\n")
+    with pytest.raises(capi.RtError):
+        capi.obj_read(str(bad))
+    nonl = tmp_path / "nonl.obj"
+    nonl.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3")                              # no newline at the end of the file
+    v, t = capi.obj_read(str(nonl))
+    assert t.shape == (1, 3) and abs(float(v["normal"][0][2]) - 1.0) < 1e-6            # generated normal
+
+
+def test_dds_reader_rejects_hostile_headers(capi, tmp_path):
+    """a crafted width must not wrap the size arithmetic."""
+    import struct
+    def header(width, mips):
+        h = struct.pack("<4sI", b"DDS ", 124) + struct.pack("<IIIIII", 0x1007, width, width, 0, 0, mips) + b"\0" * 44
+        h += struct.pack("<II4sIIIII", 32, 4, b"DX10", 0, 0, 0, 0, 0) + struct.pack("<IIIII", 0x401008, 0xFE00, 0, 0, 0)
+        return h + struct.pack("<IIIII", 10, 3, 4, 1, 0)
+    for width, mips in (((1 << 30) + 4, 1), (1 << 31, 1), (64, 4000), (70000, 1)):
+        p = tmp_path / "evil.dds"
+        p.write_bytes(header(width, mips) + b"\0" * 4096)
+        with pytest.raises(capi.RtError):
+            capi.dds_read_cube(str(p))
+    p = tmp_path / "short.dds"
+    p.write_bytes(header(64, 1) + b"\0" * 100)
+    with pytest.raises(capi.RtError):
+        capi.dds_read_cube(str(p))
+
+
+def test_oracle_environment_on_the_cathedral_fixture(oracle):
+    """The oracle's sampleEnvironment restatement on the committed down-sample of the reference's map reproduces the
+    committed values (generated on the full-size map in make_fixtures.py is a separate, larger check: here the 32^2 one)."""
+    g = np.load(os.path.join(GOLDEN, "cathedral32.npz"))
+    f = g["faces32"]
+    assert f.shape == (6, 32, 32, 4) and np.isfinite(f).all()
+    # RMS recorded when the fixture was made: the size of the deviation between the two filters on a Cornell frame
+    pins = json.load(open(os.path.join(GOLDEN, "reference_assets.json")))["CathedralRadiance.dds"]
+    d = (g["cornell_lit"].astype(np.float64) - g["cornell_lit_clamp"].astype(np.float64))[..., :3]
+    assert abs(float(np.sqrt(np.mean(d ** 2))) - pins["cornell64_rms_seamless_vs_face_clamp"]) < 1e-12
+    assert pins["env_probe_max_abs_seamless_vs_face_clamp"] == 0.0          # on the fixed-up full-size map: identical
+    from dxrexperiments_amd import rtypes as T
+    from util import CORNELL_OBJ
+    v, tri = oracle.obj_load(CORNELL_OBJ)
+    sc = oracle.Scene()
+    sc.add_instance(sc.add_model(v, tri))
+    sc.build()
+    for mode, key in ((True, "cornell_lit"), (False, "cornell_lit_clamp")):
+        oracle.set_cube_seamless(mode)
+        img, _ = sc.render(T.default_material(), g["cornell_pfc"], 64, 64, env_faces=f, nthreads=4)
+        oracle.set_cube_seamless(True)
+        assert np.array_equal(img, g[key])
+
+
+@have_ref
+def test_oracle_environment_on_the_full_size_map(capi, oracle):
+    g = np.load(os.path.join(GOLDEN, "cathedral32.npz"))
+    faces = capi.dds_read_cube(REF + "/textures/CathedralRadiance.dds")
+    for mode, key in ((True, "env_seamless"), (False, "env_clamp")):
+        oracle.set_cube_seamless(mode)
+        got = oracle.sample_cube(faces, g["dirs"])
+        oracle.set_cube_seamless(True)
+        assert np.array_equal(got, g[key])
+
+
+def test_oracle_denoiser_on_the_reference_mock_inputs(oracle):
+    """DenoiseCompositor's own test inputs (crops): the oracle reproduces the committed composite."""
+    g = np.load(os.path.join(GOLDEN, "denoise_mock.npz"))
+    direct = np.ones((144, 256, 4), np.float32)
+    indirect = np.ones((144, 256, 4), np.float32)
+    direct[..., :g["direct_rgba8"].shape[2]] = g["direct_rgba8"].astype(np.float32) / np.float32(255.0)
+    indirect[..., :g["indirect_rgba8"].shape[2]] = g["indirect_rgba8"].astype(np.float32) / np.float32(255.0)
+    params = np.frombuffer(g["denoise_params"].tobytes(), oracle.DENOISE_PARAMS)[0]
+    h, final = oracle.denoise(direct, indirect, params)
+    assert np.array_equal(h, g["pass_h"]) and np.array_equal(final, g["composite"])
+    assert g["direct_rgba8"].std() > 10 and g["indirect_rgba8"].std() > 5      # real image content, not a flat crop
