@@ -13,8 +13,8 @@
 //   3. ascending radix sort of the 62-bit keys
 //   4. Karras 2012 binary radix tree over the sorted keys (integer only)
 //   5. bottom-up AABB union (exact float min/max; order independent)
-//   6. traversal layout: 64-B two-child slabs, subtrees of <= leaf_max primitives
-//      collapsed into leaves, triangles gathered in sorted order.
+//   6. traversal layout (rt_bvh_ploc.hip, rt_bvh_wide.hip): a better binary tree over the same leaves,
+//      collapsed into four-wide 64-B nodes; subtrees of <= leaf_max primitives become leaves.
 #include "rt_internal.h"
 
 #include <chrono>
@@ -245,44 +245,6 @@ __global__ void k_refit_decode(const uint32_t *__restrict__ enc, rt_bvh_node *__
     }
 }
 
-__device__ __forceinline__ int child_code(uint32_t c, uint32_t n, const uint2 *__restrict__ ranges, uint32_t leaf_max,
-                                          const rt_bvh_node *__restrict__ nodes, bool tlas)
-{
-    if (c >= n - 1) {   // canonical leaf
-        uint32_t k = c - (n - 1);
-        return tlas ? ~(int)nodes[c].left : ~(int)((k << 3) | 0u);
-    }
-    uint2 r = ranges[c];
-    uint32_t cnt = r.y - r.x + 1;
-    if (!tlas && cnt <= leaf_max) return ~(int)((r.x << 3) | (cnt - 1));
-    return (int)c;
-}
-
-__global__ void k_layout(const rt_bvh_node *__restrict__ nodes, const uint2 *__restrict__ ranges, uint32_t n,
-                         uint32_t leaf_max, int tlas, Slab *__restrict__ slabs)
-{
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1) return;
-    rt_bvh_node nd = nodes[i];
-    rt_bvh_node a = nodes[nd.left];
-    rt_bvh_node b = nodes[nd.right];
-    // child slot 0 = the child with the larger surface: any-hit rays walk unordered and try it first (rt_bvh_ploc.hip)
-    const float ax = a.bmax[0] - a.bmin[0], ay = a.bmax[1] - a.bmin[1], az = a.bmax[2] - a.bmin[2];
-    const float bx = b.bmax[0] - b.bmin[0], by = b.bmax[1] - b.bmin[1], bz = b.bmax[2] - b.bmin[2];
-    if (bx * by + by * bz + bz * bx > ax * ay + ay * az + az * ax) {
-        const rt_bvh_node t = a; a = b; b = t;
-        const uint32_t tl = nd.left; nd.left = nd.right; nd.right = tl;
-    }
-    Slab s;
-    s.q0 = make_float4(a.bmin[0], a.bmax[0], a.bmin[1], a.bmax[1]);
-    s.q1 = make_float4(b.bmin[0], b.bmax[0], b.bmin[1], b.bmax[1]);
-    s.q2 = make_float4(a.bmin[2], a.bmax[2], b.bmin[2], b.bmax[2]);
-    int c0 = child_code(nd.left, n, ranges, leaf_max, nodes, tlas != 0);
-    int c1 = child_code(nd.right, n, ranges, leaf_max, nodes, tlas != 0);
-    s.q3 = make_float4(__int_as_float(c0), __int_as_float(c1), 0.0f, 0.0f);
-    slabs[i] = s;
-}
-
 __global__ void k_gather_tris(const uint64_t *__restrict__ keys, const rt_vertex *__restrict__ verts,
                               const uint32_t *__restrict__ idx, uint32_t n, TriRec *__restrict__ tris)
 {
@@ -312,8 +274,10 @@ int take_build_temps(rt_context *ctx, uint32_t n, BuildTemps &t)
     const size_t want[7] = {up(sizeof(Box6) * (size_t)n), A, A, up(8 * (size_t)n), up(16 * (size_t)n + (4u << 20)), up(24 * (size_t)n), A};
     size_t lbvh = 0;
     for (size_t w : want) lbvh += w;
-    const size_t ploc = rt_ploc_temp_bytes(n);
-    RT_TRY(ctx->build_arena.reserve(lbvh > ploc ? lbvh : ploc));
+    const size_t ploc = rt_ploc_temp_bytes(n), wide = rt_wide_lbvh_temp_bytes(n);
+    size_t most = lbvh > ploc ? lbvh : ploc;
+    most = most > wide ? most : wide;
+    RT_TRY(ctx->build_arena.reserve(most));
     DevBuf *bufs[7] = {&t.boxes, &t.enc, &t.bounds, &t.tkeys, &t.tsort, &t.tenc, &t.tdepth};
     size_t at = 0;
     for (int k = 0; k < 7; k++) { bufs[k]->adopt((char *)ctx->build_arena.p + at, want[k]); at += want[k]; }
@@ -324,47 +288,19 @@ void drop_build_arena_if_large(rt_context *ctx)
     if (ctx->build_arena.bytes > ((size_t)256 << 20)) ctx->build_arena.release();      // keep small arenas for the next build
 }
 
-// The first RT_TOP_NODES internal nodes of a traversal layout in breadth-first order, as a table of their
-// own: a child that is in the table is coded RT_NODE_TOP | its table index, every other child keeps its
-// code.  Every ray walks these nodes, so the traversal kernels keep the table in LDS (rt_trace_wave.h).
-// One thread: <= 128 dependent 64-B reads, once per build.
-__global__ void k_top_table(const Slab *__restrict__ slabs, int root_code, Slab *__restrict__ top, uint32_t *__restrict__ top_n)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (root_code < 0) { *top_n = 0; return; }           // the whole structure is one leaf
-    int queue[RT_TOP_NODES];
-    int head = 0, tail = 0;
-    queue[tail++] = root_code;
-    while (head < tail) {
-        Slab s = slabs[queue[head]];
-        int c[2] = {__float_as_int(s.q3.x), __float_as_int(s.q3.y)};
-        for (int k = 0; k < 2; k++)
-            if (c[k] >= 0 && tail < RT_TOP_NODES) {
-                queue[tail] = c[k];
-                c[k] = RT_NODE_TOP | tail;
-                tail++;
-            }
-        s.q3.x = __int_as_float(c[0]);
-        s.q3.y = __int_as_float(c[1]);
-        top[head++] = s;
-    }
-    *top_n = (uint32_t)tail;
-}
-
 // Steps 2..6 for a structure whose primitive boxes and bounds are already on the device.
 int lbvh_from_boxes(rt_context *ctx, BvhDev &bv, const Box6 *boxes, uint32_t n, const float *d_bounds, bool tlas,
                     DevBuf &tmp_keys, DevBuf &tmp_sort, DevBuf &tmp_enc, DevBuf &tmp_depth)
 {
     hipStream_t st = ctx->stream;
     const unsigned B = 256;
-    // the traversal addresses a 64-B slab as base + (index << 6) with a 32-bit byte offset (rt_trace_wave.h)
+    // the traversal addresses a 64-B node as base + (index << 6) with a 32-bit byte offset (rt_trace_wave.h)
     if (n > (1u << 26)) { rt_set_error("acceleration structure over %u primitives: the limit is 2^26 (67,108,864)", n); return RT_ERR_UNSUPPORTED; }
     bv.n = n;
     RT_TRY(bv.nodes.reserve(sizeof(rt_bvh_node) * (2 * (size_t)n - 1)));
     RT_TRY(bv.keys.reserve(sizeof(uint64_t) * n));
     RT_TRY(bv.parents.reserve(sizeof(uint32_t) * (2 * (size_t)n - 1)));
     RT_TRY(bv.ranges.reserve(sizeof(uint2) * (n > 1 ? n - 1 : 1)));
-    RT_TRY(bv.slabs.reserve(sizeof(Slab) * (n > 1 ? n - 1 : 1)));
     RT_TRY(tmp_keys.reserve(sizeof(uint64_t) * n));
     RT_TRY(tmp_depth.reserve(sizeof(uint32_t)));
 
@@ -384,14 +320,12 @@ int lbvh_from_boxes(rt_context *ctx, BvhDev &bv, const Box6 *boxes, uint32_t n, 
         k_refit_init<<<grid_for((size_t)(n - 1) * 6, B), B, 0, st>>>(tmp_enc.as<uint32_t>(), n - 1);
         k_refit<<<grid_for(n, B), B, 0, st>>>(nodes, parents, n, tmp_enc.as<uint32_t>(), tmp_depth.as<uint32_t>());
         k_refit_decode<<<grid_for(n - 1, B), B, 0, st>>>(tmp_enc.as<uint32_t>(), nodes, n - 1);
-        k_layout<<<grid_for(n - 1, B), B, 0, st>>>(nodes, bv.ranges.as<uint2>(), n, tlas ? 1u : ctx->leaf_max, tlas ? 1 : 0,
-                                                   bv.slabs.as<Slab>());
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&bv.max_depth, tmp_depth.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(bv.bounds, d_bounds, 6 * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    bv.fast_depth = bv.max_depth;      // at most one pending entry per internal node on the current path
+    (void)tlas;
     return RT_OK;
 }
 
@@ -437,24 +371,14 @@ int rt_build_blas(rt_context *ctx, rt_model *m)
             rc = RT_ERR_HIP;
             break;
         }
-        if (n == 1) m->blas.root_code = ~(int)0;                                   // leaf(first 0, count 1)
-        else if (n <= ctx->leaf_max) m->blas.root_code = ~(int)(n - 1);            // leaf(first 0, count n)
-        else m->blas.root_code = 0;
-        // production traversal layout: re-cluster the same leaves with PLOC (rt_bvh_ploc.hip)
+        // production traversal layout: re-cluster the same leaves with PLOC (rt_bvh_ploc.hip), then collapse the binary
+        // tree into four-wide quantised nodes (rt_bvh_wide.hip); tiny meshes and RT_FAST_BVH=lbvh collapse the LBVH itself
         mark("gather");
-        if (ctx->use_ploc && (rc = rt_build_ploc_layout(ctx, m)) != RT_OK) break;
-        mark("PLOC layout");
-        if ((rc = m->blas.top.reserve(sizeof(Slab) * RT_TOP_NODES + sizeof(uint32_t))) != RT_OK) break;
-        {
-            uint32_t *d_n = (uint32_t *)(m->blas.top.as<Slab>() + RT_TOP_NODES);
-            k_top_table<<<1, 64, 0, st>>>(m->blas.slabs.as<Slab>(), m->blas.root_code, m->blas.top.as<Slab>(), d_n);
-            if (hipMemcpyAsync(&m->blas.top_n, d_n, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-                rt_set_error("top table build failed: %s", hipGetErrorString(hipGetLastError()));
-                rc = RT_ERR_HIP;
-                break;
-            }
-        }
-        mark("top table");
+        bool ploc_done = false;
+        if (ctx->use_ploc && (rc = rt_build_ploc_layout(ctx, m, &ploc_done)) != RT_OK) break;
+        mark("PLOC + wide layout");
+        if (!ploc_done && (rc = rt_build_wide_from_lbvh(ctx, m->blas, false, ctx->leaf_max)) != RT_OK) break;
+        mark("wide layout (LBVH)");
         m->built = true;
     } while (0);
     boxes.release(); enc.release(); bounds.release(); tkeys.release(); tsort.release(); tenc.release(); tdepth.release();
@@ -526,7 +450,7 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
         }
         r.root_code = m->blas.root_code;
         r.flags = identity ? RT_INST_IDENTITY : 0u;
-        r.slabs = m->blas.slabs.as<Slab>();
+        r.wide = m->blas.wide.as<WNode>();
         r.tris = m->tris.as<TriRec>();
         r.cnodes = m->blas.nodes.as<rt_bvh_node>();
         r.verts = m->d_verts.as<rt_vertex>();
@@ -555,19 +479,10 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
         k_box_bounds<<<grid_for(n, 256), 256, 0, st>>>(boxes.as<Box6>(), n, enc.as<uint32_t>());
         k_decode_bounds<<<1, 64, 0, st>>>(enc.as<uint32_t>(), bounds.as<float>());
         if ((rc = lbvh_from_boxes(ctx, s->tlas, boxes.as<Box6>(), n, bounds.as<float>(), true, tkeys, tsort, tenc, tdepth)) != RT_OK) break;
-        s->tlas.root_code = (n == 1) ? ~(int)0 : 0;     // single instance: root is the leaf of instance 0
-        if ((rc = s->tlas.top.reserve(sizeof(Slab) * RT_TOP_NODES + sizeof(uint32_t))) != RT_OK) break;
-        {
-            uint32_t *d_n = (uint32_t *)(s->tlas.top.as<Slab>() + RT_TOP_NODES);
-            k_top_table<<<1, 64, 0, st>>>(s->tlas.slabs.as<Slab>(), s->tlas.root_code, s->tlas.top.as<Slab>(), d_n);
-            if (hipMemcpyAsync(&s->tlas.top_n, d_n, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-                rt_set_error("TLAS top table build failed: %s", hipGetErrorString(hipGetLastError()));
-                rc = RT_ERR_HIP;
-                break;
-            }
-        }
-        // one pending entry per internal node on the current path; two-level walks add the
-        // TLAS path and the sentinel that marks the bottom of a BLAS walk
+        // the TLAS is walked in the same four-wide layout (a single instance: the root is the leaf of instance 0)
+        if ((rc = rt_build_wide_from_lbvh(ctx, s->tlas, true, 1)) != RT_OK) break;
+        // a step leaves at most three siblings behind; two-level walks add the TLAS path and the sentinel that marks the
+        // bottom of a BLAS walk
         s->two_level = !(n == 1 && (s->h_inst[0].flags & RT_INST_IDENTITY));
         s->stack_need = s->two_level ? s->tlas.fast_depth + 1 + deepest : deepest;
         // the canonical traversal (parity / counting kernels and the deep-stack path of the fast one) keeps

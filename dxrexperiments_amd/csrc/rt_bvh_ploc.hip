@@ -11,9 +11,9 @@
 // compacted in order (scans, no atomics), until one cluster is left.  Node ids come from
 // prefix sums, so the build is run-to-run deterministic.
 //
-// Output: the same 64-B slab / 48-B triangle layout the traversal engine already walks
-// (rt_internal.h): triangles re-gathered in the depth-first order of the new tree so that every
-// subtree is a contiguous triangle range and subtrees of <= leaf_max triangles collapse to leaves.
+// Output: triangles re-gathered in the depth-first order of the new tree, so that every subtree is a
+// contiguous triangle range and subtrees of <= leaf_max triangles collapse to leaves, and the binary
+// tree itself, which rt_bvh_wide.hip collapses into the four-wide 64-B nodes the traversal walks.
 #include "rt_internal.h"
 
 #include <cstring>
@@ -219,33 +219,18 @@ __global__ void k_ploc_leaf_boxes(const Box6 *__restrict__ cl_box, uint32_t n, B
     if (k < n) node_box[k] = cl_box[k];
 }
 
-// depth-first offset of every node = number of leaves before it; depth of every leaf; and the
-// depth-first PRE-ORDER rank of every internal node among the internal nodes (a subtree of s leaves
-// holds s-1 of them), which becomes its slab index: a node's left child sits in the next slab, so
-// the two halves of a 128-B line are parent and child half of the time and subtrees are contiguous.
+// depth-first offset of every node = number of leaves before it
 __global__ void k_ploc_offsets(const uint32_t *__restrict__ left, const uint32_t *__restrict__ right, const uint32_t *__restrict__ size,
-                               const uint32_t *__restrict__ parent, uint32_t n, uint32_t *__restrict__ offset, uint32_t *__restrict__ slot,
-                               uint32_t *__restrict__ max_depth)
+                               const uint32_t *__restrict__ parent, uint32_t n, uint32_t *__restrict__ offset)
 {
     const uint32_t id = blockIdx.x * PB + threadIdx.x;
-    uint32_t depth = 0;
-    if (id < 2 * n - 1) {
-        uint32_t off = 0, rank = 0, cur = id;
-        for (uint32_t p = parent[cur]; p != 0xFFFFFFFFu; p = parent[cur]) {
-            rank++;                                            // the ancestor itself precedes this node
-            if (right[p - n] == cur) {
-                const uint32_t sl = size[left[p - n]];
-                off += sl;
-                rank += sl - 1;                                // internal nodes of the left sibling subtree
-            }
-            cur = p;
-            depth++;
-        }
-        offset[id] = off;
-        if (id >= n) { slot[id - n] = rank; depth = 0; }      // only leaves vote for the depth
+    if (id >= 2 * n - 1) return;
+    uint32_t off = 0, cur = id;
+    for (uint32_t p = parent[cur]; p != 0xFFFFFFFFu; p = parent[cur]) {
+        if (right[p - n] == cur) off += size[left[p - n]];
+        cur = p;
     }
-    for (int o = 32; o > 0; o >>= 1) depth = max(depth, (uint32_t)__shfl_xor((int)depth, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(max_depth, depth);
+    offset[id] = off;
 }
 
 __global__ void k_ploc_tris(const uint64_t *__restrict__ keys, const rt_vertex *__restrict__ verts, const uint32_t *__restrict__ idx,
@@ -264,35 +249,6 @@ __global__ void k_ploc_tris(const uint64_t *__restrict__ keys, const rt_vertex *
     tris[offset[k]] = t;
 }
 
-__device__ __forceinline__ int ploc_code(uint32_t c, uint32_t n, const uint32_t *__restrict__ size, const uint32_t *__restrict__ offset,
-                                         const uint32_t *__restrict__ slot, uint32_t leaf_max)
-{
-    const uint32_t s = size[c];
-    if (c < n || s <= leaf_max) return ~(int)((offset[c] << 3) | (s - 1));
-    return (int)slot[c - n];
-}
-
-__global__ void k_ploc_slabs(const uint32_t *__restrict__ left, const uint32_t *__restrict__ right, const Box6 *__restrict__ node_box,
-                             const uint32_t *__restrict__ size, const uint32_t *__restrict__ offset, const uint32_t *__restrict__ slot,
-                             uint32_t n, uint32_t leaf_max, Slab *__restrict__ slabs)
-{
-    const uint32_t i = blockIdx.x * PB + threadIdx.x;
-    if (i >= n - 1) return;
-    uint32_t l = left[i], r = right[i];
-    Box6 a = node_box[l], b = node_box[r];
-    // child slot 0 = the child with the larger surface: any-hit rays walk unordered (slot 0 first) and so try
-    // the likelier occluder first (shadow stage -11 %; ordering by triangle count or count/area: -6 %);
-    // closest-hit rays order the two by entry distance at run time and do not care
-    if (merged_area(b, b) > merged_area(a, a)) { const uint32_t t = l; l = r; r = t; const Box6 tb = a; a = b; b = tb; }
-    Slab s;
-    s.q0 = make_float4(a.lo[0], a.hi[0], a.lo[1], a.hi[1]);
-    s.q1 = make_float4(b.lo[0], b.hi[0], b.lo[1], b.hi[1]);
-    s.q2 = make_float4(a.lo[2], a.hi[2], b.lo[2], b.hi[2]);
-    s.q3 = make_float4(__int_as_float(ploc_code(l, n, size, offset, slot, leaf_max)),
-                       __int_as_float(ploc_code(r, n, size, offset, slot, leaf_max)), 0.0f, 0.0f);
-    slabs[slot[i]] = s;
-}
-
 inline unsigned gr(size_t n) { return (unsigned)((n + PB - 1) / PB); }
 
 }  // namespace
@@ -302,19 +258,20 @@ inline unsigned gr(size_t n) { return (unsigned)((n + PB - 1) / PB); }
 size_t rt_ploc_temp_bytes(uint32_t n)
 {
     const size_t nn2 = 2 * (size_t)n;
-    return 8 * (size_t)n + 2 * sizeof(Box6) * (size_t)n + 20 * ((size_t)n + 1) + 12 * (size_t)n + sizeof(Box6) * nn2 + 12 * nn2 + ((size_t)1 << 20) + 18 * 256;
+    return 8 * (size_t)n + 2 * sizeof(Box6) * (size_t)n + 20 * ((size_t)n + 1) + 8 * (size_t)n + sizeof(Box6) * nn2 + 12 * nn2 + ((size_t)1 << 20) + 18 * 256;
 }
 
-// Rebuilds m->blas.slabs / m->tris / root_code / fast_depth from a PLOC tree.  The canonical arrays
-// (nodes, keys, parents) are left untouched.
-int rt_build_ploc_layout(rt_context *ctx, rt_model *m)
+// Rebuilds m->tris and m->blas.wide / root_code / fast_depth from a PLOC tree.  The canonical arrays
+// (nodes, keys, parents) are left untouched.  Returns RT_OK with *done = false for meshes too small to bother.
+int rt_build_ploc_layout(rt_context *ctx, rt_model *m, bool *done)
 {
     const uint32_t n = m->n_tris;
+    *done = false;
     if (n < 2 * ctx->leaf_max + 2) return RT_OK;          // tiny meshes: the LBVH layout is as good as any
     hipStream_t st = ctx->stream;
     // every temporary of the build is carved out of ONE allocation (hipMalloc / hipFree synchronise the
     // device and cost more than the kernels of a small build)
-    View cl_node[2], cl_box[2], nn, keep, merge, keep_pos, merge_pos, left, right, node_box, size, parent, offset, slot, scan_tmp, depth;
+    View cl_node[2], cl_box[2], nn, keep, merge, keep_pos, merge_pos, left, right, node_box, size, parent, offset, scan_tmp, depth;
     int rc = RT_OK;
     do {
         const size_t nn2 = 2 * (size_t)n - 1;
@@ -328,7 +285,7 @@ int rt_build_ploc_layout(rt_context *ctx, rt_model *m)
         const Want wants[] = {{&cl_node[0], 4 * (size_t)n}, {&cl_node[1], 4 * (size_t)n}, {&cl_box[0], sizeof(Box6) * (size_t)n}, {&cl_box[1], sizeof(Box6) * (size_t)n},
                               {&nn, 4 * ((size_t)n + 1)}, {&keep, 4 * ((size_t)n + 1)}, {&merge, 4 * ((size_t)n + 1)}, {&keep_pos, 4 * ((size_t)n + 1)},
                               {&merge_pos, 4 * ((size_t)n + 1)}, {&left, 4 * (size_t)(n - 1)}, {&right, 4 * (size_t)(n - 1)}, {&node_box, sizeof(Box6) * nn2},
-                              {&size, 4 * nn2}, {&parent, 4 * nn2}, {&offset, 4 * nn2}, {&slot, 4 * (size_t)(n - 1)}, {&scan_tmp, tmp_bytes}, {&depth, 8}};
+                              {&size, 4 * nn2}, {&parent, 4 * nn2}, {&offset, 4 * nn2}, {&scan_tmp, tmp_bytes}, {&depth, 8}};
         size_t total = 0;
         for (const Want &w : wants) total += (w.bytes + 255) & ~(size_t)255;
         if ((rc = ctx->build_arena.reserve(total)) != RT_OK) break;      // normally already there (rt_ploc_temp_bytes)
@@ -396,22 +353,17 @@ int rt_build_ploc_layout(rt_context *ctx, rt_model *m)
             rc = RT_ERR_STATE;
             break;
         }
-        (void)hipMemsetAsync(depth.p, 0, 4, st);
         k_ploc_offsets<<<gr(nn2), PB, 0, st>>>(left.as<uint32_t>(), right.as<uint32_t>(), size.as<uint32_t>(), parent.as<uint32_t>(), n,
-                                              offset.as<uint32_t>(), slot.as<uint32_t>(), depth.as<uint32_t>());
+                                              offset.as<uint32_t>());
         k_ploc_tris<<<gr(n), PB, 0, st>>>(m->blas.keys.as<uint64_t>(), m->d_verts.as<rt_vertex>(), m->d_idx.as<uint32_t>(),
                                          offset.as<uint32_t>(), n, m->tris.as<TriRec>());
-        k_ploc_slabs<<<gr(n - 1), PB, 0, st>>>(left.as<uint32_t>(), right.as<uint32_t>(), node_box.as<Box6>(), size.as<uint32_t>(),
-                                              offset.as<uint32_t>(), slot.as<uint32_t>(), n, ctx->leaf_max, m->blas.slabs.as<Slab>());
-        uint32_t d = 0;
-        if (hipMemcpyAsync(&d, depth.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
-            hipGetLastError() != hipSuccess) {
-            rt_set_error("PLOC layout kernels failed");
-            rc = RT_ERR_HIP;
-            break;
-        }
-        m->blas.fast_depth = d;
-        m->blas.root_code = 0;                             // pre-order: the root is slab 0
+        if (hipGetLastError() != hipSuccess) { rt_set_error("PLOC layout kernels failed"); rc = RT_ERR_HIP; break; }
+        // four-wide nodes from the binary tree (root = the last node created); the cluster arrays of the rounds are free now
+        // and serve as its scratch
+        if ((rc = rt_build_wide_layout(ctx, m->blas, n, 2 * n - 2, left.as<uint32_t>(), right.as<uint32_t>(), (const float *)node_box.p,
+                                       size.as<uint32_t>(), offset.as<uint32_t>(), nullptr, ctx->leaf_max, cl_node[0].p,
+                                       (size_t)((char *)left.p - (char *)cl_node[0].p))) != RT_OK) break;
+        *done = true;
     } while (0);
     return rc;
 }

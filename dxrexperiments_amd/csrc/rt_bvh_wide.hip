@@ -1,0 +1,298 @@
+// rt_bvh_wide.hip -- the four-wide, quantised traversal layout (WNode, rt_internal.h).
+//
+// Input: a binary tree over the sorted leaves (the PLOC tree of rt_bvh_ploc.hip, or the canonical LBVH for a TLAS,
+// tiny meshes and RT_FAST_BVH=lbvh).  Output: nodes with up to four children in ONE 64-B line each.  Why: the traversal
+// stages run at the chip's rate of distinct 64-B lines per second (profiles/r02/slab_fetch.txt: reading 16, 32 or 64 B of
+// a line costs the same, a second line costs as much again), so the lever is lines per ray.  A binary node spends its
+// line on two children; round 1's four-wide node with full-precision boxes took two lines and gained nothing.  Here four
+// child boxes are quantised to one byte per plane on a power-of-two grid anchored at the node's own box, which fits
+// origin, scales, 24 plane bytes and four child codes in 64 B and halves the lines per ray.
+//
+// Collapse: breadth first, one round per level.  A frontier element is a binary node that becomes a wide node: its two
+// children are taken, and while fewer than four, the child with the largest surface that is not a leaf is replaced by
+// its own two children (surface-area greedy, as in Wald et al. 2008 / Ylitie et al. 2017).  Node numbers come from
+// prefix sums (deterministic), level after level, so the array is in breadth-first order and its first RT_TOP_NODES
+// entries are the LDS-resident top of the traversal kernels.
+//
+// Exactness: plane = fma(q, scale, origin) is evaluated here with the same expression the traversal uses; every lo
+// plane is stepped down and every hi plane up until the decoded box CONTAINS the child's true box.  The slab test is
+// monotone under box inclusion (DESIGN.md "Exactness rule"), so culling against the decoded boxes never loses a
+// candidate the canonical definition accepts.
+#include "rt_internal.h"
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+namespace {
+
+constexpr unsigned WB = 256;
+constexpr uint32_t NO_KID = 0xFFFFFFFFu;
+
+struct Box6 { float lo[3]; float hi[3]; };
+
+__device__ __forceinline__ float box_area(const Box6 &b)
+{
+    const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+struct TreeView {
+    const uint32_t *left, *right;      // indexed by id - n
+    const Box6 *box;                   // indexed by id
+    const uint32_t *size, *offset;     // indexed by id
+    const uint32_t *leaf_prim;         // TLAS: instance of leaf id; nullptr for a BLAS
+    uint32_t n, leaf_max;
+    __device__ bool is_leaf(uint32_t id) const { return id < n || (!leaf_prim && size[id] <= leaf_max); }
+    __device__ int leaf_code(uint32_t id) const
+    {
+        return leaf_prim ? ~(int)leaf_prim[id] : ~(int)((offset[id] << 3) | (size[id] - 1u));
+    }
+};
+
+// one frontier element -> its (up to four) children, largest surface first, and how many of them are wide nodes themselves
+__global__ void __launch_bounds__(WB) k_wide_expand(TreeView t, const uint32_t *__restrict__ frontier, uint32_t count,
+                                                    uint32_t *__restrict__ kids, uint32_t *__restrict__ n_internal)
+{
+    const uint32_t f = blockIdx.x * WB + threadIdx.x;
+    if (f >= count) return;
+    const uint32_t b = frontier[f];
+    uint32_t kid[4] = {t.left[b - t.n], t.right[b - t.n], NO_KID, NO_KID};
+    int nk = 2;
+    while (nk < 4) {
+        int best = -1;
+        float best_area = -1.0f;
+        for (int k = 0; k < nk; k++) {
+            if (t.is_leaf(kid[k])) continue;
+            const float a = box_area(t.box[kid[k]]);
+            if (a > best_area || best < 0) { best = k; best_area = a; }
+        }
+        if (best < 0) break;
+        const uint32_t id = kid[best];
+        kid[best] = t.left[id - t.n];
+        kid[nk++] = t.right[id - t.n];
+    }
+    float ar[4];
+    for (int k = 0; k < nk; k++) ar[k] = box_area(t.box[kid[k]]);
+    for (int i = 1; i < nk; i++)                       // insertion sort, larger surface first, stable
+        for (int j = i; j > 0 && ar[j] > ar[j - 1]; j--) {
+            const float ta = ar[j]; ar[j] = ar[j - 1]; ar[j - 1] = ta;
+            const uint32_t tk = kid[j]; kid[j] = kid[j - 1]; kid[j - 1] = tk;
+        }
+    uint32_t cnt = 0;
+    for (int k = 0; k < 4; k++) {
+        kids[4 * (size_t)f + k] = k < nk ? kid[k] : NO_KID;
+        if (k < nk && !t.is_leaf(kid[k])) cnt++;
+    }
+    n_internal[f] = cnt;
+}
+
+// quantises the planes of one axis of up to four boxes onto origin + q * scale; returns false if 255 steps do not reach
+__device__ bool quantise_axis(const Box6 *cb, int nk, int axis, float origin, float scale, uint32_t &lo4, uint32_t &hi4)
+{
+    lo4 = 0; hi4 = 0;
+    bool ok = true;
+    for (int k = 0; k < 4; k++) {
+        int ql = 255, qh = 0;                           // unused slot: an inverted interval (never tested: its code is RT_NODE_NONE)
+        if (k < nk) {
+            const float l = cb[k].lo[axis], h = cb[k].hi[axis];
+            float fl = __builtin_floorf((l - origin) / scale), fh = __builtin_ceilf((h - origin) / scale);
+            fl = fl > 0.0f ? (fl < 255.0f ? fl : 255.0f) : 0.0f;            // (NaN -> 0)
+            fh = fh > 0.0f ? (fh < 255.0f ? fh : 255.0f) : 0.0f;
+            ql = (int)fl; qh = (int)fh;
+            while (ql > 0 && __builtin_fmaf((float)ql, scale, origin) > l) ql--;
+            while (qh < 255 && __builtin_fmaf((float)qh, scale, origin) < h) qh++;
+            if (__builtin_fmaf((float)ql, scale, origin) > l || __builtin_fmaf((float)qh, scale, origin) < h) ok = false;
+        }
+        lo4 |= (uint32_t)ql << (8 * k);
+        hi4 |= (uint32_t)qh << (8 * k);
+    }
+    return ok;
+}
+
+__global__ void __launch_bounds__(WB) k_wide_emit(TreeView t, const uint32_t *__restrict__ frontier, uint32_t count, uint32_t base,
+                                                  const uint32_t *__restrict__ kids, const uint32_t *__restrict__ pos,
+                                                  uint32_t *__restrict__ next_frontier, WNode *__restrict__ out)
+{
+    const uint32_t f = blockIdx.x * WB + threadIdx.x;
+    if (f >= count) return;
+    const uint32_t b = frontier[f];
+    const Box6 nb = t.box[b];
+    Box6 cb[4];
+    int code[4];
+    int nk = 0;
+    uint32_t next = pos[f];
+    for (int k = 0; k < 4; k++) {
+        const uint32_t id = kids[4 * (size_t)f + k];
+        code[k] = RT_NODE_NONE;
+        if (id == NO_KID) continue;
+        nk = k + 1;                                     // (kids are packed at the front)
+        cb[k] = t.box[id];
+        if (t.is_leaf(id)) code[k] = t.leaf_code(id);
+        else {
+            next_frontier[next] = id;
+            code[k] = (int)(base + count + next);       // the next level starts right behind this one
+            next++;
+        }
+    }
+    float scale[3];
+    uint32_t lo4[3], hi4[3];
+    for (int a = 0; a < 3; a++) {
+        const float ext = nb.hi[a] - nb.lo[a];
+        // smallest power of two s with 255 * s >= ext (a zero or denormal extent gets the smallest normal number)
+        int e = 0;
+        const float m = __builtin_frexpf(ext / 255.0f, &e);      // ext / 255 = m * 2^e, m in [0.5, 1)
+        float s = (ext > 0.0f && ext < 3.0e38f) ? __builtin_ldexpf(1.0f, m == 0.5f ? e - 1 : e) : 1.17549435e-38f;
+        if (!(s >= 1.17549435e-38f)) s = 1.17549435e-38f;
+        for (int tries = 0; tries < 8; tries++) {
+            if (quantise_axis(cb, nk, a, nb.lo[a], s, lo4[a], hi4[a])) break;
+            s = s * 2.0f;                               // rounding in fma left the last step short: coarser grid
+        }
+        scale[a] = s;
+    }
+    WNode w;
+    w.q0 = make_float4(nb.lo[0], nb.lo[1], nb.lo[2], scale[0]);
+    w.q1 = make_float4(__uint_as_float(lo4[0]), __uint_as_float(hi4[0]), __uint_as_float(lo4[1]), __uint_as_float(hi4[1]));
+    w.q2 = make_float4(__uint_as_float(lo4[2]), __uint_as_float(hi4[2]), scale[1], scale[2]);
+    w.q3 = make_float4(__int_as_float(code[0]), __int_as_float(code[1]), __int_as_float(code[2]), __int_as_float(code[3]));
+    out[base + f] = w;
+}
+
+// canonical LBVH (rt_bvh_node[2n-1] + leaf ranges) -> cluster numbering: leaf k -> id k, internal c -> id n + c
+__global__ void __launch_bounds__(WB) k_lbvh_to_tree(const rt_bvh_node *__restrict__ nodes, const uint2 *__restrict__ ranges, uint32_t n,
+                                                     uint32_t *__restrict__ left, uint32_t *__restrict__ right, Box6 *__restrict__ box,
+                                                     uint32_t *__restrict__ size, uint32_t *__restrict__ offset, uint32_t *__restrict__ leaf_prim)
+{
+    const uint32_t c = blockIdx.x * WB + threadIdx.x;
+    if (c >= 2 * n - 1) return;
+    const rt_bvh_node nd = nodes[c];
+    const bool leaf = c >= n - 1;
+    const uint32_t id = leaf ? c - (n - 1) : n + c;
+    Box6 b;
+    for (int k = 0; k < 3; k++) { b.lo[k] = nd.bmin[k]; b.hi[k] = nd.bmax[k]; }
+    box[id] = b;
+    if (leaf) {
+        size[id] = 1;
+        offset[id] = id;
+        leaf_prim[id] = nd.left;
+    } else {
+        const uint2 r = ranges[c];
+        size[id] = r.y - r.x + 1;
+        offset[id] = r.x;
+        left[c] = nd.left >= n - 1 ? nd.left - (n - 1) : n + nd.left;
+        right[c] = nd.right >= n - 1 ? nd.right - (n - 1) : n + nd.right;
+    }
+}
+
+inline unsigned gr(size_t n) { return (unsigned)((n + WB - 1) / WB); }
+inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+}  // namespace
+
+// two frontiers, the children of a frontier, counts and their prefix sums, scan scratch
+size_t rt_wide_temp_bytes(uint32_t n)
+{
+    const size_t f = (size_t)n / 2 + 2;
+    return 2 * up256(4 * f) + up256(16 * f) + 2 * up256(4 * (f + 1)) + ((size_t)1 << 20);
+}
+
+int rt_build_wide_layout(rt_context *ctx, BvhDev &bv, uint32_t n, uint32_t root, const uint32_t *left, const uint32_t *right,
+                         const float *box6, const uint32_t *size, const uint32_t *offset, const uint32_t *leaf_prim, uint32_t leaf_max,
+                         void *tmp, size_t tmp_bytes)
+{
+    hipStream_t st = ctx->stream;
+    TreeView t;
+    t.left = left; t.right = right; t.box = (const Box6 *)box6; t.size = size; t.offset = offset; t.leaf_prim = leaf_prim;
+    t.n = n; t.leaf_max = leaf_max;
+    bv.wide_n = 0;
+    // the whole structure is one leaf (one primitive, or a BLAS of <= leaf_max triangles)
+    if (!leaf_prim && n <= leaf_max) {
+        bv.root_code = ~(int)(n - 1);                  // leaf(first 0, count n)
+        bv.fast_depth = 0;
+        RT_TRY(bv.wide.reserve(sizeof(WNode)));
+        return RT_OK;
+    }
+    const size_t fcap = (size_t)n / 2 + 2;
+    size_t scan_bytes = 0;
+    if (rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, fcap + 1, rocprim::plus<uint32_t>(), st) != hipSuccess) {
+        rt_set_error("rocprim::exclusive_scan sizing failed");
+        return RT_ERR_HIP;
+    }
+    const size_t need = 2 * up256(4 * fcap) + up256(16 * fcap) + 2 * up256(4 * (fcap + 1)) + up256(scan_bytes);
+    DevBuf own;                        // only if the caller's slice is too small
+    char *p = (char *)tmp;
+    if (need > tmp_bytes) { RT_TRY(own.reserve(need)); p = (char *)own.p; }
+    uint32_t *frontier[2] = {(uint32_t *)p, (uint32_t *)(p + up256(4 * fcap))};
+    p += 2 * up256(4 * fcap);
+    uint32_t *kids = (uint32_t *)p; p += up256(16 * fcap);
+    uint32_t *cnt = (uint32_t *)p; p += up256(4 * (fcap + 1));
+    uint32_t *pos = (uint32_t *)p; p += up256(4 * (fcap + 1));
+    void *scan_tmp = p;
+    int rc = RT_OK;
+    do {
+        if ((rc = bv.wide.reserve(sizeof(WNode) * (size_t)(n - 1))) != RT_OK) break;
+        if (hipMemcpyAsync(frontier[0], &root, 4, hipMemcpyHostToDevice, st) != hipSuccess) { rt_set_error("wide layout: upload failed"); rc = RT_ERR_HIP; break; }
+        uint32_t count = 1, base = 0, levels = 0;
+        int cur = 0;
+        while (count > 0) {
+            if ((size_t)count > fcap || (size_t)base + count > (size_t)n - 1) { rt_set_error("wide layout: frontier of %u nodes at level %u does not fit", count, levels); rc = RT_ERR_STATE; break; }
+            k_wide_expand<<<gr(count), WB, 0, st>>>(t, frontier[cur], count, kids, cnt);
+            (void)hipMemsetAsync(cnt + count, 0, 4, st);
+            size_t sb = scan_bytes;
+            (void)rocprim::exclusive_scan(scan_tmp, sb, cnt, pos, 0u, (size_t)count + 1, rocprim::plus<uint32_t>(), st);
+            k_wide_emit<<<gr(count), WB, 0, st>>>(t, frontier[cur], count, base, kids, pos, frontier[cur ^ 1], bv.wide.as<WNode>());
+            uint32_t stack_total = 0;
+            uint32_t *total = ctx->pinned ? ctx->pinned : &stack_total;
+            if (hipMemcpyAsync(total, pos + count, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
+                hipGetLastError() != hipSuccess) {
+                rt_set_error("wide layout level %u failed: %s", levels, hipGetErrorString(hipGetLastError()));
+                rc = RT_ERR_HIP;
+                break;
+            }
+            base += count;
+            count = *total;
+            cur ^= 1;
+            levels++;
+        }
+        if (rc != RT_OK) break;
+        bv.wide_n = base;
+        bv.root_code = 0;
+        bv.fast_depth = 3 * levels;        // a step leaves at most three siblings behind
+    } while (0);
+    own.release();
+    return rc;
+}
+
+// arena bytes rt_build_wide_from_lbvh takes: the tree in cluster numbering + the scratch of the collapse
+size_t rt_wide_lbvh_temp_bytes(uint32_t n)
+{
+    const size_t nn2 = 2 * (size_t)n;
+    return 2 * up256(4 * (size_t)n) + up256(sizeof(Box6) * nn2) + 3 * up256(4 * nn2) + rt_wide_temp_bytes(n);
+}
+
+int rt_build_wide_from_lbvh(rt_context *ctx, BvhDev &bv, bool tlas, uint32_t leaf_max)
+{
+    const uint32_t n = bv.n;
+    hipStream_t st = ctx->stream;
+    if (n == 1) {                                      // one primitive: the root is its leaf (TLAS: instance 0; BLAS: triangle 0)
+        bv.wide_n = 0;
+        bv.root_code = ~(int)0;
+        bv.fast_depth = 0;
+        RT_TRY(bv.wide.reserve(sizeof(WNode)));
+        return RT_OK;
+    }
+    const size_t nn2 = 2 * (size_t)n - 1;
+    const size_t tree = 2 * up256(4 * (size_t)(n - 1)) + up256(sizeof(Box6) * nn2) + 3 * up256(4 * nn2);
+    const size_t wide = rt_wide_temp_bytes(n);
+    RT_TRY(ctx->build_arena.reserve(tree + wide));
+    char *p = (char *)ctx->build_arena.p;
+    uint32_t *left = (uint32_t *)p; p += up256(4 * (size_t)(n - 1));
+    uint32_t *right = (uint32_t *)p; p += up256(4 * (size_t)(n - 1));
+    Box6 *box = (Box6 *)p; p += up256(sizeof(Box6) * nn2);
+    uint32_t *size = (uint32_t *)p; p += up256(4 * nn2);
+    uint32_t *offset = (uint32_t *)p; p += up256(4 * nn2);
+    uint32_t *leaf_prim = (uint32_t *)p; p += up256(4 * nn2);
+    k_lbvh_to_tree<<<gr(nn2), WB, 0, st>>>(bv.nodes.as<rt_bvh_node>(), bv.ranges.as<uint2>(), n, left, right, box, size, offset, leaf_prim);
+    HIP_TRY(hipGetLastError());
+    return rt_build_wide_layout(ctx, bv, n, n /* canonical root 0 */, left, right, (const float *)box, size, offset, tlas ? leaf_prim : nullptr,
+                                tlas ? 1u : leaf_max, p, wide);
+}

@@ -69,21 +69,28 @@ struct DevBuf {
 
 // ---- device-visible records -------------------------------------------------
 
-// One traversal slab = one internal BVH2 node with BOTH child boxes (64 B, one
-// aligned half cache line, fetched as 4 x dwordx4).
-//   q0 = c0.lo.x c0.hi.x c0.lo.y c0.hi.y
-//   q1 = c1.lo.x c1.hi.x c1.lo.y c1.hi.y
-//   q2 = c0.lo.z c0.hi.z c1.lo.z c1.hi.z
-//   q3 = code0 code1 (int bits) 0 0
-// Child code: >= 0 internal slab index; < 0 leaf: ~code = (first << 3) | (count-1)
-// for a BLAS (triangles first..first+count-1 of the sorted triangle array), or the
-// instance index for the TLAS.
-struct Slab { float4 q0, q1, q2, q3; };
+// One traversal node = FOUR children in one 64-B line (fetched as 4 x dwordx4): the chip delivers a fixed number of
+// distinct 64-B lines per second to divergent lanes whatever part of a line a lane reads (profiles/r02/slab_fetch.txt),
+// so a node must spend its one line on as many children as fit.  Child boxes are quantised to 8 bits per plane on a
+// grid anchored at the node's own box: plane = fma(q, scale, origin), the builder rounds lo planes down and hi planes up
+// WITH THIS SAME EXPRESSION until the decoded box contains the child's true box, so culling against it is conservative
+// and the candidate validation of rt_trace_device.h keeps every result bit-identical to the canonical definition.
+//   q0 = origin.x origin.y origin.z scale.x
+//   q1 = lo.x[4] hi.x[4] lo.y[4] hi.y[4]        (one byte per child, child k in bits 8k..8k+7)
+//   q2 = lo.z[4] hi.z[4] scale.y scale.z
+//   q3 = code[4]
+// Child code: >= 0 index of an internal node of the same array; < 0 leaf: ~code = (first << 3) | (count-1) for a BLAS
+// (triangles first..first+count-1 of the sorted triangle array), or the instance index for the TLAS; RT_NODE_NONE for an
+// unused slot.  Nodes are numbered breadth first, so the first top_n nodes ARE the top of the tree (LDS resident in the
+// traversal kernels).  Slot order: larger surface first (any-hit rays walk unordered and try the likelier occluder first).
+struct WNode { float4 q0, q1, q2, q3; };
+#define RT_NODE_NONE ((int)0x80000000)
 
 // One triangle in leaf order: the three ORIGINAL vertex positions (so that the
 // Moller-Trumbore edges and the triangle's own AABB are recomputed from the same
 // floats the canonical BVH was built from) plus the primitive id.  48 B.
 struct TriRec { float4 a, b, c; };   // a = v0.xyz v1.x ; b = v1.yz v2.xy ; c = v2.z prim 0 0
+                                     // (padding a record to one 64-B line so that none straddles two: measured, no change)
 
 #define RT_INST_IDENTITY 1u
 
@@ -91,7 +98,7 @@ struct InstanceRec {
     float inv[12];              // world-to-object, 3x4 row-major
     float wlo[3]; int root_code;
     float whi[3]; uint32_t flags;
-    const Slab *slabs;
+    const WNode *wide;
     const TriRec *tris;
     const rt_bvh_node *cnodes;  // canonical nodes of the BLAS
     const rt_vertex *verts;
@@ -102,19 +109,19 @@ struct InstanceRec {
 
 struct SceneDev {
     const InstanceRec *inst;
-    const Slab *tlas_slabs;
+    const WNode *tlas_wide;
     const rt_bvh_node *tlas_cnodes;
     uint32_t n_inst;
     int tlas_root_code;
     int *deep_stack;             // global stack rows beyond the LDS rows (rt_trace_wave.h); nullptr: never needed
-    const Slab *top;             // single-level scenes: the first top_n slabs of the BLAS in breadth-first order,
-    uint32_t top_n;              //   child codes remapped (RT_NODE_TOP | index); the kernels keep them in LDS
+    uint32_t top_n;              // nodes 0..top_n-1 of the structure a ray starts in (single-level: the BLAS, two-level: the
+                                 //   TLAS) are copied into LDS by every traversal workgroup
 };
 
-#define RT_NODE_TOP   0x40000000      // internal-node code that indexes the LDS-resident top of the tree
 #ifndef RT_TOP_NODES
-#define RT_TOP_NODES  192             // slabs of the top table: 12 KiB of LDS per 256-thread block (measured, ms per frame at
-#endif                                //   26 LDS rows in all: 64 nodes 3.64, 128 3.62, 192 3.56, 256 3.56)
+#define RT_TOP_NODES  128             // nodes of the LDS-resident top: 8 KiB of LDS per 256-thread block (with four-wide nodes the
+                                      //   size hardly matters: 32 .. 192 nodes all within 1 %; 256 nodes cost the stack rows: +3 %)
+#endif
 #define RT_TOP_ROWS(BLOCK) (RT_TOP_NODES * 16 / (BLOCK))      // LDS rows (of BLOCK ints) the top table takes
 
 // ---- host objects --------------------------------------------------------------
@@ -148,12 +155,11 @@ struct BvhDev {
     DevBuf keys;                 // uint64[n]           sorted morton keys
     DevBuf parents;              // uint32[2n-1]
     DevBuf ranges;               // uint2[n-1]          leaf range of every internal node
-    DevBuf slabs;                // Slab[max(n-1,1)]    traversal layout
-    DevBuf top;                  // Slab[RT_TOP_NODES]  breadth-first top of the traversal layout (rt_build_top_table)
-    uint32_t top_n = 0;
+    DevBuf wide;                 // WNode[wide_n]       traversal layout, breadth first
+    uint32_t wide_n = 0;
     int root_code = -1;
     uint32_t fast_depth = 0;     // stack entries the traversal layout can need
-    void release() { nodes.release(); keys.release(); parents.release(); ranges.release(); slabs.release(); top.release(); }
+    void release() { nodes.release(); keys.release(); parents.release(); ranges.release(); wide.release(); }
 };
 
 struct rt_model {
@@ -189,12 +195,11 @@ struct rt_scene {
     {
         SceneDev s;
         s.inst = d_inst.as<InstanceRec>();
-        s.tlas_slabs = tlas.slabs.as<Slab>();
+        s.tlas_wide = tlas.wide.as<WNode>();
         s.tlas_cnodes = tlas.nodes.as<rt_bvh_node>();
         s.n_inst = (uint32_t)inst.size();
         s.tlas_root_code = tlas.root_code;
         s.deep_stack = nullptr;
-        s.top = nullptr;
         s.top_n = 0;
         return s;
     }
@@ -207,7 +212,19 @@ int rt_build_blas(rt_context *ctx, rt_model *m);
 int rt_build_tlas(rt_context *ctx, rt_scene *s);
 
 // rt_bvh_ploc.hip
-int rt_build_ploc_layout(rt_context *ctx, rt_model *m);
+int rt_build_ploc_layout(rt_context *ctx, rt_model *m, bool *done);
+
+// rt_bvh_wide.hip: collapses a binary tree into the four-wide traversal layout (bv.wide, wide_n, fast_depth, root_code).
+// The binary tree is given in "cluster" numbering: leaves 0..n-1 in sorted-key order, internal nodes n..2n-2;
+// left / right are indexed by id - n; box6 = {lo[3], hi[3]} per id; size = leaves below; offset = leaves before (depth
+// first); leaf_prim (TLAS only) maps a leaf to its instance.  Temporaries come from the arena slice [tmp, tmp + tmp_bytes).
+size_t rt_wide_temp_bytes(uint32_t n);
+size_t rt_wide_lbvh_temp_bytes(uint32_t n);
+int rt_build_wide_layout(rt_context *ctx, BvhDev &bv, uint32_t n, uint32_t root, const uint32_t *left, const uint32_t *right,
+                         const float *box6, const uint32_t *size, const uint32_t *offset, const uint32_t *leaf_prim, uint32_t leaf_max,
+                         void *tmp, size_t tmp_bytes);
+// the same from the canonical LBVH arrays of bv (TLAS, tiny meshes, RT_FAST_BVH=lbvh)
+int rt_build_wide_from_lbvh(rt_context *ctx, BvhDev &bv, bool tlas, uint32_t leaf_max);
 
 // rt_trace.hip
 struct TraceOut {
@@ -232,8 +249,9 @@ static inline unsigned rt_persistent_grid(const rt_context *ctx, K kernel, int b
 }
 
 #ifndef RT_LDS_STACK_ROWS
-#define RT_LDS_STACK_ROWS 14            // LDS stack rows of the traversal kernels; with the 12-row top table (top of the BLAS for
-#endif                                  // single-level walks, top of the TLAS for two-level ones) 26 KiB per 256-thread block = 6 blocks per CU
+#define RT_LDS_STACK_ROWS 18            // LDS stack rows of the traversal kernels; with the 8-row top table (top of the BLAS for
+#endif                                  // single-level walks, top of the TLAS for two-level ones) 26 KiB per 256-thread block = 6 blocks per CU.
+                                        // Bench-scene rays: 98.1 % never hold more than 8 entries, 99.97 % not more than 12, none more than 17.
 #define RT_LDS_STACK_ROWS_TEST 6        // second instantiation (env RT_LDS_STACK_ROWS=6): tests force rays onto the global rows
 
 // The scene as the traversal kernels see it, with the global stack rows a launch of `threads` threads whose
@@ -243,8 +261,7 @@ static inline int rt_scene_dev_for_launch(rt_context *ctx, const rt_scene *s, ui
     *out = s->dev();
     if (ctx->lds_top) {          // one identity instance: rays walk its BLAS directly; otherwise the top of the TLAS
         const BvhDev &bv = s->two_level ? s->tlas : s->inst[0].model->blas;
-        out->top = bv.top.as<Slab>();
-        out->top_n = bv.top_n;
+        out->top_n = bv.wide_n < RT_TOP_NODES ? bv.wide_n : RT_TOP_NODES;
     }
     const uint32_t bound = s->stack_need + 2;
     if (bound <= lds_rows) return RT_OK;

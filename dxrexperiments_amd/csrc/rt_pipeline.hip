@@ -1203,7 +1203,7 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
     static_assert(C_COUNT <= POOL_OFFSET_WORDS, "scalar counters overlap the chunk pools");
     pd.pools = pd.counters + POOL_OFFSET_WORDS;
     HIP_TRY(hipMemsetAsync(pd.counters, 0, POOL_OFFSET_WORDS * 4 + POOL_BYTES, st));
-    // 14 LDS stack rows + the 12-row top table = 26 KiB per 256-thread block = 6 resident blocks per CU, whatever
+    // 18 LDS stack rows + the 8-row top table = 26 KiB per 256-thread block = 6 resident blocks per CU, whatever
     // the depth of the tree; the rare deeper walk continues in global rows (rt_trace_wave.h)
     if (ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST) launch_frame_any<RT_LDS_STACK_ROWS_TEST>(p, pd, shadow_slots);
     else launch_frame_any<RT_LDS_STACK_ROWS>(p, pd, shadow_slots);

@@ -13,14 +13,16 @@
 //     stand on a leaf; once those still walking are fewer than half of those waiting,
 //     the wave turns to the leaves, so the (short) triangle code is not serialised
 //     against the (long) node code and neither waits for the slowest lane;
-//   * internal nodes are 64-B slabs holding BOTH child boxes: four 16-B loads from
-//     one half cache line through explicitly global (address-space 1) pointers; the
-//     first 192 nodes of a single-level tree (breadth-first) are read from LDS;
-//   * the step is branch free: both children are slab-tested, the nearer hit child
-//     is entered (any-hit rays: slot 0, where the builders put the larger child), the
-//     other one is written to the stack slot above the top unconditionally (it only
-//     counts if the top moves), the slot below the top is read speculatively (it only
-//     counts if both children miss);
+//   * internal nodes are 64-B lines holding FOUR quantised child boxes (WNode, rt_internal.h): the
+//     stages run at the chip's rate of distinct 64-B lines per second, so a line must carry as many
+//     children as fit; four 16-B loads of one line through explicitly global (address-space 1)
+//     pointers; the first 192 nodes of the structure a ray starts in (breadth first = the top of
+//     the tree) are read from LDS;
+//   * a step decodes the four boxes (one cvt + one fma per plane), slab-tests them, enters the
+//     nearest hit child and pushes the others farthest first (closest-hit rays: a five-exchange
+//     sorting network on (entry distance, code); any-hit rays: slot order, where the builders put
+//     the larger children first); the slot below the top is read speculatively (it only counts if
+//     no child is hit);
 //   * the stack is LDS resident, stack[row][lane-in-block]: one dword per lane per
 //     row, bank = lane mod 32, conflict free for both halves of a wave; a fixed
 //     number of rows whatever the tree, the rare deeper walk continues in global rows.
@@ -59,7 +61,8 @@ RT_DEV v4f ldg16(const void *base, size_t byte_off)
 #endif
 #define RT_POOL_STRIDE 32u              // words between two counters: one 128-B L2 line each
 #ifndef RT_EXIT_K
-#define RT_EXIT_K 2                     // leave the node loop once (lanes still on internal nodes) * K < lanes waiting on a leaf
+#define RT_EXIT_K 1                     // leave the node loop once (lanes still on internal nodes) * K < lanes waiting on a leaf
+                                        //   (four-wide nodes, ms per frame 1080p / 10 M triangles 4K: K = 0 3.31 / 21.9, 1 2.80 / 15.5, 2 2.86 / 16.5, 3 2.88 / 16.9)
 #endif
 
 // (Packed fp32 -- v_pk_add_f32 / v_pk_mul_f32 on the (lo, hi) plane pairs -- was measured and is no faster
@@ -94,38 +97,106 @@ struct LaneStack {
     }
 };
 
-// One step on an internal node: both children are slab-tested, the nearer hit child is entered, the farther
-// one is written to the stack slot above the top unconditionally (it only counts if the top moves), the
-// slot below the top is read speculatively (it only counts if both children miss).  Branch free.
-template <bool DEEP, bool TOP, bool ANYHIT, int STACK, int BLOCK>
-RT_DEV void node_step(const Slab *slabs, const int *top, const RayInv &ri, float tmin, float tbest, const LaneStack<STACK, BLOCK> &st, int &node, int &sp)
+// One step on a wide node: slab-test the four children, enter the nearest hit one (any-hit: the first in slot order),
+// push the other hit ones (farthest first), pop if none is hit.  The lane's stack pointer may rise by three, so the
+// pure-LDS instantiation (DEEP = false) is only called with sp <= STACK - 3.
+//
+// The four boxes are tested in the node's quantised frame: a plane at grid step q lies at origin + q * scale, so its
+// distance along the ray is  t(q) = q * A + B  with  A = scale * inv,  B = (origin - o) * inv  per axis -- one cvt and
+// one fma per plane instead of decode, subtract, multiply.  This is CULLING arithmetic, not the canonical slab test
+// (rt_trace_device.h), so it carries an explicit margin per axis,
+//     D = 2^-20 * (|B| + |inv| * (|origin| + 255 * scale)) + 1e-37,
+// a bound (with a factor of >8 to spare) on every rounding that separates t(q) from the canonical distance of the
+// decoded plane rn(origin + q * scale): the rounding of that plane itself (<= 2^-24 |plane| |inv|), the canonical test's
+// own two roundings (<= 2^-23 |t|), and the three roundings here (B twice, the fma once).  Near planes use B - D, far
+// planes B + D; which byte is the near plane follows the sign of inv, so no min / max per axis is needed.  Hence
+//     canonical test passes on the true child box  =>  it passes on the decoded box (monotone, rt_bvh_wide.hip)
+//                                                  =>  this test passes,
+// which is all the exactness rule asks of a traversal.  (All reciprocals are finite and at most 2^16 here: steeper rays
+// take the exact path inside the step.)
+template <bool DEEP, bool ANYHIT, int STACK, int BLOCK>
+RT_DEV void wide_step(const WNode *nodes, const int *top, uint32_t top_lim, const RayInv &ri, float tmin, float tbest,
+                      const LaneStack<STACK, BLOCK> &st, int &node, int &sp)
 {
     v4f q0, q1, q2, q3;
-    if (TOP && (node & RT_NODE_TOP)) {
-        // the top of the tree is LDS resident: every ray walks it, and divergent 16-B global loads cost the
-        // vector L1 about a clock per lane whether they hit or not
-        const v4f *t = (const v4f *)(top + ((node & 0xFFFF) << 4));
+    if ((uint32_t)node < top_lim) {
+        // the top of the tree is LDS resident: every ray walks it
+        const v4f *t = (const v4f *)(top + (node << 4));
         q0 = t[0]; q1 = t[1]; q2 = t[2]; q3 = t[3];
     } else {
-        // 32-bit byte offset from the (wave-uniform, single-level) slab base: SGPR base + VGPR offset addressing
-        const char *sl = (const char *)slabs + ((uint32_t)node << 6);
-        q0 = ldg16(sl, 0); q1 = ldg16(sl, 16); q2 = ldg16(sl, 32); q3 = ldg16(sl, 48);
+        // 32-bit byte offset from the (wave-uniform in single-level walks) node base: SGPR base + VGPR offset addressing
+        const char *nd = (const char *)nodes + ((uint32_t)node << 6);
+        q0 = ldg16(nd, 0); q1 = ldg16(nd, 16); q2 = ldg16(nd, 32); q3 = ldg16(nd, 48);
     }
-    float e0, e1;
-    const bool h0 = slab_hit(ri, q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, tmin, tbest, e0);
-    const bool h1 = slab_hit(ri, q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, tmin, tbest, e1);
-    const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-    const bool both = h0 && h1, none = !(h0 || h1);
-    const bool swap = ANYHIT ? false : e1 < e0;      // any-hit rays need no order: the first hit ends them
-    const int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-    const int one = h0 ? c0 : c1;
+    const uint32_t lx = __float_as_uint(q1.x), hx = __float_as_uint(q1.y), ly = __float_as_uint(q1.z), hy = __float_as_uint(q1.w);
+    const uint32_t lz = __float_as_uint(q2.x), hz = __float_as_uint(q2.y);
+    int c[4] = {__float_as_int(q3.x), __float_as_int(q3.y), __float_as_int(q3.z), __float_as_int(q3.w)};
+    float d[4];
+    bool h[4];
+    // A ray that runs (almost) inside an axis-aligned plane -- a direction component below 2^-16, about one ray in 10^4 --
+    // needs that axis resolved exactly: it lies IN a tessellated wall, only the exact plane distance (o is within an ulp
+    // of the wall) tells which of the wall's boxes it is in, and with the margin D it would walk all of them (measured:
+    // walks of thousands of nodes, a 2 ms tail on a 1 ms stage).  Such a lane decodes the boxes and runs the canonical
+    // slab test itself; a zero component (reciprocal +-inf) goes the same way and is treated exactly as the definition says.
+    const float steep = fmax2(fmax2(__builtin_fabsf(ri.inv.x), __builtin_fabsf(ri.inv.y)), __builtin_fabsf(ri.inv.z));
+    if (!(steep <= 65536.0f)) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // plane = fma(q, scale, origin): the expression rt_bvh_wide.hip verified the containment with
+            const float blx = __builtin_fmaf((float)((lx >> (8 * k)) & 0xffu), q0.w, q0.x), bhx = __builtin_fmaf((float)((hx >> (8 * k)) & 0xffu), q0.w, q0.x);
+            const float bly = __builtin_fmaf((float)((ly >> (8 * k)) & 0xffu), q2.z, q0.y), bhy = __builtin_fmaf((float)((hy >> (8 * k)) & 0xffu), q2.z, q0.y);
+            const float blz = __builtin_fmaf((float)((lz >> (8 * k)) & 0xffu), q2.w, q0.z), bhz = __builtin_fmaf((float)((hz >> (8 * k)) & 0xffu), q2.w, q0.z);
+            float e;
+            h[k] = slab_hit(ri, blx, bhx, bly, bhy, blz, bhz, tmin, tbest, e) && c[k] != RT_NODE_NONE;
+            d[k] = h[k] ? e : __uint_as_float(0x7f800000u);
+        }
+    } else {
+        const float ax = q0.w * ri.inv.x, ay = q2.z * ri.inv.y, az = q2.w * ri.inv.z;
+        const float bx = (q0.x - ri.o.x) * ri.inv.x, by = (q0.y - ri.o.y) * ri.inv.y, bz = (q0.z - ri.o.z) * ri.inv.z;
+        const float k20 = 9.5367431640625e-07f;      // 2^-20
+        const float dx = __builtin_fmaf(__builtin_fmaf(__builtin_fabsf(ri.inv.x), __builtin_fmaf(255.0f, q0.w, __builtin_fabsf(q0.x)), __builtin_fabsf(bx)), k20, 1.0e-37f);
+        const float dy = __builtin_fmaf(__builtin_fmaf(__builtin_fabsf(ri.inv.y), __builtin_fmaf(255.0f, q2.z, __builtin_fabsf(q0.y)), __builtin_fabsf(by)), k20, 1.0e-37f);
+        const float dz = __builtin_fmaf(__builtin_fmaf(__builtin_fabsf(ri.inv.z), __builtin_fmaf(255.0f, q2.w, __builtin_fabsf(q0.z)), __builtin_fabsf(bz)), k20, 1.0e-37f);
+        const float bnx = bx - dx, bfx = bx + dx, bny = by - dy, bfy = by + dy, bnz = bz - dz, bfz = bz + dz;
+        // near / far plane bytes by the sign of the direction
+        const bool ngx = ri.inv.x < 0.0f, ngy = ri.inv.y < 0.0f, ngz = ri.inv.z < 0.0f;
+        const uint32_t nx4 = ngx ? hx : lx, fx4 = ngx ? lx : hx, ny4 = ngy ? hy : ly, fy4 = ngy ? ly : hy, nz4 = ngz ? hz : lz, fz4 = ngz ? lz : hz;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float nx = __builtin_fmaf((float)((nx4 >> (8 * k)) & 0xffu), ax, bnx), fx = __builtin_fmaf((float)((fx4 >> (8 * k)) & 0xffu), ax, bfx);
+            const float ny = __builtin_fmaf((float)((ny4 >> (8 * k)) & 0xffu), ay, bny), fy = __builtin_fmaf((float)((fy4 >> (8 * k)) & 0xffu), ay, bfy);
+            const float nz = __builtin_fmaf((float)((nz4 >> (8 * k)) & 0xffu), az, bnz), fz = __builtin_fmaf((float)((fz4 >> (8 * k)) & 0xffu), az, bfz);
+            const float lo = fmax2(fmax2(nx, ny), fmax2(nz, tmin));
+            const float hi = fmin2(fmin2(fx, fy), fmin2(fz, tbest));
+            h[k] = lo <= hi * RT_SLAB_SLACK && c[k] != RT_NODE_NONE;
+            d[k] = h[k] ? lo : __uint_as_float(0x7f800000u);
+        }
+    }
     const int below = sp > 0 ? sp - 1 : 0;
-    const int above = DEEP ? st.read(below) : st.lds[below * BLOCK];   // speculative pop (unconditional read)
-    const int popped = sp > 0 ? above : RT_NODE_EMPTY;
-    if (DEEP) st.write(sp, farc);                                      // speculative push
-    else st.lds[sp * BLOCK] = farc;
-    node = both ? nearc : (none ? popped : one);
-    sp = both ? sp + 1 : ((none && sp > 0) ? sp - 1 : sp);
+    const int under = DEEP ? st.read(below) : st.lds[below * BLOCK];       // speculative pop (unconditional read)
+    bool p3, p2, p1, any;
+    if (ANYHIT) {
+        // no order needed: the first hit ends the ray.  Enter the first hit slot, push every later hit one.
+        any = h[0] || h[1] || h[2] || h[3];
+        p3 = h[3] && (h[0] || h[1] || h[2]);
+        p2 = h[2] && (h[0] || h[1]);
+        p1 = h[1] && h[0];
+        c[0] = h[0] ? c[0] : (h[1] ? c[1] : (h[2] ? c[2] : c[3]));
+    } else {
+        // sort the four (entry, code) pairs by entry distance; misses carry +inf and end up last
+#define RT_CE(i, j) { const bool sw = d[j] < d[i]; const float td = sw ? d[j] : d[i]; d[j] = sw ? d[i] : d[j]; d[i] = td; \
+                      const int tc = sw ? c[j] : c[i]; c[j] = sw ? c[i] : c[j]; c[i] = tc; }
+        // (only bringing the nearest to the front -- three exchanges -- costs 1.3 % more steps and the same time)
+        RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
+#undef RT_CE
+        const float inf = __uint_as_float(0x7f800000u);
+        any = d[0] < inf; p1 = d[1] < inf; p2 = d[2] < inf; p3 = d[3] < inf;
+    }
+    if (p3) { if (DEEP) st.write(sp, c[3]); else st.lds[sp * BLOCK] = c[3]; sp++; }
+    if (p2) { if (DEEP) st.write(sp, c[2]); else st.lds[sp * BLOCK] = c[2]; sp++; }
+    if (p1) { if (DEEP) st.write(sp, c[1]); else st.lds[sp * BLOCK] = c[1]; sp++; }
+    if (any) node = c[0];
+    else { node = sp > 0 ? under : RT_NODE_EMPTY; sp = below; }
 }
 
 RT_DEV bool node_is_internal(int node) { return node >= 0 && node < RT_NODE_EMPTY; }
@@ -142,8 +213,8 @@ RT_DEV unsigned long long lanemask_lt()
 //   struct Sink { void store(uint32_t i, const HitD &h, bool traced) const; };
 
 // COUNT: the walk-counting instantiation (rt_pipeline_count_walk): the same walk, plus per-lane tallies of what it
-// fetches -- 64-B slabs from global memory, slabs from the LDS-resident top, 48-B triangle records, 112-B
-// instance records -- summed into walk[0..4] = rays, global slabs, LDS slabs, triangles, instance entries; walk[5] =
+// fetches -- 64-B nodes from global memory, nodes from the LDS-resident top, 48-B triangle records, 112-B
+// instance records -- summed into walk[0..4] = rays, nodes from global memory, nodes from LDS, triangles, instance entries; walk[5] =
 // max over rays of (node steps << 32 | ray index), the longest single walk (a tail detector).
 // These per-ray numbers depend on the ray and the tree only, not on chunking or lane assignment.
 template <int STACK, int BLOCK, bool TWO_LEVEL, uint32_t CHUNK, bool ANYHIT = false, bool COUNT = false, class Src, class Sink>
@@ -169,17 +240,18 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 
     // single-level scenes (one identity instance) walk the BLAS directly in world space
     const InstanceRec *in0 = sc.inst;
-    const Slab *blas_slabs0 = TWO_LEVEL ? nullptr : in0->slabs;
+    const WNode *blas_nodes0 = TWO_LEVEL ? nullptr : in0->wide;
     const TriRec *tris0 = TWO_LEVEL ? nullptr : in0->tris;
-    // the LDS-resident top of the tree (single-level walks): smem rows STACK .. STACK + RT_TOP_ROWS - 1
+    // the LDS-resident top of the tree: smem rows STACK .. STACK + RT_TOP_ROWS - 1 hold nodes 0 .. top_n - 1 (breadth-first
+    // numbering) of the structure a ray starts in: the BLAS of a single-level scene, the TLAS of a two-level one
     int *topl = smem + STACK * BLOCK;
-    const bool have_top = sc.top_n != 0;          // single-level: top of the BLAS; two-level: top of the TLAS
-    if (have_top) {
-        const int *src_top = (const int *)sc.top;
+    if (sc.top_n != 0) {
+        const int *src_top = (const int *)(TWO_LEVEL ? sc.tlas_wide : blas_nodes0);
         for (uint32_t i = threadIdx.x; i < sc.top_n * 16u; i += BLOCK) topl[i] = src_top[i];
         __syncthreads();
     }
-    const int root0 = have_top ? RT_NODE_TOP : (TWO_LEVEL ? sc.tlas_root_code : in0->root_code);
+    const int root0 = TWO_LEVEL ? sc.tlas_root_code : in0->root_code;
+    uint32_t top_lim = sc.top_n;                  // node indices below this are read from LDS (two-level: 0 while inside a BLAS)
 
     bool alive = false;
     bool exhausted = false;          // wave-uniform: the global pool has nothing left
@@ -196,7 +268,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
     int sp = 0;
     // two-level state
     ObjRay cur;                       // ray in the space of the structure being walked
-    const Slab *slabs = TWO_LEVEL ? sc.tlas_slabs : blas_slabs0;
+    const WNode *nodes = TWO_LEVEL ? sc.tlas_wide : blas_nodes0;
     const InstanceRec *in = in0;
     const TriRec *tris = tris0;
     uint32_t ii = 0;
@@ -248,7 +320,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     cur.o = r.o; cur.d = r.d; cur.ri = wri;
                     node = root0;
                     sp = 0;
-                    if (TWO_LEVEL) { slabs = sc.tlas_slabs; in_blas = false; }
+                    if (TWO_LEVEL) { nodes = sc.tlas_wide; in_blas = false; top_lim = sc.top_n; }
                     alive = true;
                     n_traced++;
                     if (COUNT) wk_ray0 = wk_glob + wk_top;
@@ -268,10 +340,10 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 #if RT_EXIT_K > 0
         const int n_alive = __popcll(__ballot(alive));
 #endif
-        while (alive && node_is_internal(node) && sp < STACK) {
+        while (alive && node_is_internal(node) && sp <= STACK - 3) {
             RT_STAT_WAVE(0); RT_STAT_LANE(0);
-            if (COUNT) { if (node & RT_NODE_TOP) wk_top++; else wk_glob++; }
-            node_step<false, true, ANYHIT>(slabs, topl, cur.ri, r.tmin, best.t, st, node, sp);
+            if (COUNT) { if ((uint32_t)node < top_lim) wk_top++; else wk_glob++; }
+            wide_step<false, ANYHIT>(nodes, topl, top_lim, cur.ri, r.tmin, best.t, st, node, sp);
 #ifdef RT_TRACE_STATS
             st_maxsp = sp > st_maxsp ? sp : st_maxsp;
 #endif
@@ -282,9 +354,12 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 #endif
         }
         // lanes whose stack has outgrown the LDS rows walk on with the global rows until it fits again
-        while (alive && node_is_internal(node) && sp >= STACK) {
-            if (COUNT) { if (node & RT_NODE_TOP) wk_top++; else wk_glob++; }
-            node_step<true, true, ANYHIT>(slabs, topl, cur.ri, r.tmin, best.t, st, node, sp);
+        while (alive && node_is_internal(node) && sp > STACK - 3) {
+            if (COUNT) { if ((uint32_t)node < top_lim) wk_top++; else wk_glob++; }
+            wide_step<true, ANYHIT>(nodes, topl, top_lim, cur.ri, r.tmin, best.t, st, node, sp);
+#ifdef RT_TRACE_STATS
+            st_maxsp = sp > st_maxsp ? sp : st_maxsp;
+#endif
         }
 
         // ---- leaves, instance entry / exit, termination -----------------------------------
@@ -303,7 +378,8 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 if (COUNT) { const unsigned long long w = ((unsigned long long)(wk_glob + wk_top - wk_ray0) << 32) | idx; wk_longest = w > wk_longest ? w : wk_longest; }
             } else if (TWO_LEVEL && node == RT_NODE_SENTINEL) {
                 in_blas = false;
-                slabs = sc.tlas_slabs;
+                nodes = sc.tlas_wide;
+                top_lim = sc.top_n;
                 cur.o = r.o; cur.d = r.d; cur.ri = wri;
             } else if (TWO_LEVEL && !in_blas) {
                 ii = (uint32_t)~node;
@@ -316,9 +392,10 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 }
                 if (enter) {
                     cur = to_object(*in, r);
-                    slabs = in->slabs;
+                    nodes = in->wide;
                     tris = in->tris;
                     in_blas = true;
+                    top_lim = 0;
                     st.write(sp, RT_NODE_SENTINEL);
                     sp++;
                     node = in->root_code;
