@@ -12,12 +12,12 @@ LIB = $(LIBDIR)/$(LIBNAME)
 HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math \
            -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize \
            -Wall -Wno-unused-function -Iinclude $(EXTRA)
-SRCS = $(CSRC)/rt_api.hip $(CSRC)/rt_bvh_build.hip $(CSRC)/rt_bvh_ploc.hip $(CSRC)/rt_bvh_wide.hip $(CSRC)/rt_trace.hip $(CSRC)/rt_pipeline.hip $(CSRC)/rt_denoise.hip \
+SRCS = $(CSRC)/rt_api.hip $(CSRC)/rt_bvh_build.hip $(CSRC)/rt_bvh_ploc.hip $(CSRC)/rt_bvh_wide.hip $(CSRC)/rt_trace.hip $(CSRC)/rt_pipeline.hip $(CSRC)/rt_denoise.hip $(CSRC)/rt_dist.hip \
        $(CSRC)/rt_obj.cpp $(CSRC)/rt_host.cpp $(CSRC)/rt_dds.cpp $(CSRC)/rt_image.cpp
 HDRS = $(wildcard $(CSRC)/*.h) include/dxr_amd.h include/dxr_amd_types.h
 OBJS = $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
 
-BIN = $(LIBDIR)/progressive $(LIBDIR)/realtime_denoise $(LIBDIR)/test_wrapper
+BIN = $(LIBDIR)/progressive $(LIBDIR)/realtime_denoise $(LIBDIR)/test_wrapper $(LIBDIR)/progressive_multi
 CXX ?= g++
 HOSTFLAGS = -O2 -std=c++17 -Wall -Iinclude -Idxrexperiments_amd/include
 HOSTLINK = -L$(LIBDIR) -ldxrexperiments_amd -L/opt/rocm/lib -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib
@@ -29,6 +29,9 @@ $(LIBDIR)/progressive: examples/progressive.cpp $(LIB) $(wildcard dxrexperiments
 	$(CXX) $(HOSTFLAGS) $< -o $@ $(HOSTLINK)
 
 $(LIBDIR)/realtime_denoise: examples/realtime_denoise.cpp $(LIB) $(wildcard dxrexperiments_amd/include/*.h)
+	$(CXX) $(HOSTFLAGS) $< -o $@ $(HOSTLINK)
+
+$(LIBDIR)/progressive_multi: examples/progressive_multi.cpp $(LIB) $(wildcard dxrexperiments_amd/include/*.h)
 	$(CXX) $(HOSTFLAGS) $< -o $@ $(HOSTLINK)
 
 $(LIBDIR)/test_wrapper: tests/cpp/test_wrapper.cpp $(LIB) $(wildcard dxrexperiments_amd/include/*.h)
@@ -44,7 +47,7 @@ build/%.cpp.o: $(CSRC)/%.cpp $(HDRS)
 
 $(LIB): $(OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -ldl
 
 oracle:
 	$(MAKE) -C oracle liboracle.so

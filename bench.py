@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--hbm-frames", type=int, default=8, help="frames of the HBM-bound 10 M-triangle 4K workload timed for roofline_hbm "
                     "(rank 0, N=1 only); 0 = skip")
     ap.add_argument("--workload", choices=("c2", "c5"), default="c2", help="c5: ONLY the 10 M-triangle workload (profiling passes)")
+    ap.add_argument("--partition", choices=("samples", "tiles"), default="samples",
+                    help="samples (default, the headline): frames sharded over the GPUs, one all-reduce.  tiles: BASELINE configs[4], the "
+                         "10 M-triangle 4K 4-bounce frame split into interleaved 16-row bands over the GPUs, one all-gather of the bands")
     return ap.parse_args()
 
 
@@ -232,6 +235,78 @@ def hbm_workload(ctx, capi, T, scenes, frames, warm):
             "bvh_build_ms": scene.build_ms(), "generate_s": gen_s, "stages": stages, "launches_timed": n_t}
 
 
+def tiles_main(args, rank, world, local_rank, dev, capi, D, T, scenes, torch, dist):
+    """BASELINE configs[4]: the 10 M-triangle mesh at 3840x2160 with 4 radiance bounces, tile-partitioned:
+    every rank renders its interleaved 16-row bands of EVERY frame (pixels are seeded by their global index, so the bands
+    equal the same rows of the whole frame bit for bit) and ONE all-gather of the disjoint bands closes the timed region.
+    Strong scaling: the frame is fixed, the rows per GPU shrink as N grows."""
+    W, H, K, Wu, band = 3840, 2160, args.steps, args.warmup, 16
+    v, tri = scenes.displaced_grid(2236, seed=7)
+    ctx = capi.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    scene = capi.Scene(ctx)
+    scene.add_model(capi.Model(ctx, v, tri))
+    pipe = capi.Pipeline(ctx)
+    pipe.set_scene(scene)
+    mat = T.default_material()
+    mat["type"] = 2
+    mat["reflectivity"] = 0.6
+    mat["roughness"] = 0.3
+    pipe.add_material(mat)
+    pipe.set_depth_limits(4, 2)
+    pipe.set_environment_cube(scenes.sky_cubemap(32))
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    pipe.bind_output(acc.data_ptr(), W, H)
+    pipe.build_acceleration_structures()
+    host = capi.ProgressiveHost(3)
+    host.options["maxIterations"] = 1 << 20
+    cam = capi.camera_array((0.0, 6.0, 19.0), (0.0, -4.0, 0.0), (0, 1, 0), 0.8, W / H)
+    pfcs = [host.update(cam, 0.0, f + 1, W, H) for f in range(Wu + K)]
+
+    def step(i):
+        pipe.update(pfcs[i])
+        pipe.render_bands(band, rank, world)          # all of this rank's bands in one set of launches
+
+    for i in range(Wu):
+        step(i)
+    if world > 1:
+        D.gather_tiles(acc.clone(), band)             # warm the collective
+        dist.barrier()
+    torch.cuda.synchronize()
+    pipe.reset_totals()
+    t0 = time.perf_counter()
+    for i in range(Wu, Wu + K):
+        step(i)
+    if world > 1:
+        D.gather_tiles(acc, band)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tot = pipe.totals()
+    red = torch.tensor([elapsed, float(tot["rays_primary"] + tot["rays_secondary"] + tot["rays_shadow"]), float(tot["rays_primary"])],
+                       dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = red.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0].item())
+    if rank == 0:
+        slots, floats = capi.tile_gather_layout(W, H, band, world)
+        print(json.dumps({
+            "metric": "Mrays/s (all traced rays), 10 M triangles 3840x2160 4-bounce progressive, tile-partitioned",
+            "value": float(red[1].item()) / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wu,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: displaced-grid mesh (seed 7, %d triangles), %dx%d, 4 radiance bounces, 1 spp/frame, "
+                                   "interleaved %d-row bands per GPU" % (tri.shape[0], W, H, band),
+                       "parallelism": "tile-partitioned x%d, one all-gather of %d band slots per rank (%.1f MB sent per rank)"
+                                      % (world, slots, floats * 4 / 1e6) if world > 1 else "single GPU",
+                       "frames": K},
+            "frames_per_s": K / elapsed, "primary_mrays_per_s": float(red[2].item()) / elapsed / 1e6, "bvh_build_ms": scene.build_ms()}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -261,6 +336,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm: xGMI between the GPUs of the node
         else:
             dist.init_process_group(backend)
+
+    if args.partition == "tiles":
+        return tiles_main(args, rank, world, local_rank, dev, capi, D, T, scenes, torch, dist)
 
     if args.workload == "c5":            # profiling passes: only the HBM-bound workload, one JSON line of its own
         assert world == 1, "--workload c5 is a single-GPU profiling mode"

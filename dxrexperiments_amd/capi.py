@@ -125,6 +125,7 @@ SIGNATURES = {
     "rt_pipeline_reset_totals": (_i, [_p]),
     "rt_pipeline_count_work": (_i, [_p, C.POINTER(StageWork)]),
     "rt_pipeline_count_walk": (_i, [_p, C.POINTER(StageWalk)]),
+    "rt_pipeline_render_bands": (_i, [_p, _u32, _u32, _u32, _u32, _u32]),
     "rt_debug_read_secondary_ray": (_i, [_p, _u32, _p, _p]),
     "rt_camera_look": (_i, [_p, _p, _p, _p, _p]),
     "rt_camera_basis": (_i, [_p, _p, _f, _f, _p, _p, _p]),
@@ -142,6 +143,15 @@ SIGNATURES = {
     "rt_debug_sample": (_i, [_p, _i, _p, _p, _f, _p, _p, _p, _sz]),
     "rt_debug_sample_cube": (_i, [_p, _p, _u32, _u32, _p, _p, _sz]),
     "rt_pipeline_set_environment_filter": (_i, [_p, _u32]),
+    "rt_shard_frame_count": (_i, [_u32, _u32, _u32, C.POINTER(C.c_uint32)]),
+    "rt_tile_bands": (_i, [_u32, _u32, _u32, _u32, _p, _p, _u32, C.POINTER(C.c_uint32)]),
+    "rt_tile_gather_layout": (_i, [_u32, _u32, _u32, _u32, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]),
+    "rt_dist_get_unique_id": (_i, [_p]),
+    "rt_dist_create": (_i, [_p, _i, _i, _p, _pp]),
+    "rt_dist_destroy": (_i, [_p]),
+    "rt_dist_get_rank": (_i, [_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rt_dist_all_reduce_sum": (_i, [_p, _p, _sz]),
+    "rt_dist_gather_bands": (_i, [_p, _p, _u32, _u32, _u32]),
     "rt_dds_read_cube": (_i, [C.c_char_p, _p, _sz, C.POINTER(C.c_uint32)]),
     "rt_obj_read": (_i, [C.c_char_p, _p, _u32, _p, _u32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }
@@ -455,6 +465,10 @@ class Pipeline:
         else:
             _check(lib().rt_pipeline_render_tile(self.h, self.width, self.height, *tile))
 
+    def render_bands(self, band_rows, rank, world):
+        """One frame over this rank's interleaved row bands (tile-partitioned multi-GPU runs)."""
+        _check(lib().rt_pipeline_render_bands(self.h, self.width, self.height, band_rows, rank, world))
+
     @property
     def num_outputs(self):
         n = C.c_int()
@@ -524,6 +538,60 @@ class Pipeline:
         t = np.empty(n, np.float32); prim = np.empty(n, np.uint32); inst = np.empty(n, np.uint32)
         _check(lib().rt_pipeline_read_primary_hits(self.h, _ptr(t), _ptr(prim), _ptr(inst)))
         return t, prim, inst
+
+
+def shard_frame_count(rank, world, n_frames):
+    """|{f < n_frames : f mod world == rank}| (partition A of SURVEY 8(e)); host logic of the C ABI, no device."""
+    n = C.c_uint32(0)
+    _check(lib().rt_shard_frame_count(rank, world, n_frames, C.byref(n)))
+    return n.value
+
+
+def tile_bands(height, band_rows, rank, world):
+    """Interleaved row bands of `rank` as (y0, y1) pairs (partition B); host logic of the C ABI, no device."""
+    n = C.c_uint32(0)
+    _check(lib().rt_tile_bands(height, band_rows, rank, world, None, None, 0, C.byref(n)))
+    y0 = np.zeros(max(n.value, 1), np.uint32)
+    y1 = np.zeros(max(n.value, 1), np.uint32)
+    _check(lib().rt_tile_bands(height, band_rows, rank, world, _ptr(y0), _ptr(y1), n.value, C.byref(n)))
+    return [(int(a), int(b)) for a, b in zip(y0[:n.value], y1[:n.value])]
+
+
+def tile_gather_layout(width, height, band_rows, world):
+    """(band slots per rank, floats per rank) of the all-gather that combines the bands."""
+    slots, floats = C.c_uint32(0), C.c_size_t(0)
+    _check(lib().rt_tile_gather_layout(width, height, band_rows, world, C.byref(slots), C.byref(floats)))
+    return slots.value, floats.value
+
+
+class Dist:
+    """rt_dist: RCCL from the C ABI (one process per GPU).  uid = Dist.unique_id() on rank 0, handed to the other ranks."""
+
+    @staticmethod
+    def unique_id():
+        buf = np.zeros(128, np.uint8)
+        _check(lib().rt_dist_get_unique_id(_ptr(buf)))
+        return buf.tobytes()
+
+    def __init__(self, ctx, rank, world, uid):
+        self.ctx = ctx
+        h = C.c_void_p()
+        buf = np.frombuffer(uid, np.uint8).copy()
+        _check(lib().rt_dist_create(ctx.h, int(rank), int(world), _ptr(buf), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rt_dist_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def all_reduce_sum(self, device_ptr, count):
+        _check(lib().rt_dist_all_reduce_sum(self.h, C.c_void_p(device_ptr), int(count)))
+
+    def gather_bands(self, device_ptr, width, height, band_rows):
+        _check(lib().rt_dist_gather_bands(self.h, C.c_void_p(device_ptr), width, height, band_rows))
 
 
 def dds_read_cube(path):

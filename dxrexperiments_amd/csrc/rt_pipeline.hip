@@ -81,6 +81,8 @@ struct PipeDev {
     uint32_t width, height;
     uint32_t x0, y0, tw, th, cap;       // tile rectangle; cap = tiles_x * tiles_y * 64 pixel slots
     uint32_t tiles_x;
+    uint32_t band_rows, band_rank, band_world;      // band_rows != 0: the rectangle's rows are interleaved bands of the image
+    uint32_t n_pixels;                  // pixels of the image this launch covers
     uint32_t max_rad, max_shadow;
     uint32_t accum_mode;
     uint32_t kind;                      // RT_PIPELINE_PROGRESSIVE / RT_PIPELINE_REALTIME
@@ -186,6 +188,10 @@ RT_DEV bool pix_xy(const PipeDev &pd, uint32_t q, uint32_t &px, uint32_t &py)
     const uint32_t t = q >> 6, w = q & 63u;
     const uint32_t lx = (t % pd.tiles_x) * 8u + (w & 7u), ly = (t / pd.tiles_x) * 8u + (w >> 3);
     px = pd.x0 + lx;
+    if (pd.band_rows) {         // rows of the rectangle = this rank's interleaved bands, packed (rt_pipeline_render_bands)
+        py = ((ly / pd.band_rows) * pd.band_world + pd.band_rank) * pd.band_rows + ly % pd.band_rows;
+        return lx < pd.tw && ly < pd.th && py < pd.height;
+    }
     py = pd.y0 + ly;
     return lx < pd.tw && ly < pd.th;
 }
@@ -844,6 +850,7 @@ struct rt_pipeline {
     uint32_t last_shadow_slots = 2;
     rt_stats stats;
     uint32_t last_tile[4] = {0, 0, 0, 0};
+    uint32_t last_pixels = 0;
     bool rendered = false;
     uint32_t last_scene_gen = 0;       // generation of the scene last_pd was filled from
 };
@@ -925,7 +932,7 @@ void launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
     if (levels <= 1) k_resolve<1><<<blocks(cap), PBLOCK, 0, st>>>(pd);
     else k_resolve<MAXD><<<blocks(cap), PBLOCK, 0, st>>>(pd);
     if (T) { (void)hipEventRecord(ev[EV_RESOLVE], st); p->ring_levels[ring_slot] = (uint8_t)levels; p->ring_pos++; }
-    k_add_totals<<<1, 64, 0, st>>>(pd.counters, p->totals.as<unsigned long long>(), pd.tw * pd.th);
+    k_add_totals<<<1, 64, 0, st>>>(pd.counters, p->totals.as<unsigned long long>(), pd.n_pixels);
 }
 
 template <int STACK>
@@ -1141,7 +1148,10 @@ int rt_pipeline_update(rt_pipeline *p, const rt_per_frame_constants *constants)
     return RT_OK;
 }
 
-int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
+// one frame over the rectangle [x0,x1) x [y0,y1); band_rows != 0: over the interleaved bands {b : b mod band_world == band_rank}
+// of band_rows rows each (the rectangle then spans the full width and the rank's rows, packed)
+static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                         uint32_t band_rows, uint32_t band_rank, uint32_t band_world)
 {
     RT_REQUIRE(p, "null pipeline");
     if (!p->scene || !p->scene->built) { rt_set_error("render: acceleration structures not built"); return RT_ERR_STATE; }
@@ -1150,7 +1160,7 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
     if (p->mats.empty()) { rt_set_error("render: no material"); return RT_ERR_STATE; }
     RT_REQUIRE(width == p->width && height == p->height, "width/height differ from the output resource");
     if (x1 > width) x1 = width;
-    if (y1 > height) y1 = height;
+    if (!band_rows && y1 > height) y1 = height;      // (band mode: y counts the rank's packed rows, checked per pixel)
     RT_REQUIRE(x0 < x1 && y0 < y1, "empty tile");
     rt_context *ctx = p->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1186,6 +1196,14 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
     for (int k = 0; k < 3; k++) pd.env_const[k] = p->env_const[k];
     pd.width = width; pd.height = height;
     pd.x0 = x0; pd.y0 = y0; pd.tw = tw; pd.th = th; pd.cap = cap; pd.tiles_x = tiles_x;
+    pd.band_rows = band_rows; pd.band_rank = band_rank; pd.band_world = band_world;
+    uint32_t owned_rows = th;
+    if (band_rows) {            // rows of the rank's bands that lie inside the image (the last band may be short)
+        owned_rows = 0;
+        for (uint32_t b = band_rank; (uint64_t)b * band_rows < height; b += band_world)
+            owned_rows += (uint64_t)(b + 1) * band_rows <= height ? band_rows : height - b * band_rows;
+    }
+    pd.n_pixels = tw * owned_rows;
     pd.max_rad = p->max_rad; pd.max_shadow = p->max_shadow;
     pd.accum_mode = p->accum_mode;
     pd.kind = p->kind;
@@ -1212,8 +1230,24 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uin
     p->last_shadow_slots = shadow_slots;
     p->last_scene_gen = p->scene->generation;
     p->last_tile[0] = x0; p->last_tile[1] = y0; p->last_tile[2] = x1; p->last_tile[3] = y1;
+    p->last_pixels = pd.n_pixels;
     p->rendered = true;
     return RT_OK;
+}
+
+int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
+{
+    return render_region(p, width, height, x0, y0, x1, y1, 0, 0, 1);
+}
+
+int rt_pipeline_render_bands(rt_pipeline *p, uint32_t width, uint32_t height, uint32_t band_rows, uint32_t rank, uint32_t world)
+{
+    RT_REQUIRE(world > 0 && rank < world, "rank outside [0, world)");
+    RT_REQUIRE(band_rows > 0 && band_rows % 8 == 0, "band_rows must be a positive multiple of 8 (pixel slots are 8x8 tiles)");
+    uint32_t n = 0;
+    RT_TRY(rt_tile_bands(height, band_rows, rank, world, nullptr, nullptr, 0, &n));
+    if (n == 0) return RT_OK;                   // more ranks than bands: nothing to render here
+    return render_region(p, width, height, 0, 0, width, n * band_rows, band_rows, rank, world);
 }
 
 int rt_pipeline_render(rt_pipeline *p, uint32_t width, uint32_t height)
@@ -1387,7 +1421,7 @@ int rt_pipeline_get_stats(rt_pipeline *p, rt_stats *out)
     if (!p->rendered) return RT_OK;
     uint32_t c[C_COUNT];
     HIP_TRY(hipMemcpy(c, p->counters.p, sizeof c, hipMemcpyDeviceToHost));
-    out->rays_primary = (uint64_t)(p->last_tile[2] - p->last_tile[0]) * (p->last_tile[3] - p->last_tile[1]);
+    out->rays_primary = p->last_pixels;
     out->primary_hits = c[C_NHIT];
     out->secondary_hits = 0;
     for (int l = 1; l <= MAXD; l++) out->secondary_hits += c[C_NHIT + l];

@@ -16,6 +16,8 @@ backend (the tests drive them over gloo on CPU).
 import torch
 import torch.distributed as dist
 
+from . import capi
+
 
 def shard_frames(rank, world_size, n_frames, first_frame=0):
     """Frame indices rank `rank` renders: first_frame + {f : f mod world_size == rank}."""
@@ -23,7 +25,8 @@ def shard_frames(rank, world_size, n_frames, first_frame=0):
 
 
 def frames_per_rank(world_size, n_frames):
-    return [len(range(r, n_frames, world_size)) for r in range(world_size)]
+    """Frames each rank renders: the C ABI's own partition (rt_shard_frame_count), so C++ and Python callers agree."""
+    return [capi.shard_frame_count(r, world_size, n_frames) for r in range(world_size)]
 
 
 def reduce_accumulation(sum_buffer, n_local_frames, group=None):
@@ -40,21 +43,42 @@ def reduce_accumulation(sum_buffer, n_local_frames, group=None):
     return sum_buffer / float(max(total, 1)), total
 
 
-def tile_rows(rank, world_size, height, band=64):
-    """Partitioning B (image tiles): interleaved bands of `band` rows owned by `rank`,
-    as (y0, y1) pairs.  Pixels are seeded by their GLOBAL index, so the tiled image is
-    bit-identical to the single-GPU one and needs no arithmetic exchange."""
-    out = []
-    for b, y0 in enumerate(range(0, height, band)):
-        if b % world_size == rank:
-            out.append((y0, min(y0 + band, height)))
-    return out
+def tile_rows(rank, world_size, height, band=16):
+    """Partitioning B (image tiles): interleaved bands of `band` rows owned by `rank`, as (y0, y1) pairs -- the C ABI's
+    rt_tile_bands.  Pixels are seeded by their GLOBAL index, so the tiled image is bit-identical to the single-GPU one
+    and needs no arithmetic exchange."""
+    return capi.tile_bands(height, band, rank, world_size)
 
 
 def combine_tiles(image, group=None):
-    """Partitioning B, the only exchange: every rank rendered its own bands into an otherwise ZERO buffer
-    (rt_pipeline_render_tile leaves foreign pixels untouched), so a SUM all-reduce is a gather -- x + 0 == x
-    exactly -- and every rank ends up with the whole image, bit-identical to the single-GPU frame."""
+    """Partitioning B combined with ONE SUM all-reduce: every rank rendered its own bands into an otherwise ZERO buffer
+    (rt_pipeline_render_tile leaves foreign pixels untouched), so the sum is a gather -- x + 0 == x exactly.  Simple, but
+    it moves two images per rank; gather_tiles moves one."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(image, op=dist.ReduceOp.SUM, group=group)
+    return image
+
+
+def gather_tiles(image, band=16, group=None):
+    """Partitioning B combined with ONE all-gather of the disjoint bands (what rt_dist_gather_bands does from C): rank r
+    packs its bands b = r, r + R, ... into ceil(bands / R) slots, the all-gather delivers every rank's slots, and each band
+    is copied to its rows.  Every rank receives (R-1)/R of one image: half the bytes of the SUM all-reduce.  In place on
+    `image` (H, W, 4 float32); foreign rows need not be zero."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return image
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    H, W = image.shape[0], image.shape[1]
+    slots, floats = capi.tile_gather_layout(W, H, band, world)
+    send = torch.zeros((slots, band, W, 4), dtype=image.dtype, device=image.device)
+    for s, (y0, y1) in enumerate(tile_rows(rank, world, H, band)):
+        send[s, :y1 - y0] = image[y0:y1]
+    assert send.numel() == floats
+    flat = torch.empty((world * slots, band, W, 4), dtype=image.dtype, device=image.device)     # rank-major concatenation
+    dist.all_gather_into_tensor(flat, send, group=group)
+    recv = flat.view(world, slots, band, W, 4)
+    for r in range(world):
+        if r == rank:
+            continue
+        for s, (y0, y1) in enumerate(tile_rows(r, world, H, band)):
+            image[y0:y1] = recv[r, s, :y1 - y0]
     return image

@@ -40,6 +40,21 @@ public:
     virtual void render(UINT frameIndex, UINT width, UINT height) override
     {
         (void)frameIndex;
+        fillShaderTable();
+        mRtContext->raytrace(mRtBindings, mRtState, width, height, 3);
+    }
+
+    // The same frame restricted to the interleaved row bands {b : b mod world == rank} of bandRows rows (a tile-partitioned
+    // multi-GPU run, examples/progressive_multi.cpp); no counterpart in the single-GPU reference.
+    void renderBands(UINT width, UINT height, UINT bandRows, UINT rank, UINT world)
+    {
+        fillShaderTable();
+        DXRFramework::ThrowIfFailed(rt_pipeline_render_bands(mPipeline, width, height, bandRows, rank, world));
+    }
+
+    // what render() does before DispatchRays (:217-240): per-instance hit records, miss records, apply
+    void fillShaderTable()
+    {
         auto program = mRtBindings->getProgram();
         for (UINT rayType = 0; rayType < program->getHitProgramCount(); ++rayType) {
             for (UINT instance = 0; instance < mRtScene->getNumInstances(); ++instance) {
@@ -56,7 +71,6 @@ public:
             missVars->appendHeapRanges(0);            // envCubemap: set by loadResources / setEnvironment*
         }
         mRtBindings->apply(mRtContext, mRtState);
-        mRtContext->raytrace(mRtBindings, mRtState, width, height, 3);
     }
 
     // loadResources (:104-125): the radiance cube map.  The reference's path is hard-coded; pass "" for a

@@ -163,6 +163,9 @@ int rt_pipeline_render(rt_pipeline *p, uint32_t width, uint32_t height);
 /* same, restricted to pixel rectangle [x0,x1) x [y0,y1) (tile sharding) */
 int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height,
                             uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
+/* same, restricted to the interleaved row bands {b : b mod world == rank} of band_rows rows each (rt_tile_bands), all of
+ * them in ONE set of launches: the per-frame call of a tile-partitioned multi-GPU run.  band_rows must be a multiple of 8. */
+int rt_pipeline_render_bands(rt_pipeline *p, uint32_t width, uint32_t height, uint32_t band_rows, uint32_t rank, uint32_t world);
 int rt_pipeline_get_num_outputs(const rt_pipeline *p, int *n);               /* getNumOutputs .h:34 */
 int rt_pipeline_get_output_device_ptr(rt_pipeline *p, uint32_t id, void **ptr); /* getOutputResource .h:35 */
 /* synchronises; host buffer is w*h*4 floats (RGBA32F) or halfs (RGBA16F) */
@@ -243,6 +246,29 @@ int rt_denoiser_get_output_device_ptr(rt_denoiser *d, void **ptr);              
 int rt_denoiser_read_output(rt_denoiser *d, void *host, size_t bytes);                         /* final (pass V) image */
 int rt_denoiser_read_intermediate(rt_denoiser *d, void *host, size_t bytes);                   /* pass H image (tests) */
 int rt_denoiser_last_ms(rt_denoiser *d, float *ms);
+
+/* ---- multi-GPU: the reference drives one device (src/DXRExperimentsApp.cpp:107-130); a multi-GPU caller is
+ *      one such process PER GPU (scene and acceleration structures replicated) and exactly one collective, issued on the
+ *      context's stream through RCCL (librccl.so is opened on first use).  Create the processes before any of them
+ *      touches the GPU.  examples/progressive_multi.cpp is the worked example; DESIGN.md section 5 the cost model. ---- */
+/* host-side partitions (no device needed) */
+/* frames {f < n_frames : f mod world == rank} (partition A: sample batches, rendered with RT_ACCUM_SUM) */
+int rt_shard_frame_count(uint32_t rank, uint32_t world, uint32_t n_frames, uint32_t *count);
+/* interleaved row bands {b : b mod world == rank}, band b = rows [b*band_rows, min((b+1)*band_rows, height)) (partition B:
+ * image tiles for rt_pipeline_render_tile); y0 / y1 may be NULL to count */
+int rt_tile_bands(uint32_t height, uint32_t band_rows, uint32_t rank, uint32_t world, uint32_t *y0, uint32_t *y1, uint32_t capacity,
+                  uint32_t *n_bands);
+/* what rt_dist_gather_bands sends per rank: ceil(bands / world) band slots of band_rows x width RGBA32F texels */
+int rt_tile_gather_layout(uint32_t width, uint32_t height, uint32_t band_rows, uint32_t world, uint32_t *slots_per_rank, size_t *floats_per_rank);
+typedef struct rt_dist rt_dist;
+int rt_dist_get_unique_id(void *id128);                                   /* ncclGetUniqueId: rank 0 makes it, the launcher hands it round */
+int rt_dist_create(rt_context *ctx, int rank, int world, const void *id128, rt_dist **out);   /* ncclCommInitRank on ctx's device */
+int rt_dist_destroy(rt_dist *d);
+int rt_dist_get_rank(const rt_dist *d, int *rank, int *world);
+/* partition A: in-place SUM all-reduce of `count` floats (the RT_ACCUM_SUM image of rt_pipeline_get_output_device_ptr) */
+int rt_dist_all_reduce_sum(rt_dist *d, void *device_f32, size_t count);
+/* partition B: every rank holds its own bands of the width x height RGBA32F image; afterwards every rank holds all of it */
+int rt_dist_gather_bands(rt_dist *d, void *device_rgba32f, uint32_t width, uint32_t height, uint32_t band_rows);
 
 /* ---- image files for host copies of the outputs (the reference only blits to its window,
  *      src/DXRExperimentsApp.cpp:213-214).  rgba32f = width*height float4, row 0 on top. ---------------- */

@@ -1,6 +1,7 @@
 """Run under torch.distributed.run: BASELINE config 5's multi-GPU scheme (image tiles, no arithmetic exchange).
 Every rank renders its interleaved row bands of N progressive frames of the same scene, the bands are combined
-with one all-reduce, and rank 0 checks the result bit for bit against the whole frame rendered by itself.
+with one all-gather (and, for comparison, with one all-reduce), and rank 0 checks the result bit for bit against the
+whole frame rendered by itself.
 Test hook: DXR_BENCH_DEVICE / DXR_BENCH_BACKEND as in bench.py (two ranks on the one GPU of a test box, gloo)."""
 import os
 import sys
@@ -31,7 +32,7 @@ def main():
     host = capi.ProgressiveHost(5)
     pfcs = [host.update(cam, 0.0, f + 1, W, H) for f in range(frames)]
 
-    def render(rows):
+    def render(rows, bands=None):
         img = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
         pipe = capi.Pipeline(ctx)
         pipe.set_scene(scene)
@@ -41,14 +42,20 @@ def main():
         pipe.build_acceleration_structures()
         for pfc in pfcs:
             pipe.update(pfc)
-            for (y0, y1) in rows:
-                pipe.render(tile=(0, y0, W, y1))
+            if bands:
+                pipe.render_bands(*bands)                # all bands of a rank in one set of launches
+            else:
+                for (y0, y1) in rows:
+                    pipe.render(tile=(0, y0, W, y1))
         ctx.synchronize()
         return img
 
     mine = render(D.tile_rows(rank, world, H, band=16))
-    whole = D.combine_tiles(mine)
+    assert torch.equal(mine, render(None, bands=(16, rank, world)))      # rt_pipeline_render_bands == band by band
+    whole = D.gather_tiles(mine.clone(), band=16)            # one all-gather of the disjoint bands
+    summed = D.combine_tiles(mine)                           # the simpler form: one SUM all-reduce over a zero background
     torch.cuda.synchronize()
+    assert torch.equal(whole, summed)
     if rank == 0:
         ref = render([(0, H)])
         torch.cuda.synchronize()

@@ -425,3 +425,36 @@ def test_cornell_lit_by_the_reference_environment_map(gpu, capi, tmp_path):
             p.render()
             assert np.array_equal(p.read_output(), g[key]), "via_dds=%s seamless=%s" % (via_dds, seamless)
     assert not np.array_equal(g["cornell_lit"], g["cornell_lit_clamp"])
+
+
+@pytest.mark.parametrize("world,band", [(1, 16), (3, 8), (4, 24)])
+def test_render_bands_equals_the_whole_frame(gpu, capi, world, band):
+    """rt_pipeline_render_bands (the per-frame call of a tile-partitioned multi-GPU run): the ranks' interleaved bands,
+    rendered one rank after the other into one image, equal the whole frame bit for bit, ragged last band included;
+    ray counts add up."""
+    W, H = 200, 141
+    v, i = triangle_soup(2500, 9)
+    p = make_gpu_pipeline(capi, gpu, [(v, i)], [(0, None)], [T.default_material()], W, H, env=scenes.sky_cubemap(8))
+    host = capi.ProgressiveHost(2)
+    cam = cam_array(dict(eye=(0, 0, 30), at=(0, 0, 0), up=(0, 1, 0), fov=0.8), W / H)
+    pfcs = [host.update(cam, 0.0, f + 1, W, H) for f in range(2)]
+    for pfc in pfcs:
+        p.update(pfc)
+        p.render()
+    whole, st = p.read_output(), p.stats()
+    p.clear_output()
+    rays = 0
+    for pfc in pfcs:
+        p.update(pfc)
+        rays = 0
+        for r in range(world):
+            p.render_bands(band, r, world)
+            s = p.stats()
+            rays += s["rays_primary"]
+            assert s["rays_primary"] == W * sum(y1 - y0 for y0, y1 in capi.tile_bands(H, band, r, world))
+    assert np.array_equal(p.read_output(), whole)
+    assert rays == st["rays_primary"] == W * H
+    with pytest.raises(capi.RtError):
+        p.render_bands(12, 0, 1)                    # not a multiple of the 8x8 pixel tiles
+    with pytest.raises(capi.RtError):
+        p.render_bands(16, 2, 2)

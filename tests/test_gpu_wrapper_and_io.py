@@ -135,3 +135,27 @@ def test_realtime_denoise_example_writes_png(tmp_path):
         pos += 12 + n
     px = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(64, 96 * 3 + 1)[:, 1:]
     assert px.max() > 32 and px.std() > 1.0            # an image, not a constant
+
+
+@pytest.mark.parametrize("mode", ["samples", "tiles"])
+def test_multi_gpu_example_from_the_c_abi(tmp_path, mode):
+    """examples/progressive_multi.cpp: launcher forks one process per GPU before any GPU call, RCCL is opened from the
+    C ABI (rt_dist_*), the rank renders and runs the collective.  A test box has ONE GPU (and RCCL wants a device per
+    rank), so this runs world size 1: it proves the dlopen, the entry points, communicator creation and both
+    collectives on the context stream, and that the result equals the single-process example's image."""
+    multi, single = os.path.join(LIBDIR, "progressive_multi"), os.path.join(LIBDIR, "progressive")
+    a, b = tmp_path / "multi.pfm", tmp_path / "single.pfm"
+    r = subprocess.run([multi, CORNELL_OBJ, "96", "64", "4", str(a), "1", mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout
+    assert "on 1 GPU(s)" in r.stdout
+    r = subprocess.run([single, CORNELL_OBJ, "96", "64", "4", str(b)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    x = np.frombuffer(a.read_bytes()[-96 * 64 * 12:], np.float32)
+    y = np.frombuffer(b.read_bytes()[-96 * 64 * 12:], np.float32)
+    if mode == "tiles":
+        assert np.array_equal(x, y)                      # bands of the same frames: bit for bit
+    else:
+        assert float(np.sqrt(np.mean((x.astype(np.float64) - y) ** 2))) <= 1e-5      # sum / n against the running mean
+    # more ranks than GPUs is refused up front, not deadlocked
+    r = subprocess.run([multi, CORNELL_OBJ, "32", "32", "1", str(a), "2", mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode != 0 and "visible GPUs" in r.stdout

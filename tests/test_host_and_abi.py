@@ -210,8 +210,22 @@ assert bool((own == 1).all())             # tile partition covers every row exac
 tiled = np.zeros((64, 64, 4), np.float32)
 for y0, y1 in rows:
     sc.render(T.default_material(), g["pfc"][0], 64, 64, accum=tiled, env_constant=(0.5, 0.5, 0.5), tile=(0, y0, 64, y1))
-whole = D.combine_tiles(torch.from_numpy(tiled)).numpy()
+whole = D.combine_tiles(torch.from_numpy(tiled.copy())).numpy()
 assert np.array_equal(whole, g["images"][0]), "tiled frame differs from the golden frame"
+# the same with ONE all-gather of the disjoint bands (half the bytes; rt_dist_gather_bands' scheme); foreign rows hold junk
+junk = tiled.copy()
+for r in range(world):
+    if r != rank:
+        for y0, y1 in D.tile_rows(r, world, 64, band=16): junk[y0:y1] = -7.0
+whole = D.gather_tiles(torch.from_numpy(junk), band=16).numpy()
+assert np.array_equal(whole, g["images"][0]), "gathered frame differs from the golden frame"
+# ragged: 64 rows in bands of 24 -> bands of 24, 24, 16 rows; rank 1 owns one band, rank 0 two (one slot is padding)
+rag = np.full((64, 64, 4), float(rank + 1), np.float32)
+out = D.gather_tiles(torch.from_numpy(rag), band=24).numpy()
+want = np.zeros(64, np.float32)
+for r in range(world):
+    for y0, y1 in D.tile_rows(r, world, 64, band=24): want[y0:y1] = r + 1
+assert np.array_equal(out[:, 0, 0], want)
 dist.barrier(); dist.destroy_process_group()
 open(os.path.join(sys.argv[2], "ok_%d" % rank), "w").write("%s %g" % (mine, rms))
 '''
@@ -229,7 +243,8 @@ def test_sample_sharding_over_gloo_world2(tmp_path, oracle):
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists(), r.stdout[-2000:]
 
 
-def test_shard_helpers():
+def test_shard_helpers(capi):
+    """The partitions are host logic of the C ABI (rt_shard_frame_count, rt_tile_bands, rt_tile_gather_layout)."""
     from dxrexperiments_amd import distributed as D
     for world in (1, 2, 3, 8):
         fr = [D.shard_frames(r, world, 21) for r in range(world)]
@@ -237,3 +252,11 @@ def test_shard_helpers():
         assert [len(x) for x in fr] == D.frames_per_rank(world, 21)
         rows = sum((D.tile_rows(r, world, 1080) for r in range(world)), [])
         assert sum(b - a for a, b in rows) == 1080
+        assert sorted(rows) == [(y, min(y + 16, 1080)) for y in range(0, 1080, 16)]          # bands of 16 rows, each owned once
+        slots, floats = capi.tile_gather_layout(1920, 1080, 16, world)
+        assert slots == -(-68 // world) and floats == slots * 16 * 1920 * 4
+        assert all(len(D.tile_rows(r, world, 1080)) <= slots for r in range(world))
+    with pytest.raises(capi.RtError):
+        capi.tile_bands(1080, 0, 0, 1)
+    with pytest.raises(capi.RtError):
+        capi.shard_frame_count(3, 2, 10)
