@@ -6,10 +6,13 @@
 // AOV, guided by the direct-lighting AOV, horizontally then vertically, and in the second
 // pass the composite (+ direct), exposure, Reinhard tone map and optional gamma.
 //
-// HBM-bound stencil (2 x 16 B in, 16 B out per pixel and pass); the taps come from an LDS
-// tile so each texel is fetched from memory once per block:
+// A stencil of 2 x 16 B in, 16 B out per pixel and pass, but bound by VALU issue, not by HBM: a tap costs ~16 vector
+// instructions (no FMA: the HLSL's operation order is kept), 25 taps per pixel and pass.  The taps come from an LDS
+// tile so each texel is fetched from memory once per block; the 41 tap weights are computed ONCE per dispatch on the
+// host with the reference's expression (BilateralFilter.hlsli:82-90 computes them once per thread group) and reach the
+// kernels as kernel arguments, i.e. scalar registers: round 1 recomputed a correctly rounded division per tap and pixel.
 //   pass H  block = 256 x 1 pixels,  tile = (256 + 2*20) texels of both images
-//   pass V  block = 32 x 32 pixels (256 threads, 4 rows each), tile = 32 x (32 + 2*20) texels
+//   pass V  block = 8 x 64 pixels (256 threads, 2 rows each), tile = 8 x (64 + 2*20) texels
 // The reference's own LDS cache (64 + 2*20 texels, BilateralFilter.hlsli:40-73) has an
 // index-clamp race on its left halo; it is meant to equal "the texture with a zero border",
 // which is what the tiles hold (out-of-image loads read 0, like D3D).
@@ -33,6 +36,7 @@ struct DenoiseArgs {
     float4 *output;
     int width, height;
     rt_denoiser_params prm;
+    float w[2 * MAX_EXTENT + 1];    // sPrecalculatedGaussianWeights, BilateralFilter.hlsli:40,82-90
 };
 
 RT_DEV float4 load_texel(const float4 *img, int x, int y, int w, int h)
@@ -41,8 +45,9 @@ RT_DEV float4 load_texel(const float4 *img, int x, int y, int w, int h)
     return img[(size_t)y * w + x];
 }
 
-// weights table of BilateralFilter.hlsli:82-90
-RT_DEV float tap_weight(int i, float kernelRadius)
+// weights table of BilateralFilter.hlsli:82-90 (host: IEEE single arithmetic, the same bits as the device's correctly
+// rounded division)
+static float tap_weight(int i, float kernelRadius)
 {
     const int a = i < 0 ? -i : i;
     int idx = (int)((float)(a * 5) / (0.001f + __builtin_fabsf(kernelRadius * 0.8f)));
@@ -61,6 +66,37 @@ RT_DEV void accumulate_tap(float4 s, float4 sj, float4 cj, float gw, float4 &col
     const float bw = gw * cw;
     color.x += s.x * bw; color.y += s.y * bw; color.z += s.z * bw; color.w += s.w * bw;
     weight += bw;
+}
+
+// A tile texel as one 16-B LDS read: without this the compiler fetches the three used components with ds_read_b96,
+// which moves 96 B per clock per CU against ds_read_b128's 256 (MI355X_MICROARCH.md, LDS table), and the two reads per
+// tap are what bounds these kernels.
+RT_DEV float4 lds_texel(const float4 *p)
+{
+    float4 t = *p;
+    asm volatile("" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w));
+    return t;
+}
+
+// the 2K+1 taps of one pixel, in the reference's order (BilateralFilter.hlsli:101-114); `stride` texels between taps.
+// Five taps per trip: their weights arrive as one batch of scalar loads and their LDS reads are in flight together.
+RT_DEV void filter_taps(const DenoiseArgs &a, const float4 *s_in, const float4 *s_jn, int c, int stride, float4 cj, float4 &color, float &weight)
+{
+    const int K = a.prm.maxKernelSize;
+    int i = -K;
+    for (; i + 4 <= K; i += 5) {
+        const float w0 = a.w[i + MAX_EXTENT], w1 = a.w[i + MAX_EXTENT + 1], w2 = a.w[i + MAX_EXTENT + 2], w3 = a.w[i + MAX_EXTENT + 3], w4 = a.w[i + MAX_EXTENT + 4];
+        const int t = c + i * stride;
+        const float4 i0 = lds_texel(s_in + t), j0 = lds_texel(s_jn + t), i1 = lds_texel(s_in + t + stride), j1 = lds_texel(s_jn + t + stride);
+        const float4 i2 = lds_texel(s_in + t + 2 * stride), j2 = lds_texel(s_jn + t + 2 * stride), i3 = lds_texel(s_in + t + 3 * stride);
+        const float4 j3 = lds_texel(s_jn + t + 3 * stride), i4 = lds_texel(s_in + t + 4 * stride), j4 = lds_texel(s_jn + t + 4 * stride);
+        accumulate_tap(i0, j0, cj, w0, color, weight);
+        accumulate_tap(i1, j1, cj, w1, color, weight);
+        accumulate_tap(i2, j2, cj, w2, color, weight);
+        accumulate_tap(i3, j3, cj, w3, color, weight);
+        accumulate_tap(i4, j4, cj, w4, color, weight);
+    }
+    for (; i <= K; ++i) accumulate_tap(lds_texel(s_in + c + i * stride), lds_texel(s_jn + c + i * stride), cj, a.w[i + MAX_EXTENT], color, weight);
 }
 
 // composite + exposure + tone map + gamma of pass 1 (DenoiseCommon.hlsli:56-74)
@@ -102,19 +138,21 @@ __global__ void __launch_bounds__(HB) k_denoise_h(DenoiseArgs a)
     float4 color;
     if (a.prm.debugVisualize == 2) color = s_in[c];
     else {
-        const int K = a.prm.maxKernelSize;
-        const float radius = (float)K;
         const float4 cj = s_jn[c];
         color = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         float weight = 0.0f;
-        for (int i = -K; i <= K; ++i) accumulate_tap(s_in[c + i], s_jn[c + i], cj, tap_weight(i, radius), color, weight);
+        filter_taps(a, s_in, s_jn, c, 1, cj, color, weight);
         color = make_float4(color.x / weight, color.y / weight, color.z / weight, color.w / weight);
     }
     a.output[(size_t)y * a.width + x] = make_float4(color.x, color.y, color.z, 1.0f);
 }
 
-// ---- pass V: 32 x 32 pixel tile per block, each thread 4 rows -------------------------------------
-constexpr int VW = 32, VH = 32;
+// ---- pass V: 8 x 64 pixel tile per block, each thread 2 rows ------------------------------------------
+// A narrow, tall tile: a tile row is 8 texels = one 128-B line of each image, the halo costs 104 / 64 of the rows
+// (round 1's 32 x 32 tile: 72 / 32), the tile takes 26 KiB of LDS instead of 72 (6 blocks per CU instead of 2, and this
+// kernel lives on occupancy: every tap waits for two LDS reads), and with the [row][8] layout the 64 lanes of a wave --
+// 8 rows x 8 columns -- read 64 consecutive texels, which is conflict free.
+constexpr int VW = 8, VH = 64;
 __global__ void __launch_bounds__(256) k_denoise_v(DenoiseArgs a)
 {
     __shared__ float4 s_in[(VH + 2 * MAX_EXTENT) * VW];
@@ -129,8 +167,6 @@ __global__ void __launch_bounds__(256) k_denoise_v(DenoiseArgs a)
     const int tx = threadIdx.x % VW;
     const int x = x0 + tx;
     if (x >= a.width) return;
-    const int K = a.prm.maxKernelSize;
-    const float radius = (float)K;
     for (int r = threadIdx.x / VW; r < VH; r += 256 / VW) {
         const int y = y0 + r;
         if (y >= a.height) break;
@@ -141,7 +177,7 @@ __global__ void __launch_bounds__(256) k_denoise_v(DenoiseArgs a)
             const float4 cj = s_jn[c];
             color = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             float weight = 0.0f;
-            for (int i = -K; i <= K; ++i) accumulate_tap(s_in[c + i * VW], s_jn[c + i * VW], cj, tap_weight(i, radius), color, weight);
+            filter_taps(a, s_in, s_jn, c, VW, cj, color, weight);
             color = make_float4(color.x / weight, color.y / weight, color.z / weight, color.w / weight);
         }
         color = finish_pass1(a.prm, color, s_jn[c]);
@@ -238,6 +274,7 @@ int rt_denoiser_dispatch(rt_denoiser *d, const void *direct_lighting, const void
     a.direct = (const float4 *)direct_lighting;
     a.width = (int)width; a.height = (int)height;
     a.prm = d->prm;
+    for (int i = -MAX_EXTENT; i <= MAX_EXTENT; i++) a.w[i + MAX_EXTENT] = tap_weight(i, (float)d->prm.maxKernelSize);
     HIP_TRY(hipEventRecord(d->ev0, st));
     a.input = (const float4 *)indirect_specular;                 // pass 0: Dispatch(ceil(w/64), h, 1) in the reference
     a.output = d->out[0].as<float4>();
