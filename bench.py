@@ -28,12 +28,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
-L2_PEAK_GBS = 34500.0          # aggregate L2 bandwidth of the 8 XCDs (MI355X_MICROARCH.md, "L2 (per XCD)")
+# Rate at which the chip serves uniformly random cache-resident rows to divergent lanes: MI355X_MICROARCH.md, "Indexed rows:
+# gather into LDS", 38 MB table (Infinity Cache): 33.5 GB/s per CU = 8.6 TB/s chip-wide.  tools/microbench/slab_fetch.hip
+# measures 7.5 TB/s for this engine's own access shape (one 64-B line per lane from an 8 MiB table, profiles/r02/slab_fetch.txt).
+GATHER_PEAK_GBS = 8600.0
+LINE_BYTES = 64
 RAY_BYTES, NODE_BYTES, TRI_BYTES = 48, 32, 36   # 32 B ray in + 16 B hit out; node; triangle
-# what the production kernels request from the memory system per unit: one 64-B slab per
-# node step that is not served by the LDS top table, one 48-B record per triangle test, one 112-B instance record
-# per instance entry, and the ray in / result out of the stage
-SLAB_BYTES, TRIREC_BYTES, INSTANCE_BYTES = 64, 48, 112
+# what the production kernels request per unit (DESIGN.md sections 3 / 4): one 64-B node per step that is not served by the
+# LDS-resident top of the tree, one 48-B record per triangle test, one 112-B instance record per instance entry, and the
+# ray in / result out of the stage
+NODE_LINE_BYTES, TRIREC_BYTES, INSTANCE_BYTES = 64, 48, 112
 STAGE_IO_BYTES = {"primary": 0 + 20, "secondary": 32 + 20, "shadow": 32 + 4}
 # stage -> (rt_stats time fields, kernel, rt_pipeline_count_work stages whose rays the launch traces)
 TRACE_STAGES = {"primary": (("ms_primary",), "k_primary", ("primary",)),
@@ -156,9 +160,16 @@ def committed_profile(workload):
 
 
 def walk_bytes(stage, w):
-    """Bytes a traversal stage requests from L2 and beyond, from the production-walk tallies of rt_pipeline_count_walk."""
-    return (SLAB_BYTES * w["slabs_global"] + TRIREC_BYTES * w["tris"] + INSTANCE_BYTES * w["instance_entries"]
+    """Bytes the lanes of a traversal stage request (per lane, before any sharing between lanes), from the production-walk
+    tallies of rt_pipeline_count_walk."""
+    return (NODE_LINE_BYTES * w["nodes_global"] + TRIREC_BYTES * w["tris"] + INSTANCE_BYTES * w["instance_entries"]
             + STAGE_IO_BYTES[stage] * w["rays"])
+
+
+def gather_bytes(stage, w):
+    """Bytes of DISTINCT 64-B lines a stage gathers: node lines de-duplicated over the lanes of every wave step, the lines
+    the triangle records span, two lines per instance record, and the (coalesced) ray in / result out."""
+    return LINE_BYTES * (w["lines"] + 2 * w["instance_entries"]) + STAGE_IO_BYTES[stage] * w["rays"]
 
 
 def stage_table(pipe, tot, with_canonical=True):
@@ -169,13 +180,15 @@ def stage_table(pipe, tot, with_canonical=True):
     n_t = max(int(tot["frames"]), 1)
     stages = {}
     for name, (keys, kernel, parts) in TRACE_STAGES.items():
-        wk = {k: sum(walk[p][k] for p in parts) for k in ("rays", "slabs_global", "slabs_lds", "tris", "instance_entries")}
+        wk = {k: sum(walk[p][k] for p in parts) for k in ("rays", "nodes_global", "nodes_lds", "tris", "instance_entries", "lines")}
+        wk["longest_walk"] = max(walk[p]["longest_walk"] for p in parts)
         ms = sum(tot[k] for k in keys) / n_t
-        rb = walk_bytes(name, wk)
-        st = {"kernel": kernel, "avg_ms": ms, "rays": wk["rays"], "requested_bytes": rb,
-              "requested_GBps": rb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
-              "slabs_global_per_ray": wk["slabs_global"] / max(wk["rays"], 1), "slabs_lds_per_ray": wk["slabs_lds"] / max(wk["rays"], 1),
+        rb, gb = walk_bytes(name, wk), gather_bytes(name, wk)
+        st = {"kernel": kernel, "avg_ms": ms, "rays": wk["rays"], "requested_bytes": rb, "gathered_bytes": gb,
+              "requested_GBps": rb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "gathered_GBps": gb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+              "nodes_global_per_ray": wk["nodes_global"] / max(wk["rays"], 1), "nodes_lds_per_ray": wk["nodes_lds"] / max(wk["rays"], 1),
               "tris_per_ray": wk["tris"] / max(wk["rays"], 1), "instance_entries_per_ray": wk["instance_entries"] / max(wk["rays"], 1),
+              "lines_per_ray": wk["lines"] / max(wk["rays"], 1), "longest_walk_steps": wk["longest_walk"],
               "Mrays_per_s": wk["rays"] / (ms * 1e-3) / 1e6 if ms > 0 else 0.0}
         if work is not None:
             w = {k: sum(work[p][k] for p in parts) for k in ("rays", "nodes", "tris")}
@@ -439,28 +452,33 @@ def main():
             dom = max(TRACE_STAGES, key=lambda s: stages[s]["avg_ms"])
             d = stages[dom]
             prof = committed_profile("c2").get("kernels", {}).get(d["kernel"], {})
-            # The C2 working set (~23 MB of slabs + triangle records) is cache resident, so HBM cannot bound these
-            # kernels; what they stress is the rate of 64-B / 48-B requests into the XCD L2s (and, behind them, the
-            # Infinity Cache).  achieved = bytes the production walk requests per launch / measured launch time.
-            out["roofline"] = {"bound": "l2", "kernel": d["kernel"], "stage": dom,
-                               "achieved": d["requested_GBps"], "peak": L2_PEAK_GBS, "unit": "GB/s",
-                               "frac": d["requested_GBps"] / L2_PEAK_GBS,
+            # The C2 working set (~12 MB of nodes + 12 MB of triangle records) lives in the 4 MiB-per-XCD L2s and the
+            # Infinity Cache, so HBM cannot bound these kernels (memory-side traffic = `traffic`, a few % of what the lanes
+            # request).  What they are is a random gather of 64-B lines from cache-resident tables by divergent lanes, and the
+            # roofline is the rate the chip serves such a gather at: achieved = distinct lines x 64 B per launch / launch time.
+            out["roofline"] = {"bound": "cache-gather", "kernel": d["kernel"], "stage": dom,
+                               "achieved": d["gathered_GBps"], "peak": GATHER_PEAK_GBS, "unit": "GB/s",
+                               "frac": d["gathered_GBps"] / GATHER_PEAK_GBS,
                                "traffic": prof.get("bytes_per_launch"),
-                               "bytes_per_launch": d["requested_bytes"], "avg_launch_ms": d["avg_ms"], "launches_timed": n_t,
-                               "definition": "bytes = 64 B x slabs fetched from global memory + 48 B x triangle records + 112 B x instance "
-                                             "entries + ray in / result out, tallied per lane by a counting instantiation of the timed "
-                                             "kernel (rt_pipeline_count_walk) on the last frame's queues; node steps served by the LDS top "
-                                             "table are excluded; peak = aggregate L2 bandwidth; traffic = memory-side bytes (2 x "
-                                             "FETCH_SIZE + WRITE_SIZE) of the committed PMC pass",
+                               "bytes_per_launch": d["gathered_bytes"], "avg_launch_ms": d["avg_ms"], "launches_timed": n_t,
+                               "definition": "bytes = 64 B x distinct lines the launch gathers (node lines de-duplicated over the lanes of "
+                                             "each wave step + the lines its triangle records span, tallied by a counting instantiation "
+                                             "of the timed kernel on the last frame's queues, rt_pipeline_count_walk) + ray in / result "
+                                             "out; nodes served by the LDS-resident top of the tree are excluded; peak = random-row "
+                                             "gather rate from the Infinity Cache (MI355X_MICROARCH.md: 8.6 TB/s; this access shape "
+                                             "measured at 7.5 TB/s, profiles/r02/slab_fetch.txt); traffic = memory-side bytes "
+                                             "(FETCH_SIZE by request size + WRITE_SIZE) of the committed PMC pass",
+                               "requested_GBps_per_lane": d["requested_GBps"],
                                "pmc": {k: prof.get(k) for k in ("TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "SQ_INSTS_VALU", "SQ_WAIT_ANY",
-                                                               "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "avg_us") if k in prof},
+                                                               "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES",
+                                                               "avg_us", "GBps") if k in prof},
                                "pmc_source": committed_profile("c2").get("source"), "pmc_commit": committed_profile("c2").get("commit"),
                                # SURVEY 8(d)'s layout-independent contract figure, kept for reference: canonical-LBVH counters x
                                # (32 B node, 36 B triangle, 48 B ray) against HBM peak.  NOT a physical bound for this cache-resident
                                # working set (the timed kernel walks a different tree and its bytes never leave the caches).
                                "contract_8d_hbm": {"algorithmic_bytes_per_launch": d["canonical"]["algorithmic_bytes"],
                                                    "GBps": d["canonical"]["GBps"], "over_hbm_peak": d["canonical"]["GBps"] / HBM_PEAK_GBS}}
-            tb = sum(stages[s]["requested_bytes"] for s in TRACE_STAGES)
+            tb = sum(stages[s]["gathered_bytes"] for s in TRACE_STAGES)
             out["roofline"]["all_stages_GBps_over_step"] = tb / (out["ms_per_step"] * 1e-3) / 1e9
             out["stages"] = stages
         if world == 1 and args.hbm_frames > 0 and not args.no_roofline:
@@ -472,15 +490,21 @@ def main():
             k5 = prof5.get("kernels", {}).get(d["kernel"], {})
             traffic = k5.get("bytes_per_launch")
             prof_us = k5.get("avg_us")
+            live_ms = d["avg_ms"]
             h["roofline"] = {"bound": "hbm", "kernel": d["kernel"], "stage": dom,
-                             # HBM-side bytes per launch (PMC, committed pass of this same workload) / the duration rocprofv3
-                             # measured for the same launches; live HIP-event duration alongside
-                             "achieved": traffic / (prof_us * 1e-6) / 1e9 if traffic and prof_us else None,
+                             # memory-side bytes per launch (PMC passes of THIS workload, profiles/<round>/traffic.json: read requests
+                             # by size + WRITE_SIZE) / this run's HIP-event duration of the same launches; the profiling session's own
+                             # duration and rate alongside.  The ~0.8 GB of nodes + triangle records do not fit the 256 MB Infinity Cache.
+                             "achieved": traffic / (live_ms * 1e-3) / 1e9 if traffic else None,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": traffic / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS if traffic and prof_us else None,
-                             "traffic": traffic, "profiled_avg_us": prof_us,
-                             "requested_bytes_per_launch": d["requested_bytes"], "avg_launch_ms": d["avg_ms"],
-                             "requested_GBps": d["requested_GBps"], "launches_timed": h["launches_timed"],
+                             "frac": traffic / (live_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
+                             "traffic": traffic, "avg_launch_ms": live_ms, "launches_timed": h["launches_timed"],
+                             "profiled_avg_us": prof_us, "profiled_GBps": k5.get("GBps"),
+                             "gathered_bytes_per_launch": d["gathered_bytes"], "gathered_GBps": d["gathered_GBps"],
+                             "requested_bytes_per_launch": d["requested_bytes"],
+                             "pmc": {k: k5.get(k) for k in ("TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum",
+                                                            "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES",
+                                                            "SQ_INSTS_VALU") if k in k5},
                              "pmc_source": prof5.get("source"), "pmc_commit": prof5.get("commit")}
             out["roofline_hbm"] = h
         if world == 1 and args.cpu_seconds > 0:

@@ -37,8 +37,8 @@ class StageWork(C.Structure):
 
 
 class StageWalk(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("slabs_global", C.c_uint64), ("slabs_lds", C.c_uint64), ("tris", C.c_uint64),
-                ("instance_entries", C.c_uint64), ("longest_walk", C.c_uint64), ("longest_walk_ray", C.c_uint64)]
+    _fields_ = [("rays", C.c_uint64), ("nodes_global", C.c_uint64), ("nodes_lds", C.c_uint64), ("tris", C.c_uint64),
+                ("instance_entries", C.c_uint64), ("lines", C.c_uint64), ("longest_walk", C.c_uint64), ("longest_walk_ray", C.c_uint64)]
 
 
 STAGES = ("primary", "secondary", "shadow0", "shadow1")
@@ -524,7 +524,7 @@ class Pipeline:
 
     def count_walk(self):
         """What the PRODUCTION traversal fetched for the last frame per stage:
-        {stage: dict(rays, slabs_global, slabs_lds, tris, instance_entries)}."""
+        {stage: dict(rays, nodes_global, nodes_lds, tris, instance_entries, lines, longest_walk, longest_walk_ray)}."""
         w = (StageWalk * len(STAGES))()
         _check(lib().rt_pipeline_count_walk(self.h, w))
         return {n: {f: int(getattr(w[i], f)) for f, _ in StageWalk._fields_} for i, n in enumerate(STAGES)}

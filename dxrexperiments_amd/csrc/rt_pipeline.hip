@@ -950,16 +950,16 @@ static int count_walk_launch(rt_pipeline *p, unsigned long long *w)
     const PipeDev &pd = p->last_pd;
     const uint32_t cap = pd.cap, ss = p->last_shadow_slots;
     const uint32_t any = RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH | RT_RAY_FLAG_SKIP_CLOSEST_HIT_SHADER;
-    k_walk_primary<TWO_LEVEL><<<rt_persistent_grid(ctx, k_walk_primary<TWO_LEVEL>, PBLOCK, cap), PBLOCK, 0, st>>>(pd, w + 6 * RT_STAGE_PRIMARY);
+    k_walk_primary<TWO_LEVEL><<<rt_persistent_grid(ctx, k_walk_primary<TWO_LEVEL>, PBLOCK, cap), PBLOCK, 0, st>>>(pd, w + 7 * RT_STAGE_PRIMARY);
     const unsigned gq = rt_persistent_grid(ctx, k_walk_queue<TWO_LEVEL>, PBLOCK, (size_t)cap * 2);
     const unsigned gs = rt_persistent_grid(ctx, k_walk_shadow<TWO_LEVEL>, PBLOCK, (size_t)cap * 2);
-    k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any}, w + 6 * RT_STAGE_SHADOW0);
+    k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any}, w + 7 * RT_STAGE_SHADOW0);
     const uint32_t levels = pd.max_rad < (uint32_t)MAXD ? pd.max_rad : (uint32_t)MAXD;
     for (uint32_t l = 1; l <= levels; l++) {
         k_walk_queue<TWO_LEVEL><<<gq, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE},
-                                                       w + 6 * RT_STAGE_SECONDARY);
+                                                       w + 7 * RT_STAGE_SECONDARY);
         if (l < pd.max_shadow)
-            k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any}, w + 6 * RT_STAGE_SHADOW1);
+            k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any}, w + 7 * RT_STAGE_SHADOW1);
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -1477,7 +1477,7 @@ int rt_pipeline_count_work(rt_pipeline *p, rt_stage_work *out)
     if (!p->rendered || !p->scene->built || p->scene->generation != p->last_scene_gen) { rt_set_error("count_work: nothing rendered since the last change of scene, materials or output"); return RT_ERR_STATE; }
     HIP_TRY(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->stream;
-    RT_TRY(p->work.reserve(RT_STAGE_COUNT * 6 * sizeof(unsigned long long)));
+    RT_TRY(p->work.reserve(RT_STAGE_COUNT * 7 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(p->work.p, 0, RT_STAGE_COUNT * 3 * sizeof(unsigned long long), st));
     unsigned long long *w = p->work.as<unsigned long long>();
     const PipeDev &pd = p->last_pd;
@@ -1509,20 +1509,20 @@ int rt_pipeline_count_walk(rt_pipeline *p, rt_stage_walk *out)
     if (!p->rendered || !p->scene->built || p->scene->generation != p->last_scene_gen) { rt_set_error("count_walk: nothing rendered since the last change of scene, materials or output"); return RT_ERR_STATE; }
     HIP_TRY(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->stream;
-    const size_t bytes = RT_STAGE_COUNT * 6 * sizeof(unsigned long long);
+    const size_t bytes = RT_STAGE_COUNT * 7 * sizeof(unsigned long long);
     RT_TRY(p->work.reserve(bytes));
     HIP_TRY(hipMemsetAsync(p->work.p, 0, bytes, st));
     unsigned long long *w = p->work.as<unsigned long long>();
     if (p->scene->two_level) RT_TRY(count_walk_launch<true>(p, w));
     else RT_TRY(count_walk_launch<false>(p, w));
-    unsigned long long h[RT_STAGE_COUNT * 6];
+    unsigned long long h[RT_STAGE_COUNT * 7];
     HIP_TRY(hipMemcpyAsync(h, w, sizeof h, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (int k = 0; k < RT_STAGE_COUNT; k++) {
-        out[k].rays = h[6 * k]; out[k].slabs_global = h[6 * k + 1]; out[k].slabs_lds = h[6 * k + 2];
-        out[k].tris = h[6 * k + 3]; out[k].instance_entries = h[6 * k + 4];
-        out[k].longest_walk = h[6 * k + 5] >> 32;
-        out[k].longest_walk_ray = (uint32_t)h[6 * k + 5];
+        out[k].rays = h[7 * k]; out[k].nodes_global = h[7 * k + 1]; out[k].nodes_lds = h[7 * k + 2];
+        out[k].tris = h[7 * k + 3]; out[k].instance_entries = h[7 * k + 4]; out[k].lines = h[7 * k + 5];
+        out[k].longest_walk = h[7 * k + 6] >> 32;
+        out[k].longest_walk_ray = (uint32_t)h[7 * k + 6];
     }
     return RT_OK;
 }

@@ -199,6 +199,21 @@ RT_DEV void wide_step(const WNode *nodes, const int *top, uint32_t top_lim, cons
     else { node = sp > 0 ? under : RT_NODE_EMPTY; sp = below; }
 }
 
+// COUNT builds: how many DISTINCT 64-B node lines the active lanes of this wave step fetch from global memory (lanes on
+// the same node share one line; lanes on the LDS-resident top fetch none); added to the calling leader lane's tally
+RT_DEV uint32_t distinct_node_lines(int node, bool from_global)
+{
+    unsigned long long todo = __ballot(from_global);
+    uint32_t n = 0;
+    while (todo) {
+        const int l = __builtin_ctzll(todo);
+        const int v = __builtin_amdgcn_readlane(node, l);
+        todo &= ~__ballot(from_global && node == v);
+        n++;
+    }
+    return n;
+}
+
 RT_DEV bool node_is_internal(int node) { return node >= 0 && node < RT_NODE_EMPTY; }
 
 RT_DEV unsigned long long lanemask_lt()
@@ -214,15 +229,16 @@ RT_DEV unsigned long long lanemask_lt()
 
 // COUNT: the walk-counting instantiation (rt_pipeline_count_walk): the same walk, plus per-lane tallies of what it
 // fetches -- 64-B nodes from global memory, nodes from the LDS-resident top, 48-B triangle records, 112-B
-// instance records -- summed into walk[0..4] = rays, nodes from global memory, nodes from LDS, triangles, instance entries; walk[5] =
-// max over rays of (node steps << 32 | ray index), the longest single walk (a tail detector).
+// instance records -- summed into walk[0..5] = rays, nodes from global memory, nodes from LDS, triangles, instance entries,
+// distinct 64-B lines (node lines de-duplicated across the lanes of each wave step + the lines the triangle records span);
+// walk[6] = max over rays of (node steps << 32 | ray index), the longest single walk (a tail detector).
 // These per-ray numbers depend on the ray and the tree only, not on chunking or lane assignment.
 template <int STACK, int BLOCK, bool TWO_LEVEL, uint32_t CHUNK, bool ANYHIT = false, bool COUNT = false, class Src, class Sink>
 RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uint32_t *pool, int *smem, uint32_t *traced_counter,
                        unsigned long long *walk = nullptr)
 {
     uint32_t n_traced = 0;           // rays this lane actually traversed (statistics)
-    uint32_t wk_glob = 0, wk_top = 0, wk_tri = 0, wk_inst = 0;
+    uint32_t wk_glob = 0, wk_top = 0, wk_tri = 0, wk_inst = 0, wk_lines = 0;
     uint32_t wk_ray0 = 0;                        // node steps tallied when the lane's current ray started
     unsigned long long wk_longest = 0;           // (node steps << 32 | ray index) of the lane's longest walk
 #ifdef RT_TRACE_STATS
@@ -342,7 +358,11 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 #endif
         while (alive && node_is_internal(node) && sp <= STACK - 3) {
             RT_STAT_WAVE(0); RT_STAT_LANE(0);
-            if (COUNT) { if ((uint32_t)node < top_lim) wk_top++; else wk_glob++; }
+            if (COUNT) {
+                if ((uint32_t)node < top_lim) wk_top++; else wk_glob++;
+                const uint32_t dl = distinct_node_lines(node, !((uint32_t)node < top_lim));
+                if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_read_exec())) wk_lines += dl;
+            }
             wide_step<false, ANYHIT>(nodes, topl, top_lim, cur.ri, r.tmin, best.t, st, node, sp);
 #ifdef RT_TRACE_STATS
             st_maxsp = sp > st_maxsp ? sp : st_maxsp;
@@ -355,7 +375,11 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
         }
         // lanes whose stack has outgrown the LDS rows walk on with the global rows until it fits again
         while (alive && node_is_internal(node) && sp > STACK - 3) {
-            if (COUNT) { if ((uint32_t)node < top_lim) wk_top++; else wk_glob++; }
+            if (COUNT) {
+                if ((uint32_t)node < top_lim) wk_top++; else wk_glob++;
+                const uint32_t dl = distinct_node_lines(node, !((uint32_t)node < top_lim));
+                if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_read_exec())) wk_lines += dl;
+            }
             wide_step<true, ANYHIT>(nodes, topl, top_lim, cur.ri, r.tmin, best.t, st, node, sp);
 #ifdef RT_TRACE_STATS
             st_maxsp = sp > st_maxsp ? sp : st_maxsp;
@@ -406,7 +430,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 const uint32_t first_tri = code >> 3, cnt = (code & 7u) + 1u;
                 for (uint32_t k = 0; k < cnt; k++) {
                     RT_STAT_WAVE(2); RT_STAT_LANE(2);
-                    if (COUNT) wk_tri++;
+                    if (COUNT) { wk_tri++; const uint32_t by = (first_tri + k) * 48u; wk_lines += 1u + ((by & 63u) > 16u ? 1u : 0u); }   // a 48-B record spans one or two lines
                     const char *tp = (const char *)(tris + first_tri + k);
                     const v4f a = ldg16(tp, 0), b = ldg16(tp, 16), c = ldg16(tp, 32);
                     const uint32_t prim = __float_as_uint(c.y);
@@ -433,13 +457,13 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
     }
 #endif
     if (COUNT && walk) {
-        unsigned long long w5[5] = {n_traced, wk_glob, wk_top, wk_tri, wk_inst};
-        for (int k = 0; k < 5; k++) {
+        unsigned long long w5[6] = {n_traced, wk_glob, wk_top, wk_tri, wk_inst, wk_lines};
+        for (int k = 0; k < 6; k++) {
             unsigned long long v = w5[k];
             for (int o = 32; o > 0; o >>= 1) v += (unsigned long long)__shfl_xor((long long)v, o, 64);
             if ((threadIdx.x & 63u) == 0u && v) atomicAdd(&walk[k], v);
         }
-        atomicMax(&walk[5], wk_longest);
+        atomicMax(&walk[6], wk_longest);
     }
     if (traced_counter) {            // one no-return atomic per persistent wave
         for (int o = 32; o > 0; o >>= 1) n_traced += (uint32_t)__shfl_xor((int)n_traced, o, 64);

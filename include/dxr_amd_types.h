@@ -158,10 +158,12 @@ typedef struct rt_stage_work {
  * are the bytes the timed kernels really request, and the input of bench.py's L2-bound roofline. */
 typedef struct rt_stage_walk {
     uint64_t rays;               /* rays traversed                                              */
-    uint64_t slabs_global;       /* 64-B internal-node slabs loaded from global memory (L2)      */
-    uint64_t slabs_lds;          /* slabs read from the LDS-resident top table                   */
+    uint64_t nodes_global;       /* 64-B four-wide nodes loaded from global memory, per lane      */
+    uint64_t nodes_lds;          /* nodes read from the LDS-resident top of the tree              */
     uint64_t tris;               /* 48-B triangle records loaded                                */
     uint64_t instance_entries;   /* 112-B instance records visited (two-level scenes)           */
+    uint64_t lines;              /* distinct 64-B lines fetched: node lines de-duplicated over the lanes of each wave step +
+                                    the one or two lines each triangle record spans                                   */
     uint64_t longest_walk;       /* node steps of the stage's longest single ray (persistent kernels end with their slowest lane) */
     uint64_t longest_walk_ray;   /* ... and that ray's index in its queue (last launch of the stage) */
 } rt_stage_walk;

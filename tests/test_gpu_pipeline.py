@@ -371,8 +371,11 @@ def test_count_walk_is_the_production_walk(gpu, capi):
     assert w1["shadow0"]["rays"] + w1["shadow1"]["rays"] == st["rays_shadow"]
     for s in w1.values():
         assert s["instance_entries"] == 0                       # one identity instance: single-level walk
-        assert s["slabs_global"] + s["slabs_lds"] >= s["rays"] // 2 and s["tris"] > 0
-    assert w1["primary"]["slabs_lds"] > 0                       # the top of the tree is LDS resident
+        assert s["nodes_global"] + s["nodes_lds"] >= s["rays"] // 2 and s["tris"] > 0
+        assert 0 < s["lines"] <= s["nodes_global"] + 2 * s["tris"]            # lanes of a wave share node lines
+        assert 0 < s["longest_walk"] < 500
+    assert w1["primary"]["nodes_lds"] > 0                       # the top of the tree is LDS resident
+    assert w1["primary"]["lines"] < w1["primary"]["nodes_global"] + w1["primary"]["tris"] * 3 // 2    # primary rays of a tile share lines
     assert np.array_equal(img, p.read_output())
     cw = p.count_work()
     assert cw["primary"]["rays"] == W * H

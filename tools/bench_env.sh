@@ -4,7 +4,7 @@ for e in "$@"; do
   env $e timeout 300 python bench.py --steps 30 --warmup 5 --cpu-seconds 0 --hbm-frames ${HBM:-0} 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-f=lambda st:{k:(round(v['avg_ms'],3), round(v['slabs_global_per_ray']+v['slabs_lds_per_ray'],2), round(v['tris_per_ray'],2)) for k,v in st.items() if isinstance(v,dict)}
+f=lambda st:{k:(round(v['avg_ms'],3), round(v['nodes_global_per_ray']+v['nodes_lds_per_ray'],2), round(v['tris_per_ray'],2)) for k,v in st.items() if isinstance(v,dict)}
 print('%-28s' % '$e', round(d['ms_per_step'],3), 'ms', f(d['stages']), 'build', round(d['bvh_rebuild_ms'],2))
 h=d.get('roofline_hbm')
 if h: print('   c5', round(h['ms_per_frame'],2), 'ms', f(h['stages']))"

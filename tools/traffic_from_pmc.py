@@ -3,15 +3,18 @@
 the memory-side bytes per launch (`roofline.traffic` in bench.py), the rocprofv3 average duration and the SQ / TCC counters.
 
 usage: tools/traffic_from_pmc.py profiles/r02
-gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies 128-B read requests at 64 B, so it
-is doubled; WRITE_SIZE is exact; rocprofv3 reports both in KiB; Infinity-Cache hits are included."""
+gfx950 (MI355X_MICROARCH.md, HBM section): FETCH_SIZE = TCC_EA0_RDREQ x 64 B whatever the request size, exact only for 64-B
+requests and half the bytes of wide streaming reads; other access shapes are "uncalibrated", so the read bytes are taken from
+the requests BY SIZE (TCC_EA0_RDREQ_32B / _64B / _128B, a pass of their own): bytes_per_launch = 32 n32 + 64 n64 + 128 n128 +
+WRITE_SIZE.  The guide's FETCH_SIZE x 2 + WRITE_SIZE is kept as bytes_per_launch_fetch_x2.  Infinity-Cache hits are included
+in both (these are the L2's memory-side requests)."""
 import json
 import os
 import re
 import subprocess
 import sys
 
-KERNELS = ("k_primary", "k_trace_secondary", "k_trace_shadow")
+KERNELS = ("k_primary", "k_trace_secondary", "k_trace_shadow", "k_denoise_h", "k_denoise_v", "k_shade_emit", "k_resolve")
 
 
 def rows(path):
@@ -38,9 +41,9 @@ def main():
                          "Infinity-Cache hits are included (MI355X_MICROARCH.md, HBM section)",
            "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, text=True).stdout.strip(),
            "workloads": {}}
-    for w in ("c2", "c5"):
+    for w in ("c2", "c5", "c4"):
         kt, fe, wr = rows("%s/%s_kt.md" % (d, w)), rows("%s/%s_fetch.md" % (d, w)), rows("%s/%s_write.md" % (d, w))
-        tcc, sq = rows("%s/%s_tcc.md" % (d, w)), rows("%s/%s_sq.md" % (d, w))
+        tcc, sq, ea = rows("%s/%s_tcc.md" % (d, w)), rows("%s/%s_sq.md" % (d, w)), rows("%s/%s_ea.md" % (d, w))
         if not fe:
             continue
         ks = {}
@@ -49,11 +52,19 @@ def main():
                 continue
             f, wv = fe[(k, "FETCH_SIZE")], wr.get((k, "WRITE_SIZE"), 0.0)
             e = {"fetch_size_kib_per_launch": f, "write_size_kib_per_launch": wv, "dispatches": int(fe[(k, "FETCH_SIZE:n")]),
-                 "bytes_per_launch": int((2.0 * f + wv) * 1024)}
+                 "bytes_per_launch_fetch_x2": int((2.0 * f + wv) * 1024)}
+            # read requests by size (their own pass): the calibrated figure for this access shape; FETCH_SIZE x 2 (the guide's
+            # correction for wide streaming reads) is kept beside it
+            sized = [ea.get((k, "TCC_EA0_RDREQ_%s_sum" % sz)) for sz in ("32B", "64B", "128B")]
+            if all(v is not None for v in sized):
+                e["read_bytes_by_request_size"] = int(32 * sized[0] + 64 * sized[1] + 128 * sized[2])
+                e["bytes_per_launch"] = int(e["read_bytes_by_request_size"] + wv * 1024)
+            else:
+                e["bytes_per_launch"] = e["bytes_per_launch_fetch_x2"]
             if (k, "avg_us") in kt:
                 e["avg_us"] = kt[(k, "avg_us")]
                 e["GBps"] = e["bytes_per_launch"] / (e["avg_us"] * 1e-6) / 1e9
-            for src in (tcc, sq):
+            for src in (tcc, sq, ea):
                 for (kk, c), v in src.items():
                     if kk == k and not c.endswith(":n"):
                         e[c] = v
