@@ -241,7 +241,7 @@ def hbm_workload(ctx, capi, T, scenes, frames, warm):
     dt = time.perf_counter() - t0
     tot = pipe.totals()
     stages, n_t = stage_table(pipe, tot, with_canonical=False)
-    rays = tot["rays_primary"] + tot["rays_secondary"] + tot["rays_shadow"]
+    rays = tot["rays_primary"] + tot["rays_secondary"] + tot["rays_shadow"] - tot["rays_shadow_skipped"]      # rays actually traversed
     return {"workload": "BASELINE configs[4] on one GPU: displaced-grid mesh (seed 7, %d triangles), %dx%d, 4 radiance bounces, "
                         "1 spp/frame" % (tri.shape[0], W, H),
             "frames": frames, "ms_per_frame": dt / frames * 1e3, "Mrays_per_s": rays / dt / 1e6, "rays_per_frame": rays / frames,
@@ -296,8 +296,8 @@ def tiles_main(args, rank, world, local_rank, dev, capi, D, T, scenes, torch, di
         dist.barrier()
     elapsed = time.perf_counter() - t0
     tot = pipe.totals()
-    red = torch.tensor([elapsed, float(tot["rays_primary"] + tot["rays_secondary"] + tot["rays_shadow"]), float(tot["rays_primary"])],
-                       dtype=torch.float64, device=dev)
+    red = torch.tensor([elapsed, float(tot["rays_primary"] + tot["rays_secondary"] + tot["rays_shadow"] - tot["rays_shadow_skipped"]),
+                        float(tot["rays_primary"])], dtype=torch.float64, device=dev)
     if world > 1:
         mx = red.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -421,14 +421,16 @@ def main():
     elapsed = time.perf_counter() - t0
 
     tot = pipe.totals()
-    rays_local = tot["rays_primary"] + tot["rays_secondary"] + tot["rays_shadow"]
-    red = torch.tensor([elapsed, float(rays_local), float(tot["rays_primary"])], dtype=torch.float64, device=dev)
+    # `value` counts rays that were actually TRAVERSED.  Shadow rays of a light with N.L == 0 are emitted by the reference's
+    # shaders (and counted in rays_shadow) but their visibility is multiplied by zero, so this engine does not walk them.
+    rays_local = tot["rays_primary"] + tot["rays_secondary"] + tot["rays_shadow"] - tot["rays_shadow_skipped"]
+    red = torch.tensor([elapsed, float(rays_local), float(tot["rays_primary"]), float(tot["rays_shadow_skipped"])], dtype=torch.float64, device=dev)
     if world > 1:
         mx = red.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(red, op=dist.ReduceOp.SUM)
         elapsed = float(mx[0].item())
-    rays_all, primary_all = float(red[1].item()), float(red[2].item())
+    rays_all, primary_all, skipped_all = float(red[1].item()), float(red[2].item()), float(red[3].item())
 
     out = None
     if rank == 0:
@@ -445,6 +447,9 @@ def main():
             "primary_mrays_per_s": primary_all / elapsed / 1e6,
             "frames_per_s": K * world / elapsed,
             "rays_per_frame": rays_all / (K * world),
+            # every ray the reference's shaders trace for these frames (the unlit shadow rays included) per second of this run
+            "reference_ray_budget_mrays_per_s": (rays_all + skipped_all) / elapsed / 1e6,
+            "shadow_rays_not_traversed_per_frame": skipped_all / (K * world),
             "bvh_build_ms": build_ms, "bvh_rebuild_ms": rebuild_ms,
         }
         if not args.no_roofline:

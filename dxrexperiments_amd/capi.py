@@ -26,7 +26,7 @@ class RtError(RuntimeError):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays_primary", "rays_secondary", "rays_shadow", "primary_hits", "secondary_hits")] + \
                [(n, C.c_float) for n in ("ms_primary", "ms_shade0", "ms_trace_secondary", "ms_trace_shadow0", "ms_shade1",
-                                          "ms_trace_shadow1", "ms_resolve", "ms_total")] + [("frames", C.c_uint64)]
+                                          "ms_trace_shadow1", "ms_resolve", "ms_total")] + [("frames", C.c_uint64), ("rays_shadow_skipped", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -96,6 +96,7 @@ SIGNATURES = {
     "rt_pipeline_bind_output": (_i, [_p, _p, _u32, _u32]),
     "rt_pipeline_build_acceleration_structures": (_i, [_p]),
     "rt_pipeline_set_depth_limits": (_i, [_p, _u32, _u32]),
+    "rt_pipeline_set_skip_unlit_shadow_rays": (_i, [_p, _i]),
     "rt_pipeline_set_accumulation_mode": (_i, [_p, _u32]),
     "rt_pipeline_clear_output": (_i, [_p]),
     "rt_pipeline_update": (_i, [_p, _p]),
@@ -422,6 +423,10 @@ class Pipeline:
         f = _f32(faces)
         assert f.ndim == 4 and f.shape[0] == 6 and f.shape[1] == f.shape[2] and f.shape[3] == 4
         _check(lib().rt_pipeline_set_environment_cube(self.h, _ptr(f), f.shape[1]))
+
+    def set_skip_unlit_shadow_rays(self, on=True):
+        """Shadow rays of lights with N.L == 0 (visibility multiplied by zero): counted but not traversed (default) or traversed."""
+        _check(lib().rt_pipeline_set_skip_unlit_shadow_rays(self.h, 1 if on else 0))
 
     def set_environment_filter(self, seamless=True):
         """Cube-map filtering: seamless (cross-face taps, what D3D12 hardware does; default) or clamped to the face."""

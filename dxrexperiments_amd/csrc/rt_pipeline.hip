@@ -54,7 +54,9 @@ constexpr int PBLOCK = 256;
 constexpr int MAXD = 4;
 enum { C_NHIT = 0,                       // [0..MAXD] compacted hits per level
        C_SECONDARY = MAXD + 1, C_SHADOW = MAXD + 2,
-       C_COUNT = MAXD + 3 };
+       C_SHADOW_SKIPPED = MAXD + 3,      // shadow rays whose result cannot matter (N.L == 0): emitted, counted (by the shadow
+                                         //   launch: traced_counter[1], rt_trace_wave.h), not traversed
+       C_COUNT = MAXD + 4 };
 
 // Level L: the rays at radiance depth L (L >= 1; primary rays are generated, not stored), their hit
 // records, the compaction of the hits, and the shadow-ray queue of those hits.
@@ -85,6 +87,7 @@ struct PipeDev {
     uint32_t n_pixels;                  // pixels of the image this launch covers
     uint32_t max_rad, max_shadow;
     uint32_t accum_mode;
+    uint32_t skip_unlit;                // do not traverse shadow rays of lights with N.L == 0 (their visibility is multiplied by 0)
     uint32_t kind;                      // RT_PIPELINE_PROGRESSIVE / RT_PIPELINE_REALTIME
     float4 *accum;
     float4 *aov_direct, *aov_indirect;  // realtime pipeline outputs (RealtimeRaytracing.hlsl:3-4)
@@ -235,7 +238,9 @@ RT_DEV f3 directional_light(const PipeDev &pd, IO &io, f3 P, f3 N, uint32_t dept
     const rt_directional_light_params &dl = pd.pfc.directionalLight;
     const f3 L = normalize(mk3(-dl.forwardDir.x, -dl.forwardDir.y, -dl.forwardDir.z));
     const float NoL = saturate(dot(N, L));
-    const float vis = io.shadow(0, P, L, RAY_EPSILON, RAY_MAX_T, depth);
+    // the reference traces this ray even when NoL == 0 (RaytracingCommon.hlsli:132-133); its visibility is then multiplied
+    // by 0, so the ray is emitted and counted but need not be traversed (io.shadow's last argument)
+    const float vis = io.shadow(0, P, L, RAY_EPSILON, RAY_MAX_T, depth, NoL > 0.0f);
     return mk3(dl.color.x, dl.color.y, dl.color.z) * dl.color.w * NoL * vis;
 }
 
@@ -247,7 +252,7 @@ RT_DEV f3 point_light(const PipeDev &pd, IO &io, f3 P, f3 N, uint32_t depth)
     const float dist = length(path);
     const f3 L = normalize(path);
     const float NoL = saturate(dot(N, L));
-    const float vis = io.shadow(1, P, L, RAY_EPSILON, dist - RAY_EPSILON, depth);
+    const float vis = io.shadow(1, P, L, RAY_EPSILON, dist - RAY_EPSILON, depth, NoL > 0.0f);
     const float falloff = 1.0f / (2.0f * HLSL_PI * dist * dist);
     return mk3(pl.color.x, pl.color.y, pl.color.z) * pl.color.w * NoL * vis * falloff;
 }
@@ -268,7 +273,7 @@ RT_DEV f3 ambient_occlusion(const PipeDev &pd, IO &io, f3 P, f3 N, uint32_t pix)
             NoL = saturate(dot(N, dir));
             pdf = 1.0f / (2.0f * HLSL_PI);
         }
-        visibility += io.shadow(i, P, dir, RAY_EPSILON, 10.0f, 1u) * NoL / pdf;
+        visibility += io.shadow(i, P, dir, RAY_EPSILON, 10.0f, 1u, true) * NoL / pdf;
     }
     const float r = visibility / 4.0f;
     return mk3(r, r, r);
@@ -421,9 +426,15 @@ struct EmitIO {
     uint32_t idx, q;            // compact hit index at level L, pixel slot
     uint32_t shadow_mask, sec_mask;
     RT_DEV EmitIO(const PipeDev &p, int level, uint32_t i, uint32_t qq) : pd(p), L(level), idx(i), q(qq), shadow_mask(0), sec_mask(0) {}
-    RT_DEV float shadow(int s, f3 o, f3 d, float tmin, float tmax, uint32_t depth)
+    // matters = false: whatever this ray finds is multiplied by zero by the caller
+    RT_DEV float shadow(int s, f3 o, f3 d, float tmin, float tmax, uint32_t depth, bool matters)
     {
         if (depth >= pd.max_shadow) return 1.0f;
+        if (!matters && pd.skip_unlit) {          // tmax = -2: "emitted but not worth traversing"; the trace kernel counts these
+            store_ray(pd.lv[L].shO, pd.lv[L].shD, (size_t)s * hcap(pd, L) + idx, mk3(0.0f, 0.0f, 0.0f), 0.0f, mk3(0.0f, 0.0f, 0.0f), RT_TMAX_SKIPPED);
+            shadow_mask |= 1u << s;
+            return 1.0f;
+        }
         store_ray(pd.lv[L].shO, pd.lv[L].shD, (size_t)s * hcap(pd, L) + idx, o, tmin, d, tmax);
         shadow_mask |= 1u << s;
         return 1.0f;
@@ -446,9 +457,10 @@ struct ResolveIO {
     const PipeDev &pd;
     uint32_t idx, pix;
     RT_DEV ResolveIO(const PipeDev &p, uint32_t i, uint32_t px) : pd(p), idx(i), pix(px) {}
-    RT_DEV float shadow(int s, f3, f3, float, float, uint32_t depth)
+    RT_DEV float shadow(int s, f3, f3, float, float, uint32_t depth, bool matters)
     {
         if (depth >= pd.max_shadow) return 1.0f;
+        if (!matters && pd.skip_unlit) return 1.0f;                       // never traced; the caller multiplies by zero
         return pd.lv[L].vis[(size_t)s * hcap(pd, L) + idx] ? 1.0f : 0.0f;
     }
     RT_DEV f3 secondary(int w, f3 o, f3 d, float tmin, uint32_t depth)
@@ -740,7 +752,8 @@ __global__ void k_add_totals(const uint32_t *__restrict__ counters, unsigned lon
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     totals[0] += cap;
     totals[1] += counters[C_SECONDARY];
-    totals[2] += counters[C_SHADOW];
+    totals[2] += counters[C_SHADOW] + counters[C_SHADOW_SKIPPED];
+    totals[6] += counters[C_SHADOW_SKIPPED];
     totals[3] += counters[C_NHIT + 0];
     for (int l = 1; l <= MAXD; l++) totals[4] += counters[C_NHIT + l];
     totals[5] += 1;
@@ -836,6 +849,7 @@ struct rt_pipeline {
     rt_per_frame_constants pfc;
     bool have_pfc = false;
     uint32_t max_rad = 1, max_shadow = 2, accum_mode = RT_ACCUM_RUNNING_MEAN;
+    uint32_t skip_unlit = 0;           // off by default: every shadow ray the reference traces is traversed (rt_pipeline_set_skip_unlit_shadow_rays)
     // queues (sized for `cap` pixels)
     uint32_t cap = 0, sh0_batches = 0, levels = 0;
     struct LevelBuf { DevBuf O, D, hit, inst, slot_j, jlist, pix, shO, shD, vis; } lv[MAXD + 1];
@@ -1122,6 +1136,13 @@ int rt_pipeline_set_depth_limits(rt_pipeline *p, uint32_t max_radiance_depth, ui
     return RT_OK;
 }
 
+int rt_pipeline_set_skip_unlit_shadow_rays(rt_pipeline *p, int on)
+{
+    RT_REQUIRE(p, "null pipeline");
+    p->skip_unlit = on ? 1u : 0u;
+    return RT_OK;
+}
+
 int rt_pipeline_set_accumulation_mode(rt_pipeline *p, uint32_t mode)
 {
     RT_REQUIRE(p, "null pipeline");
@@ -1206,6 +1227,7 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     pd.n_pixels = tw * owned_rows;
     pd.max_rad = p->max_rad; pd.max_shadow = p->max_shadow;
     pd.accum_mode = p->accum_mode;
+    pd.skip_unlit = p->skip_unlit;
     pd.kind = p->kind;
     pd.accum = p->accum;
     pd.aov_direct = p->accum;                       // realtime: output 0 = direct lighting, output 1 = indirect specular
@@ -1426,7 +1448,8 @@ int rt_pipeline_get_stats(rt_pipeline *p, rt_stats *out)
     out->secondary_hits = 0;
     for (int l = 1; l <= MAXD; l++) out->secondary_hits += c[C_NHIT + l];
     out->rays_secondary = c[C_SECONDARY];
-    out->rays_shadow = c[C_SHADOW];
+    out->rays_shadow = (uint64_t)c[C_SHADOW] + c[C_SHADOW_SKIPPED];
+    out->rays_shadow_skipped = c[C_SHADOW_SKIPPED];
     out->frames = 1;
     if (p->ring_frames > 0 && p->ring_pos > 0) {
         float ms[8];
@@ -1446,7 +1469,7 @@ int rt_pipeline_get_totals(rt_pipeline *p, rt_stats *out)
     if (!p->totals.p) return RT_OK;
     unsigned long long t[8];
     HIP_TRY(hipMemcpy(t, p->totals.p, sizeof t, hipMemcpyDeviceToHost));
-    out->rays_primary = t[0]; out->rays_secondary = t[1]; out->rays_shadow = t[2];
+    out->rays_primary = t[0]; out->rays_secondary = t[1]; out->rays_shadow = t[2]; out->rays_shadow_skipped = t[6];
     out->primary_hits = t[3]; out->secondary_hits = t[4];
     out->frames = t[5];
     if (p->ring_frames > 0) {

@@ -46,6 +46,7 @@ RT_DEV v4f ldg16(const void *base, size_t byte_off)
     return *(gptr4)((const char *)base + byte_off);
 }
 
+#define RT_TMAX_SKIPPED  (-2.0f)        // a queue slot whose ray was emitted but need not be traversed (any-hit launches count them)
 #define RT_NODE_EMPTY    0x7FFFFFFE     // popped from an empty stack: the ray is finished
 #define RT_NODE_SENTINEL 0x7FFFFFFF     // bottom of a BLAS walk: return to the TLAS
 
@@ -238,6 +239,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                        unsigned long long *walk = nullptr)
 {
     uint32_t n_traced = 0;           // rays this lane actually traversed (statistics)
+    uint32_t n_skipped = 0;          // any-hit launches: queue slots marked RT_TMAX_SKIPPED
     uint32_t wk_glob = 0, wk_top = 0, wk_tri = 0, wk_inst = 0, wk_lines = 0;
     uint32_t wk_ray0 = 0;                        // node steps tallied when the lane's current ray started
     unsigned long long wk_longest = 0;           // (node steps << 32 | ray index) of the lane's longest walk
@@ -341,6 +343,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     n_traced++;
                     if (COUNT) wk_ray0 = wk_glob + wk_top;
                 } else {
+                    if (ANYHIT && r.tmax == RT_TMAX_SKIPPED) n_skipped++;
                     sink.store(my, best, traced);
                 }
             }
@@ -468,6 +471,10 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
     if (traced_counter) {            // one no-return atomic per persistent wave
         for (int o = 32; o > 0; o >>= 1) n_traced += (uint32_t)__shfl_xor((int)n_traced, o, 64);
         if ((threadIdx.x & 63u) == 0u && n_traced) atomicAdd(traced_counter, n_traced);
+        if (ANYHIT) {                // (the word behind an any-hit launch's ray counter tallies its skipped slots)
+            for (int o = 32; o > 0; o >>= 1) n_skipped += (uint32_t)__shfl_xor((int)n_skipped, o, 64);
+            if ((threadIdx.x & 63u) == 0u && n_skipped) atomicAdd(traced_counter + 1, n_skipped);
+        }
     }
 }
 

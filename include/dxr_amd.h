@@ -155,6 +155,12 @@ int rt_pipeline_build_acceleration_structures(rt_pipeline *p);               /* 
  * more -> RT_ERR_UNSUPPORTED.  The shadow depth is unbounded (levels past the radiance depth cast none). */
 int rt_pipeline_set_depth_limits(rt_pipeline *p, uint32_t max_radiance_depth, uint32_t max_shadow_depth);
 int rt_pipeline_set_accumulation_mode(rt_pipeline *p, uint32_t mode);        /* RT_ACCUM_* */
+/* evaluateDirectionalLight / evaluatePointLight trace their shadow ray even when N.L == 0 (RaytracingCommon.hlsli:126-147) and
+ * then multiply the visibility by that zero.  off (default): they are traversed like every other ray, as in the reference.
+ * on: such rays are emitted and counted (rt_stats.rays_shadow) but not traversed (rt_stats.rays_shadow_skipped); the image is
+ * bit-identical either way.  Measured: a third of the shadow rays of the bench scene, but they end within a few steps inside
+ * the closed geometry they start in, so the frame time does not move; -7 % on the single-sided 10 M-triangle terrain. */
+int rt_pipeline_set_skip_unlit_shadow_rays(rt_pipeline *p, int on);
 int rt_pipeline_clear_output(rt_pipeline *p);
 /* update(): the 188-byte constant buffer the reference fills each frame (.cpp:177-213) */
 int rt_pipeline_update(rt_pipeline *p, const rt_per_frame_constants *constants);

@@ -138,6 +138,9 @@ typedef struct rt_stats {
     float    ms_resolve;         /* final shade + accumulate              */
     float    ms_total;
     uint64_t frames;             /* frames the counts / times above cover  */
+    uint64_t rays_shadow_skipped;/* of rays_shadow: emitted for a light with N.L == 0, whose visibility is multiplied by zero,
+                                    and therefore not traversed (rt_pipeline_set_skip_unlit_shadow_rays); rays_shadow itself counts
+                                    every shadow ray the reference's shaders trace                                              */
 } rt_stats;
 
 /* Algorithmic work of one traversal stage of the last rendered frame, counted by

@@ -368,7 +368,7 @@ def test_count_walk_is_the_production_walk(gpu, capi):
     assert w1 == w2
     assert w1["primary"]["rays"] == st["rays_primary"] == W * H
     assert w1["secondary"]["rays"] == st["rays_secondary"]
-    assert w1["shadow0"]["rays"] + w1["shadow1"]["rays"] == st["rays_shadow"]
+    assert w1["shadow0"]["rays"] + w1["shadow1"]["rays"] == st["rays_shadow"] and st["rays_shadow_skipped"] == 0
     for s in w1.values():
         assert s["instance_entries"] == 0                       # one identity instance: single-level walk
         assert s["nodes_global"] + s["nodes_lds"] >= s["rays"] // 2 and s["tris"] > 0
@@ -461,3 +461,29 @@ def test_render_bands_equals_the_whole_frame(gpu, capi, world, band):
         p.render_bands(12, 0, 1)                    # not a multiple of the 8x8 pixel tiles
     with pytest.raises(capi.RtError):
         p.render_bands(16, 2, 2)
+
+
+def test_unlit_shadow_rays_are_counted_but_not_traversed(gpu, capi, oracle):
+    """evaluateDirectionalLight / evaluatePointLight trace their shadow ray even when N.L == 0 and multiply its visibility by
+    that zero (RaytracingCommon.hlsli:126-147).  Skipping the traversal of exactly those rays leaves image and emitted-ray counts
+    (the oracle's) unchanged; only rays_shadow_skipped tells."""
+    W, H = 120, 90
+    v, i = oracle.obj_load(CORNELL_OBJ)
+    osc = make_oracle_scene(oracle, [(v, i)], [(0, None)])
+    p = make_gpu_pipeline(capi, gpu, [(v, i)], [(0, None)], [T.default_material()], W, H, env=scenes.sky_cubemap(8))
+    host = capi.ProgressiveHost(12)
+    c = scenes.cornell_camera()
+    cam = cam_array(c, W / H)
+    pfc = host.update(cam, 0.0, 1, W, H)
+    imgs, stats = [], []
+    for on in (True, False):
+        p.set_skip_unlit_shadow_rays(on)
+        p.clear_output()
+        p.update(pfc)
+        p.render()
+        imgs.append(p.read_output())
+        stats.append(p.stats())
+    ref, ost = osc.render(T.default_material(), pfc, W, H, env_faces=scenes.sky_cubemap(8))
+    assert np.array_equal(imgs[0], ref) and np.array_equal(imgs[1], ref)
+    assert stats[0]["rays_shadow"] == stats[1]["rays_shadow"] == ost["rays_shadow"]
+    assert stats[1]["rays_shadow_skipped"] == 0 and 0 < stats[0]["rays_shadow_skipped"] < stats[0]["rays_shadow"]
