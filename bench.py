@@ -172,7 +172,7 @@ def gather_bytes(stage, w):
     return LINE_BYTES * (w["lines"] + 2 * w["instance_entries"]) + STAGE_IO_BYTES[stage] * w["rays"]
 
 
-def stage_table(pipe, tot, with_canonical=True):
+def stage_table(pipe, tot, with_canonical=True, levels=1):
     """Per traversal stage: HIP-event time (average over the timed launches), rays, the production walk's requested bytes
     and -- as SURVEY 8(d)'s layout-independent contract figure -- the canonical-LBVH counters' algorithmic bytes."""
     walk = pipe.count_walk()
@@ -189,6 +189,7 @@ def stage_table(pipe, tot, with_canonical=True):
               "nodes_global_per_ray": wk["nodes_global"] / max(wk["rays"], 1), "nodes_lds_per_ray": wk["nodes_lds"] / max(wk["rays"], 1),
               "tris_per_ray": wk["tris"] / max(wk["rays"], 1), "instance_entries_per_ray": wk["instance_entries"] / max(wk["rays"], 1),
               "lines_per_ray": wk["lines"] / max(wk["rays"], 1), "longest_walk_steps": wk["longest_walk"],
+              "launches_per_frame": levels if name == "secondary" else 1,
               "Mrays_per_s": wk["rays"] / (ms * 1e-3) / 1e6 if ms > 0 else 0.0}
         if work is not None:
             w = {k: sum(work[p][k] for p in parts) for k in ("rays", "nodes", "tris")}
@@ -240,7 +241,7 @@ def hbm_workload(ctx, capi, T, scenes, frames, warm):
     ctx.synchronize()
     dt = time.perf_counter() - t0
     tot = pipe.totals()
-    stages, n_t = stage_table(pipe, tot, with_canonical=False)
+    stages, n_t = stage_table(pipe, tot, with_canonical=False, levels=4)
     rays = tot["rays_primary"] + tot["rays_secondary"] + tot["rays_shadow"] - tot["rays_shadow_skipped"]      # rays actually traversed
     return {"workload": "BASELINE configs[4] on one GPU: displaced-grid mesh (seed 7, %d triangles), %dx%d, 4 radiance bounces, "
                         "1 spp/frame" % (tri.shape[0], W, H),
@@ -495,8 +496,8 @@ def main():
             k5 = prof5.get("kernels", {}).get(d["kernel"], {})
             traffic = k5.get("bytes_per_launch")
             prof_us = k5.get("avg_us")
-            live_ms = d["avg_ms"]
-            h["roofline"] = {"bound": "hbm", "kernel": d["kernel"], "stage": dom,
+            live_ms = d["avg_ms"] / d["launches_per_frame"]          # the stage time covers one launch per radiance level
+            h["roofline"] = {"bound": "hbm", "kernel": d["kernel"], "stage": dom, "launches_per_frame": d["launches_per_frame"],
                              # memory-side bytes per launch (PMC passes of THIS workload, profiles/<round>/traffic.json: read requests
                              # by size + WRITE_SIZE) / this run's HIP-event duration of the same launches; the profiling session's own
                              # duration and rate alongside.  The ~0.8 GB of nodes + triangle records do not fit the 256 MB Infinity Cache.
