@@ -506,8 +506,8 @@ def main():
                              "frac": traffic / (live_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
                              "traffic": traffic, "avg_launch_ms": live_ms, "launches_timed": h["launches_timed"],
                              "profiled_avg_us": prof_us, "profiled_GBps": k5.get("GBps"),
-                             "gathered_bytes_per_launch": d["gathered_bytes"], "gathered_GBps": d["gathered_GBps"],
-                             "requested_bytes_per_launch": d["requested_bytes"],
+                             "gathered_bytes_per_frame": d["gathered_bytes"], "gathered_GBps": d["gathered_GBps"],
+                             "requested_bytes_per_frame": d["requested_bytes"],
                              "pmc": {k: k5.get(k) for k in ("TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum",
                                                             "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES",
                                                             "SQ_INSTS_VALU") if k in k5},
