@@ -378,10 +378,11 @@ int rt_scene_build(rt_scene *s, uint32_t hit_group_count)
         if ((rc = rt_build_blas(ctx, in.model)) != RT_OK) break;
     if (rc == RT_OK) rc = rt_build_tlas(ctx, s);
     if (rc == RT_OK) {
-        (void)hipEventRecord(e1, ctx->stream);
-        (void)hipEventSynchronize(e1);
-        (void)hipEventElapsedTime(&s->build_ms, e0, e1);
-        s->built = true;
+        if (hipEventRecord(e1, ctx->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+            hipEventElapsedTime(&s->build_ms, e0, e1) != hipSuccess) {
+            rt_set_error("rt_scene_build: timing events failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = RT_ERR_HIP;
+        } else s->built = true;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

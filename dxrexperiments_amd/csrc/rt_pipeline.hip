@@ -899,9 +899,12 @@ int ensure_queues(rt_pipeline *p, uint32_t cap, uint32_t sh0_batches, uint32_t l
 // radiance levels a frame traces: level l exists when hits of depth l-1 may spawn rays
 inline uint32_t frame_levels(const rt_pipeline *p) { return p->max_rad < (uint32_t)MAXD ? p->max_rad : (uint32_t)MAXD; }
 
+// returns the first error of an event record (kernel launch errors surface in hipGetLastError at the call site)
 template <int STACK, bool TWO_LEVEL>
-void launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
+hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
 {
+    hipError_t first_error = hipSuccess;
+    auto record = [&](hipEvent_t e, hipStream_t s) { const hipError_t rc = hipEventRecord(e, s); if (first_error == hipSuccess) first_error = rc; };
     hipStream_t st = p->ctx->stream;
     const bool T = p->ring_frames > 0;
     const size_t ring_slot = T ? (size_t)(p->ring_pos % (uint64_t)p->ring_frames) : 0;
@@ -910,13 +913,13 @@ void launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
     const rt_context *ctx = p->ctx;
     const uint32_t levels = frame_levels(p);
     const uint32_t any = RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH | RT_RAY_FLAG_SKIP_CLOSEST_HIT_SHADER;
-    if (T) (void)hipEventRecord(ev[0], st);
+    if (T) record(ev[0], st);
     // primary rays are coherent: one 8x8 tile per wave, scheduled by the hardware dispatcher
     k_primary<STACK, TWO_LEVEL><<<blocks(cap), PBLOCK, 0, st>>>(pd);
     k_compact_level<<<(cap + CBLOCK - 1) / CBLOCK, CBLOCK, 0, st>>>(pd, 0);
-    if (T) (void)hipEventRecord(ev[1], st);
+    if (T) record(ev[1], st);
     k_shade_emit<true><<<blocks(cap), PBLOCK, 0, st>>>(pd, 0, shadow_slots, levels >= 1 ? 1u : 0u);
-    if (T) (void)hipEventRecord(ev[2], st);
+    if (T) record(ev[2], st);
     ShadowSrcN shadows;
     memset(&shadows, 0, sizeof shadows);
     shadows.q[0] = QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, shadow_slots, any};         // RaytracingCommon.hlsli:94
@@ -929,10 +932,10 @@ void launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
         k_trace_secondary<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_secondary<STACK, TWO_LEVEL>, PBLOCK, (size_t)cap * 2), PBLOCK, 0, st>>>(
             pd.sc, rays, pd.lv[l].hit, pd.lv[l].inst, pd.pools + (size_t)l * RT_POOL_GROUPS * RT_POOL_STRIDE, &pd.counters[C_SECONDARY]);
         k_compact_level<<<(2 * cap + CBLOCK - 1) / CBLOCK, CBLOCK, 0, st>>>(pd, (int)l);
-        if (T) (void)hipEventRecord(ev[3 + 2 * (l - 1)], st);
+        if (T) record(ev[3 + 2 * (l - 1)], st);
         const bool casts_shadows = l < pd.max_shadow, spawns = l < levels;
         if (casts_shadows || spawns) k_shade_emit<false><<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd, (int)l, 2u, spawns ? 1u : 0u);
-        if (T) (void)hipEventRecord(ev[4 + 2 * (l - 1)], st);
+        if (T) record(ev[4 + 2 * (l - 1)], st);
         if (casts_shadows) {
             shadows.q[shadows.nq] = QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any};
             shadows.vis[shadows.nq] = pd.lv[l].vis;
@@ -942,18 +945,18 @@ void launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
     }
     k_trace_shadow<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL>, PBLOCK, shadow_max), PBLOCK, 0, st>>>(
         pd.sc, shadows, pd.pools, &pd.counters[C_SHADOW]);
-    if (T) (void)hipEventRecord(ev[EV_SHADOW], st);
+    if (T) record(ev[EV_SHADOW], st);
     if (levels <= 1) k_resolve<1><<<blocks(cap), PBLOCK, 0, st>>>(pd);
     else k_resolve<MAXD><<<blocks(cap), PBLOCK, 0, st>>>(pd);
-    if (T) { (void)hipEventRecord(ev[EV_RESOLVE], st); p->ring_levels[ring_slot] = (uint8_t)levels; p->ring_pos++; }
+    if (T) { record(ev[EV_RESOLVE], st); p->ring_levels[ring_slot] = (uint8_t)levels; p->ring_pos++; }
     k_add_totals<<<1, 64, 0, st>>>(pd.counters, p->totals.as<unsigned long long>(), pd.n_pixels);
+    return first_error;
 }
 
 template <int STACK>
-void launch_frame_any(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
+hipError_t launch_frame_any(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
 {
-    if (p->scene->two_level) launch_frame<STACK, true>(p, pd, shadow_slots);
-    else launch_frame<STACK, false>(p, pd, shadow_slots);
+    return p->scene->two_level ? launch_frame<STACK, true>(p, pd, shadow_slots) : launch_frame<STACK, false>(p, pd, shadow_slots);
 }
 
 template <bool TWO_LEVEL>
@@ -1245,8 +1248,8 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     HIP_TRY(hipMemsetAsync(pd.counters, 0, POOL_OFFSET_WORDS * 4 + POOL_BYTES, st));
     // 18 LDS stack rows + the 8-row top table = 26 KiB per 256-thread block = 6 resident blocks per CU, whatever
     // the depth of the tree; the rare deeper walk continues in global rows (rt_trace_wave.h)
-    if (ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST) launch_frame_any<RT_LDS_STACK_ROWS_TEST>(p, pd, shadow_slots);
-    else launch_frame_any<RT_LDS_STACK_ROWS>(p, pd, shadow_slots);
+    HIP_TRY(ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST ? launch_frame_any<RT_LDS_STACK_ROWS_TEST>(p, pd, shadow_slots)
+                                                           : launch_frame_any<RT_LDS_STACK_ROWS>(p, pd, shadow_slots));
     HIP_TRY(hipGetLastError());
     p->last_pd = pd;
     p->last_shadow_slots = shadow_slots;

@@ -89,6 +89,43 @@ def test_sponza_class_rays(gpu, oracle, capi):
     assert p.g.trace_last_ms() >= 0
 
 
+def test_wide_node_culling_stays_conservative_in_hard_places(gpu, oracle, capi):
+    """The production walk culls against quantised child boxes in the node's own frame with a rounding margin per axis, and
+    sends steep rays down an exact path (rt_trace_wave.h, wide_step).  Places where a too-tight margin or a wrong path
+    would lose a hit: geometry far from the coordinate origin (large |origin|, small extents), tiny triangles, rays with
+    direction components from 1e-9 to 1e-3 (both sides of the 2^-16 steepness threshold) and exactly zero, rays that
+    start on box planes and run inside axis-aligned walls.  Every hit must equal the brute-force oracle's, bit for bit."""
+    r = np.random.default_rng(77)
+    # (a) a soup of small triangles 4000 units away from the origin
+    v, i = triangle_soup(12000, seed=21, extent=6.0, size=0.05)
+    v["position"] += np.array([4000.0, -2500.0, 3000.0], np.float32)
+    p = Pair(oracle, capi, gpu, [(v, i)], [(0, None)])
+    c = np.array([4000.0, -2500.0, 3000.0])
+    O, D = random_rays(30000, 31, c - 6, c + 6)
+    compare_all(p, O, D, brute=True)
+    # (b) an axis-aligned tessellated wall + floor (flat boxes, shared planes) and rays inside / along them
+    wall, wt = scenes.displaced_grid(64, seed=3, extent=8.0)
+    wall["position"][:, 1] = 0.0                                    # a perfectly flat floor at y = 0: every box is flat
+    p = Pair(oracle, capi, gpu, [(wall, wt)], [(0, None)])
+    n = 24000
+    O = np.zeros((n, 4), np.float32); D = np.zeros((n, 4), np.float32)
+    O[:, 0] = r.uniform(-4, 4, n); O[:, 2] = r.uniform(-4, 4, n)
+    O[:, 1] = np.where(r.uniform(size=n) < 0.5, 0.0, r.uniform(-1e-6, 1e-6, n))       # on the floor plane or within a micron of it
+    ang = r.uniform(0, 2 * np.pi, n)
+    D[:, 0] = np.cos(ang); D[:, 2] = np.sin(ang)
+    steep = 10.0 ** r.uniform(-9, -3, n) * np.where(r.uniform(size=n) < 0.5, 1.0, -1.0)
+    D[:, 1] = np.where(r.uniform(size=n) < 0.25, 0.0, steep)        # a quarter exactly in the plane
+    D[:, :3] /= np.linalg.norm(D[:, :3].astype(np.float64), axis=1, keepdims=True).astype(np.float32)
+    O[:, 3] = 0.0; D[:, 3] = 1e38
+    compare_all(p, O, D, brute=True)
+    # (c) the same rays against a mesh with relief, origins ON vertices (ray origin exactly on box planes)
+    hill, ht = scenes.displaced_grid(48, seed=5, extent=8.0)
+    p = Pair(oracle, capi, gpu, [(hill, ht)], [(0, None)])
+    pick = r.integers(0, hill.shape[0], n)
+    O[:, :3] = hill["position"][pick]
+    compare_all(p, O, D, brute=True)
+
+
 def test_small_lds_stack_spills_to_global_rows():
     """The production kernels keep 24 stack rows per lane in LDS and continue in global memory beyond them
     (rt_trace_wave.h); real scenes rarely get there, so the 6-row instantiation (RT_LDS_STACK_ROWS=6) re-runs
