@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget (rank 0, N=1 only); 0 = skip")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not re-run a few frames under rocprofv3 for roofline.traffic; use the "
+                    "committed profiles/<round>/traffic.json only")
     ap.add_argument("--hbm-frames", type=int, default=8, help="frames of the HBM-bound 10 M-triangle 4K workload timed for roofline_hbm "
                     "(rank 0, N=1 only); 0 = skip")
     ap.add_argument("--workload", choices=("c2", "c5"), default="c2", help="c5: ONLY the 10 M-triangle workload (profiling passes)")
@@ -157,6 +159,61 @@ def committed_profile(workload):
             if w:
                 return dict(w, commit=d.get("commit"), source=path[len(here) + 1:])
     return {}
+
+
+LIVE_PMC_PASSES = {"ea": ["TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"], "write": ["WRITE_SIZE"]}
+
+
+def live_traffic(workload, width, height, budget_s=90.0):
+    """Memory-side bytes per launch of the traversal kernels, measured IN THIS RUN: bench.py re-runs itself for a few frames
+    as a child of `rocprofv3 --kernel-trace --pmc ...`, one pass for the L2's read requests by size (32 / 64 / 128 B: the
+    calibrated byte count for this access shape, MI355X_MICROARCH.md HBM section) and one for WRITE_SIZE (they do not fit one
+    pass).  Called before this process touches the GPU.  {kernel: {"bytes_per_launch", ...}} or {} if rocprofv3 is not
+    usable here (the committed profiles/<round>/traffic.json is the fallback)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}
+    here = os.path.dirname(os.path.abspath(__file__))
+    child = [os.path.join(here, "bench.py"), "--cpu-seconds", "0", "--no-roofline", "--no-live-pmc"]
+    child += (["--steps", "3", "--warmup", "1", "--hbm-frames", "0", "--width", str(width), "--height", str(height)] if workload == "c2"
+              else ["--workload", "c5", "--hbm-frames", "2"])
+    out, t0 = {}, time.perf_counter()
+    env = dict(os.environ, TMPDIR="/tmp")
+    for name, counters in LIVE_PMC_PASSES.items():
+        if time.perf_counter() - t0 > budget_s:
+            return {}
+        d = tempfile.mkdtemp(prefix="dxr_pmc_")
+        try:
+            # (the program itself directly behind `--`: the profiler's preloaded library initialises the GPU first)
+            r = subprocess.run([exe, "--kernel-trace", "--pmc"] + counters + ["-d", d, "-o", "p", "--output-format", "csv", "--",
+                                sys.executable, *child], cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {}
+            acc = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    k = next((k for k in ("k_trace_secondary", "k_trace_shadow", "k_primary") if k in row["Kernel_Name"]), None)
+                    if k:
+                        a = acc.setdefault((k, row["Counter_Name"]), [0, 0.0])
+                        a[0] += 1
+                        a[1] += float(row["Counter_Value"])
+            for (k, c), (n, v) in acc.items():
+                out.setdefault(k, {})[c] = v / n
+                out[k]["dispatches"] = n
+        except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+            return {}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    for k, e in out.items():
+        if all(c in e for c in LIVE_PMC_PASSES["ea"]) and "WRITE_SIZE" in e:
+            e["read_bytes_by_request_size"] = int(32 * e["TCC_EA0_RDREQ_32B_sum"] + 64 * e["TCC_EA0_RDREQ_64B_sum"] + 128 * e["TCC_EA0_RDREQ_128B_sum"])
+            e["bytes_per_launch"] = int(e["read_bytes_by_request_size"] + e["WRITE_SIZE"] * 1024)      # rocprofv3 reports WRITE_SIZE in KiB
+    return {k: e for k, e in out.items() if "bytes_per_launch" in e}
 
 
 def walk_bytes(stage, w):
@@ -335,6 +392,12 @@ def main():
         sys.exit(relaunch_distributed(args))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # memory-side traffic for the two rooflines, measured by child runs under rocprofv3 BEFORE this process touches the GPU
+    live = {}
+    if world == 1 and not args.no_roofline and not args.no_live_pmc and args.partition == "samples" and args.workload == "c2":
+        live["c2"] = live_traffic("c2", args.width, args.height)
+        if args.hbm_frames > 0:
+            live["c5"] = live_traffic("c5", args.width, args.height)
 
     import numpy as np
     import torch
@@ -458,6 +521,7 @@ def main():
             dom = max(TRACE_STAGES, key=lambda s: stages[s]["avg_ms"])
             d = stages[dom]
             prof = committed_profile("c2").get("kernels", {}).get(d["kernel"], {})
+            lv = live.get("c2", {}).get(d["kernel"], {})
             # The C2 working set (~12 MB of nodes + 12 MB of triangle records) lives in the 4 MiB-per-XCD L2s and the
             # Infinity Cache, so HBM cannot bound these kernels (memory-side traffic = `traffic`, a few % of what the lanes
             # request).  What they are is a random gather of 64-B lines from cache-resident tables by divergent lanes, and the
@@ -465,7 +529,9 @@ def main():
             out["roofline"] = {"bound": "cache-gather", "kernel": d["kernel"], "stage": dom,
                                "achieved": d["gathered_GBps"], "peak": GATHER_PEAK_GBS, "unit": "GB/s",
                                "frac": d["gathered_GBps"] / GATHER_PEAK_GBS,
-                               "traffic": prof.get("bytes_per_launch"),
+                               "traffic": lv.get("bytes_per_launch", prof.get("bytes_per_launch")),
+                               "traffic_source": ("this run: %d launches under rocprofv3 --pmc (read requests by size, WRITE_SIZE)" % lv["dispatches"])
+                                                 if lv else "committed profile",
                                "bytes_per_launch": d["gathered_bytes"], "avg_launch_ms": d["avg_ms"], "launches_timed": n_t,
                                "definition": "bytes = 64 B x distinct lines the launch gathers (node lines de-duplicated over the lanes of "
                                              "each wave step + the lines its triangle records span, tallied by a counting instantiation "
@@ -494,7 +560,8 @@ def main():
             d = h["stages"][dom]
             prof5 = committed_profile("c5")
             k5 = prof5.get("kernels", {}).get(d["kernel"], {})
-            traffic = k5.get("bytes_per_launch")
+            lv5 = live.get("c5", {}).get(d["kernel"], {})
+            traffic = lv5.get("bytes_per_launch", k5.get("bytes_per_launch"))
             prof_us = k5.get("avg_us")
             live_ms = d["avg_ms"] / d["launches_per_frame"]          # the stage time covers one launch per radiance level
             h["roofline"] = {"bound": "hbm", "kernel": d["kernel"], "stage": dom, "launches_per_frame": d["launches_per_frame"],
@@ -505,6 +572,9 @@ def main():
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": traffic / (live_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
                              "traffic": traffic, "avg_launch_ms": live_ms, "launches_timed": h["launches_timed"],
+                             "traffic_source": ("this run: %d launches under rocprofv3 --pmc (read requests by size, WRITE_SIZE)" % lv5["dispatches"])
+                                               if lv5 else "committed profile",
+                             "traffic_committed_profile": k5.get("bytes_per_launch"),
                              "profiled_avg_us": prof_us, "profiled_GBps": k5.get("GBps"),
                              "gathered_bytes_per_frame": d["gathered_bytes"], "gathered_GBps": d["gathered_GBps"],
                              "requested_bytes_per_frame": d["requested_bytes"],

@@ -159,7 +159,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["frames_per_gpu"] == 4
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--width", "480", "--height", "270",
-                          "--cpu-seconds", "0"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+                          "--cpu-seconds", "0", "--no-live-pmc", "--hbm-frames", "0"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-3000:]
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     # weak scaling: two ranks trace twice the frames, i.e. about twice the rays per step

@@ -7,7 +7,7 @@ n=0
 : > gpurun_out/pmc_${TAG}.md
 for C in "$@"; do
   n=$((n+1))
-  ( cd /tmp && export TMPDIR=/tmp && timeout 240 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/pmc_${TAG}_$n -o pmc --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-roofline --hbm-frames 0 > $R/gpurun_out/pmc_${TAG}_$n.log 2>&1 )
+  ( cd /tmp && export TMPDIR=/tmp && timeout 240 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/pmc_${TAG}_$n -o pmc --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-roofline --hbm-frames 0 --no-live-pmc > $R/gpurun_out/pmc_${TAG}_$n.log 2>&1 )
   python3 tools/profile_summary.py gpurun_out/pmc_${TAG}_$n "rocprofv3 --pmc $C : python3 bench.py --steps 3 (1080p Sponza-class)" | grep -E "^#|^\| (kernel|---|k_trace|k_primary)" >> gpurun_out/pmc_${TAG}.md
   rm -rf gpurun_out/pmc_${TAG}_$n gpurun_out/pmc_${TAG}_$n.log
 done

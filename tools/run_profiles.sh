@@ -12,7 +12,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for w in $WL; do
   PROG=$R/bench.py
-  if [ $w = c2 ]; then ARGS="--steps 8 --warmup 2 --cpu-seconds 0 --hbm-frames 0"; elif [ $w = c5 ]; then ARGS="--workload c5 --hbm-frames 4"; else PROG=$R/tools/profile_c4.py; ARGS="4"; fi
+  if [ $w = c2 ]; then ARGS="--steps 8 --warmup 2 --cpu-seconds 0 --hbm-frames 0 --no-live-pmc"; elif [ $w = c5 ]; then ARGS="--workload c5 --hbm-frames 4 --no-live-pmc"; else PROG=$R/tools/profile_c4.py; ARGS="4"; fi
   run() {   # name, rocprof options...
     n=$1; shift
     timeout 600 rocprofv3 "$@" -d $OUT/${w}_$n -o p --output-format csv -- python3 $PROG $ARGS > $OUT/${w}_$n.log 2>&1
