@@ -8,16 +8,18 @@
 // Meister & Bittner 2018): clusters start as the Morton-sorted leaves of the canonical tree;
 // every round each cluster finds, inside a window of +-RADIUS neighbours, the partner that
 // minimises the surface area of the merged box; mutual pairs merge; the cluster array is
-// compacted in order (scans, no atomics), until one cluster is left.  Node ids come from
-// prefix sums, so the build is run-to-run deterministic.
+// compacted in order (prefix sums by workgroup index, rt_level_scan.h), until one cluster is left.
+// Node ids come from those prefix sums, so the build is run-to-run deterministic.  A round is two
+// launches; its cluster count lives in device memory and the host launches a batch of rounds blind.
 //
 // Output: triangles re-gathered in the depth-first order of the new tree, so that every subtree is a
 // contiguous triangle range and subtrees of <= leaf_max triangles collapse to leaves, and the binary
 // tree itself, which rt_bvh_wide.hip collapses into the four-wide 64-B nodes the traversal walks.
 #include "rt_internal.h"
 
+#include "rt_level_scan.h"
+
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 namespace {
 
@@ -37,11 +39,34 @@ __device__ __forceinline__ float merged_area(const Box6 &a, const Box6 &b)
     return dx * dy + dy * dz + dz * dx;
 }
 
+// a piece of the build's one temporary allocation
+struct View {
+    void *p = nullptr;
+    template <class T> T *as() const { return (T *)p; }
+};
+
+// where the clustering stands before round r (device memory, one entry per round of a batch)
+struct PlocRound { uint32_t c, next_node, cur, error; };
+constexpr uint32_t PLOC_TAIL = 4096, TAIL_BLOCK = 1024, PLOC_MAX_BATCH = 64;
+
+// the arrays the PLOC rounds read and write
+struct PlocArrays {
+    uint32_t *nn, *flags;
+    uint64_t *tally;                   // per workgroup: clusters kept (low word) and nodes created (high word)
+    uint32_t *arrivals;
+    PlocRound *round;                  // PLOC_MAX_BATCH + 1 entries
+    uint32_t *cl_node[2];
+    Box6 *cl_box[2];
+    uint32_t *left, *right, *size, *parent;
+    Box6 *node_box;
+};
+
 // clusters start as the canonical leaves, in key order
 __global__ void k_ploc_init(const rt_bvh_node *__restrict__ nodes, uint32_t n, uint32_t *__restrict__ cl_node, Box6 *__restrict__ cl_box,
-                            uint32_t *__restrict__ size, uint32_t *__restrict__ parent)
+                            uint32_t *__restrict__ size, uint32_t *__restrict__ parent, PlocRound *__restrict__ round0, uint32_t *__restrict__ arrivals)
 {
     const uint32_t k = blockIdx.x * PB + threadIdx.x;
+    if (k == 0) { const PlocRound r0 = {n, n, 0u, 0u}; *round0 = r0; *arrivals = 0; }
     if (k >= n) return;
     const rt_bvh_node nd = nodes[n - 1 + k];
     Box6 b;
@@ -52,76 +77,106 @@ __global__ void k_ploc_init(const rt_bvh_node *__restrict__ nodes, uint32_t n, u
     parent[k] = 0xFFFFFFFFu;
 }
 
-// nearest neighbour inside the window, smallest merged area, ties -> lower index
-__global__ void __launch_bounds__(PB) k_ploc_nn(const Box6 *__restrict__ cl_box, uint32_t c, uint32_t *__restrict__ nn)
+// First half of a round.  Nearest neighbour inside the window (smallest merged area, ties -> lower index) for the
+// workgroup's clusters and a halo of RADIUS either side, so that "is the choice mutual" needs no second launch; then the
+// flags (bit 0: the cluster survives, bit 1: it creates a node), the workgroup's tally, and -- in the last workgroup to
+// arrive -- the offsets of all workgroups and the size of the next round.
+__global__ void __launch_bounds__(PB) k_ploc_pair(PlocArrays a, uint32_t r)
 {
-    __shared__ Box6 tile[PB + 2 * PLOC_RADIUS];
-    const int base = (int)(blockIdx.x * PB) - PLOC_RADIUS;
-    for (int t = threadIdx.x; t < (int)PB + 2 * PLOC_RADIUS; t += PB) {
+    constexpr int R = PLOC_RADIUS;
+    __shared__ Box6 tile[PB + 4 * R];
+    __shared__ uint32_t near[PB + 2 * R];
+    __shared__ uint64_t lds64[PB];
+    __shared__ uint32_t lds[PB / 64];
+    __shared__ uint32_t lds_flag;
+    const PlocRound s = a.round[r];
+    if (s.c <= PLOC_TAIL || s.error) {                 // the tail kernel's share, or a failed round: hand the state on
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.round[r + 1] = s;
+        return;
+    }
+    const uint32_t c = s.c, nblocks = (c + PB - 1) / PB;
+    if (blockIdx.x >= nblocks) return;
+    const Box6 *cl_box = a.cl_box[s.cur];
+    const int base = (int)(blockIdx.x * PB) - 2 * R;    // tile[t] = cluster base + t
+    for (int t = threadIdx.x; t < (int)PB + 4 * R; t += PB) {
         const int g = base + t;
         if (g >= 0 && g < (int)c) tile[t] = cl_box[g];
     }
     __syncthreads();
-    const uint32_t i = blockIdx.x * PB + threadIdx.x;
-    if (i >= c) return;
-    const Box6 me = tile[threadIdx.x + PLOC_RADIUS];
-    float best = __uint_as_float(0x7f800000u);
-    uint32_t arg = i;
-    for (int d = -PLOC_RADIUS; d <= PLOC_RADIUS; d++) {
-        const int j = (int)i + d;
-        if (d == 0 || j < 0 || j >= (int)c) continue;
-        const float a = merged_area(me, tile[threadIdx.x + PLOC_RADIUS + d]);
-        if (a < best) { best = a; arg = (uint32_t)j; }
+    for (int t = threadIdx.x; t < (int)PB + 2 * R; t += PB) {       // near[t] = nn of cluster base + R + t
+        const int i = base + R + t;
+        if (i < 0 || i >= (int)c) continue;
+        const Box6 me = tile[t + R];
+        float best = __uint_as_float(0x7f800000u);
+        uint32_t arg = (uint32_t)i;
+        for (int d = -R; d <= R; d++) {
+            const int j = i + d;
+            if (d == 0 || j < 0 || j >= (int)c) continue;
+            const float ar = merged_area(me, tile[t + R + d]);
+            if (ar < best) { best = ar; arg = (uint32_t)j; }
+        }
+        near[t] = arg;
     }
-    nn[i] = arg;
-}
-
-__global__ void k_ploc_flags(const uint32_t *__restrict__ nn, uint32_t c, uint32_t *__restrict__ keep, uint32_t *__restrict__ merge)
-{
+    __syncthreads();
     const uint32_t i = blockIdx.x * PB + threadIdx.x;
-    if (i >= c) return;
-    const uint32_t j = nn[i];
-    const bool mutual = j != i && nn[j] == i;
-    merge[i] = (mutual && i < j) ? 1u : 0u;        // the lower index of a mutual pair creates the node
-    keep[i] = (mutual && i > j) ? 0u : 1u;         // the higher index disappears
+    uint32_t packed = 0;                                // kept | created << 16
+    if (i < c) {
+        const uint32_t j = near[threadIdx.x + R];
+        const bool mutual = j != i && near[(int)j - base - R] == i;
+        const uint32_t mg = (mutual && i < j) ? 1u : 0u;        // the lower index of a mutual pair creates the node
+        const uint32_t kp = (mutual && i > j) ? 0u : 1u;        // the higher index disappears
+        a.nn[i] = j;
+        a.flags[i] = kp | (mg << 1);
+        packed = kp | (mg << 16);
+    }
+    uint32_t block_total;
+    (void)rt_scan::block_exclusive<PB>(packed, lds, block_total);
+    const uint64_t mine = (uint64_t)(block_total & 0xFFFFu) | ((uint64_t)(block_total >> 16) << 32);
+    if (!rt_scan::publish_and_arrive(a.tally, mine, a.arrivals, nblocks, &lds_flag)) return;
+    const uint64_t total = rt_scan::scan_tallies<uint64_t, PB>(a.tally, nblocks, lds64);
+    if (threadIdx.x == 0) {
+        const uint32_t kept = (uint32_t)total, created = (uint32_t)(total >> 32);
+        PlocRound nx = {kept, s.next_node + created, s.cur ^ 1u, 0u};
+        if (created == 0 || kept != c - created) { nx = s; nx.error = 1; }      // no progress: reported by the host
+        a.round[r + 1] = nx;
+        *a.arrivals = 0;
+    }
 }
 
-// a piece of the build's one temporary allocation
-struct View {
-    void *p = nullptr;
-    template <class T> T *as() const { return (T *)p; }
-};
-
-// the arrays one PLOC round reads and writes
-struct PlocArrays {
-    uint32_t *nn, *keep, *merge, *keep_pos, *merge_pos;
-    uint32_t *cl_node[2];
-    Box6 *cl_box[2];
-    uint32_t *left, *right, *size, *parent;
-    Box6 *node_box;
-};
-
-__device__ __forceinline__ void ploc_apply_one(uint32_t i, const uint32_t *nn, const uint32_t *keep, const uint32_t *merge,
-                                               const uint32_t *keep_pos, const uint32_t *merge_pos, uint32_t n, uint32_t next_node,
-                                               const uint32_t *cl_node, const Box6 *cl_box, uint32_t *out_node, Box6 *out_box,
-                                               uint32_t *left, uint32_t *right, Box6 *node_box, uint32_t *size, uint32_t *parent)
+// Second half: every surviving cluster moves to its place in the other cluster array; the lower index of a mutual pair
+// becomes the new node (same arithmetic and numbering as the tail kernel below).
+__global__ void __launch_bounds__(PB) k_ploc_apply(PlocArrays a, uint32_t r, uint32_t n)
 {
-    if (!keep[i]) return;
-    const uint32_t pos = keep_pos[i];
-    if (merge[i]) {
-        const uint32_t j = nn[i];
-        const uint32_t m = next_node + merge_pos[i];
-        const uint32_t a = cl_node[i], b = cl_node[j];
+    __shared__ uint32_t lds[PB / 64];
+    const PlocRound s = a.round[r];
+    if (s.c <= PLOC_TAIL || s.error || a.round[r + 1].error) return;
+    const uint32_t c = s.c;
+    if (blockIdx.x * PB >= c) return;
+    const uint32_t i = blockIdx.x * PB + threadIdx.x;
+    const uint32_t fl = i < c ? a.flags[i] : 0u;
+    uint32_t block_total;
+    const uint32_t before = rt_scan::block_exclusive<PB>((fl & 1u) | ((fl >> 1) << 16), lds, block_total);
+    if (!(fl & 1u)) return;
+    const uint64_t off = a.tally[blockIdx.x];
+    const uint32_t pos = (uint32_t)off + (before & 0xFFFFu);
+    const uint32_t *cl_node = a.cl_node[s.cur];
+    const Box6 *cl_box = a.cl_box[s.cur];
+    uint32_t *out_node = a.cl_node[s.cur ^ 1u];
+    Box6 *out_box = a.cl_box[s.cur ^ 1u];
+    if (fl & 2u) {
+        const uint32_t j = a.nn[i];
+        const uint32_t m = s.next_node + (uint32_t)(off >> 32) + (before >> 16);
+        const uint32_t na = cl_node[i], nb = cl_node[j];
         const Box6 ba = cl_box[i], bb = cl_box[j];
         Box6 u;
         for (int k = 0; k < 3; k++) { u.lo[k] = fminf(ba.lo[k], bb.lo[k]); u.hi[k] = fmaxf(ba.hi[k], bb.hi[k]); }
-        left[m - n] = a;
-        right[m - n] = b;
-        node_box[m] = u;
-        size[m] = size[a] + size[b];
-        parent[a] = m;
-        parent[b] = m;
-        parent[m] = 0xFFFFFFFFu;
+        a.left[m - n] = na;
+        a.right[m - n] = nb;
+        a.node_box[m] = u;
+        a.size[m] = a.size[na] + a.size[nb];
+        a.parent[na] = m;
+        a.parent[nb] = m;
+        a.parent[m] = 0xFFFFFFFFu;
         out_node[pos] = m;
         out_box[pos] = u;
     } else {
@@ -130,86 +185,110 @@ __device__ __forceinline__ void ploc_apply_one(uint32_t i, const uint32_t *nn, c
     }
 }
 
-__global__ void k_ploc_apply(const uint32_t *__restrict__ nn, const uint32_t *__restrict__ keep, const uint32_t *__restrict__ merge,
-                             const uint32_t *__restrict__ keep_pos, const uint32_t *__restrict__ merge_pos, uint32_t c, uint32_t n,
-                             uint32_t next_node, const uint32_t *__restrict__ cl_node, const Box6 *__restrict__ cl_box,
-                             uint32_t *__restrict__ out_node, Box6 *__restrict__ out_box, uint32_t *__restrict__ left,
-                             uint32_t *__restrict__ right, Box6 *__restrict__ node_box, uint32_t *__restrict__ size,
-                             uint32_t *__restrict__ parent)
+// The tail of the clustering: once PLOC_TAIL or fewer clusters are left, ONE workgroup runs all the remaining rounds
+// (nearest neighbour, mutual-pair flags, the two prefix sums, merge) back to back with barriers in between -- the same
+// arithmetic and the same node numbering as the multi-kernel rounds, without ~40 rounds of launches and host round trips
+// for a handful of clusters each.  The cluster array (boxes, node ids) lives in LDS for the whole tail: 4096 x 28 B =
+// 112 KiB of the CU's 160; round 2 kept it in global memory and spent 0.36 ms of a 2.5 ms build on round trips.
+struct TailLds {
+    Box6 box[PLOC_TAIL];
+    uint32_t node[PLOC_TAIL];
+    uint16_t nn[PLOC_TAIL];
+    uint32_t part_keep[TAIL_BLOCK], part_merge[TAIL_BLOCK];
+};
+__global__ void __launch_bounds__(TAIL_BLOCK) k_ploc_tail(PlocArrays a, uint32_t r, uint32_t n, PlocRound *__restrict__ result)
 {
-    const uint32_t i = blockIdx.x * PB + threadIdx.x;
-    if (i >= c) return;
-    ploc_apply_one(i, nn, keep, merge, keep_pos, merge_pos, n, next_node, cl_node, cl_box, out_node, out_box, left, right, node_box, size, parent);
-}
-
-// The tail of the clustering: once PLOC_TAIL or fewer clusters are left, ONE workgroup runs all the
-// remaining rounds (nearest neighbour, mutual-pair flags, the two prefix sums, merge) back to back with
-// barriers in between -- the same arithmetic and the same node numbering as the multi-kernel rounds,
-// without ~40 rounds of launches and host round trips for a handful of clusters each.
-constexpr uint32_t PLOC_TAIL = 4096, TAIL_BLOCK = 1024;
-__global__ void __launch_bounds__(TAIL_BLOCK) k_ploc_tail(PlocArrays a, uint32_t c, uint32_t n, uint32_t next_node, int cur, uint32_t *__restrict__ result)
-{
-    __shared__ uint32_t part_keep[TAIL_BLOCK], part_merge[TAIL_BLOCK];
+    const PlocRound s = a.round[r];
+    if (s.c > PLOC_TAIL || s.error) {                  // the batch of rounds fell short (or failed): the host decides
+        if (threadIdx.x == 0) *result = s;
+        return;
+    }
+    uint32_t c = s.c, next_node = s.next_node;
+    const uint32_t cur = s.cur;
+    extern __shared__ __align__(16) unsigned char tail_smem[];
+    TailLds &L = *reinterpret_cast<TailLds *>(tail_smem);
     constexpr uint32_t PER = PLOC_TAIL / TAIL_BLOCK;
     const uint32_t t = threadIdx.x;
+    for (uint32_t i = t; i < c; i += TAIL_BLOCK) { L.box[i] = a.cl_box[cur][i]; L.node[i] = a.cl_node[cur][i]; }
+    __syncthreads();
     while (c > 1) {
-        const Box6 *box = a.cl_box[cur];
         for (uint32_t i = t; i < c; i += TAIL_BLOCK) {               // nearest neighbour (k_ploc_nn)
-            const Box6 me = box[i];
+            const Box6 me = L.box[i];
             float best = __uint_as_float(0x7f800000u);
             uint32_t arg = i;
             for (int d = -PLOC_RADIUS; d <= PLOC_RADIUS; d++) {
                 const int j = (int)i + d;
                 if (d == 0 || j < 0 || j >= (int)c) continue;
-                const float ar = merged_area(me, box[j]);
+                const float ar = merged_area(me, L.box[j]);
                 if (ar < best) { best = ar; arg = (uint32_t)j; }
             }
-            a.nn[i] = arg;
+            L.nn[i] = (uint16_t)arg;
         }
         __syncthreads();
-        uint32_t k_sum = 0, m_sum = 0;
-        for (uint32_t e = 0; e < PER; e++) {                          // flags (k_ploc_flags), PER consecutive clusters per thread
-            const uint32_t i = t * PER + e;
-            if (i >= c) break;
-            const uint32_t j = a.nn[i];
-            const bool mutual = j != i && a.nn[j] == i;
-            const uint32_t mg = (mutual && i < j) ? 1u : 0u, kp = (mutual && i > j) ? 0u : 1u;
-            a.merge[i] = mg;
-            a.keep[i] = kp;
-            k_sum += kp;
-            m_sum += mg;
-        }
-        part_keep[t] = k_sum;
-        part_merge[t] = m_sum;
-        __syncthreads();
-        for (uint32_t off = 1; off < TAIL_BLOCK; off <<= 1) {         // inclusive scan of the per-thread sums
-            const uint32_t pk = t >= off ? part_keep[t - off] : 0u, pm = t >= off ? part_merge[t - off] : 0u;
-            __syncthreads();
-            part_keep[t] += pk;
-            part_merge[t] += pm;
-            __syncthreads();
-        }
-        uint32_t k_run = part_keep[t] - k_sum, m_run = part_merge[t] - m_sum;      // exclusive prefix of this thread's run
+        // flags (k_ploc_flags), PER consecutive clusters per thread; the thread keeps its flags in registers
+        uint32_t k_sum = 0, m_sum = 0, keep_bits = 0, merge_bits = 0;
         for (uint32_t e = 0; e < PER; e++) {
             const uint32_t i = t * PER + e;
             if (i >= c) break;
-            a.keep_pos[i] = k_run;
-            a.merge_pos[i] = m_run;
-            k_run += a.keep[i];
-            m_run += a.merge[i];
+            const uint32_t j = L.nn[i];
+            const bool mutual = j != i && L.nn[j] == i;
+            const uint32_t mg = (mutual && i < j) ? 1u : 0u, kp = (mutual && i > j) ? 0u : 1u;
+            merge_bits |= mg << e;
+            keep_bits |= kp << e;
+            k_sum += kp;
+            m_sum += mg;
         }
-        const uint32_t kept = part_keep[TAIL_BLOCK - 1], merged = part_merge[TAIL_BLOCK - 1];
+        L.part_keep[t] = k_sum;
+        L.part_merge[t] = m_sum;
         __syncthreads();
-        if (merged == 0 || kept != c - merged) break;                 // no progress: reported by the host
-        for (uint32_t i = t; i < c; i += TAIL_BLOCK)
-            ploc_apply_one(i, a.nn, a.keep, a.merge, a.keep_pos, a.merge_pos, n, next_node, a.cl_node[cur], a.cl_box[cur], a.cl_node[cur ^ 1],
-                           a.cl_box[cur ^ 1], a.left, a.right, a.node_box, a.size, a.parent);
+        for (uint32_t off = 1; off < TAIL_BLOCK; off <<= 1) {         // inclusive scan of the per-thread sums
+            const uint32_t pk = t >= off ? L.part_keep[t - off] : 0u, pm = t >= off ? L.part_merge[t - off] : 0u;
+            __syncthreads();
+            L.part_keep[t] += pk;
+            L.part_merge[t] += pm;
+            __syncthreads();
+        }
+        uint32_t k_run = L.part_keep[t] - k_sum, m_run = L.part_merge[t] - m_sum;      // exclusive prefix of this thread's run
+        const uint32_t kept = L.part_keep[TAIL_BLOCK - 1], merged = L.part_merge[TAIL_BLOCK - 1];
+        if (merged == 0 || kept != c - merged) break;                 // no progress: reported by the host (block-uniform)
+        // what this thread's clusters become (ploc_apply_one), computed into registers before anybody overwrites the array
+        Box6 out_box[PER];
+        uint32_t out_node[PER], out_pos[PER];
+        for (uint32_t e = 0; e < PER; e++) {
+            const uint32_t i = t * PER + e;
+            out_pos[e] = 0xFFFFFFFFu;
+            if (i >= c || !((keep_bits >> e) & 1u)) continue;
+            out_pos[e] = k_run;
+            if ((merge_bits >> e) & 1u) {
+                const uint32_t j = L.nn[i], m = next_node + m_run;
+                const uint32_t na = L.node[i], nb = L.node[j];
+                const Box6 ba = L.box[i], bb = L.box[j];
+                Box6 u;
+                for (int k = 0; k < 3; k++) { u.lo[k] = fminf(ba.lo[k], bb.lo[k]); u.hi[k] = fmaxf(ba.hi[k], bb.hi[k]); }
+                a.left[m - n] = na;
+                a.right[m - n] = nb;
+                a.node_box[m] = u;
+                a.size[m] = a.size[na] + a.size[nb];
+                a.parent[na] = m;
+                a.parent[nb] = m;
+                a.parent[m] = 0xFFFFFFFFu;
+                out_node[e] = m;
+                out_box[e] = u;
+                m_run++;
+            } else {
+                out_node[e] = L.node[i];
+                out_box[e] = L.box[i];
+            }
+            k_run++;
+        }
+        __syncthreads();
+        for (uint32_t e = 0; e < PER; e++)
+            if (out_pos[e] != 0xFFFFFFFFu) { L.box[out_pos[e]] = out_box[e]; L.node[out_pos[e]] = out_node[e]; }
         __syncthreads();
         c = kept;
         next_node += merged;
-        cur ^= 1;
     }
-    if (t == 0) { result[0] = c; result[1] = next_node; }
+    if (t == 0) { const PlocRound out = {c, next_node, cur, 0u}; *result = out; }
 }
 
 // leaf boxes into node_box[0..n-1] so every node id indexes one box array
@@ -258,7 +337,8 @@ inline unsigned gr(size_t n) { return (unsigned)((n + PB - 1) / PB); }
 size_t rt_ploc_temp_bytes(uint32_t n)
 {
     const size_t nn2 = 2 * (size_t)n;
-    return 8 * (size_t)n + 2 * sizeof(Box6) * (size_t)n + 20 * ((size_t)n + 1) + 8 * (size_t)n + sizeof(Box6) * nn2 + 12 * nn2 + ((size_t)1 << 20) + 18 * 256;
+    return 8 * (size_t)n + 2 * sizeof(Box6) * (size_t)n + 8 * (size_t)n + 8 * ((size_t)n / PB + 1) + 8 * (size_t)n + sizeof(Box6) * nn2 + 12 * nn2 +
+           sizeof(PlocRound) * (PLOC_MAX_BATCH + 2) + 16 + 16 * 256;
 }
 
 // Rebuilds m->tris and m->blas.wide / root_code / fast_depth from a PLOC tree.  The canonical arrays
@@ -271,83 +351,73 @@ int rt_build_ploc_layout(rt_context *ctx, rt_model *m, bool *done)
     hipStream_t st = ctx->stream;
     // every temporary of the build is carved out of ONE allocation (hipMalloc / hipFree synchronise the
     // device and cost more than the kernels of a small build)
-    View cl_node[2], cl_box[2], nn, keep, merge, keep_pos, merge_pos, left, right, node_box, size, parent, offset, scan_tmp, depth;
+    View cl_node[2], cl_box[2], nn, flags, tally, left, right, node_box, size, parent, offset, state;
     int rc = RT_OK;
     do {
         const size_t nn2 = 2 * (size_t)n - 1;
-        size_t tmp_bytes = 0;
-        if (rocprim::exclusive_scan(nullptr, tmp_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st) != hipSuccess) {
-            rt_set_error("rocprim::exclusive_scan sizing failed");
-            rc = RT_ERR_HIP;
-            break;
-        }
         struct Want { View *v; size_t bytes; };
         const Want wants[] = {{&cl_node[0], 4 * (size_t)n}, {&cl_node[1], 4 * (size_t)n}, {&cl_box[0], sizeof(Box6) * (size_t)n}, {&cl_box[1], sizeof(Box6) * (size_t)n},
-                              {&nn, 4 * ((size_t)n + 1)}, {&keep, 4 * ((size_t)n + 1)}, {&merge, 4 * ((size_t)n + 1)}, {&keep_pos, 4 * ((size_t)n + 1)},
-                              {&merge_pos, 4 * ((size_t)n + 1)}, {&left, 4 * (size_t)(n - 1)}, {&right, 4 * (size_t)(n - 1)}, {&node_box, sizeof(Box6) * nn2},
-                              {&size, 4 * nn2}, {&parent, 4 * nn2}, {&offset, 4 * nn2}, {&scan_tmp, tmp_bytes}, {&depth, 8}};
+                              {&nn, 4 * (size_t)n}, {&flags, 4 * (size_t)n}, {&tally, 8 * (size_t)gr(n)}, {&left, 4 * (size_t)(n - 1)}, {&right, 4 * (size_t)(n - 1)},
+                              {&node_box, sizeof(Box6) * nn2}, {&size, 4 * nn2}, {&parent, 4 * nn2}, {&offset, 4 * nn2},
+                              {&state, sizeof(PlocRound) * (PLOC_MAX_BATCH + 2) + 16}};
         size_t total = 0;
         for (const Want &w : wants) total += (w.bytes + 255) & ~(size_t)255;
         if ((rc = ctx->build_arena.reserve(total)) != RT_OK) break;      // normally already there (rt_ploc_temp_bytes)
         size_t at = 0;
         for (const Want &w : wants) { w.v->p = (char *)ctx->build_arena.p + at; at += (w.bytes + 255) & ~(size_t)255; }
 
+        PlocArrays pa;
+        pa.nn = nn.as<uint32_t>(); pa.flags = flags.as<uint32_t>(); pa.tally = tally.as<uint64_t>();
+        pa.round = state.as<PlocRound>();
+        PlocRound *d_result = pa.round + PLOC_MAX_BATCH + 1;
+        pa.arrivals = (uint32_t *)(d_result + 1);
+        for (int k = 0; k < 2; k++) { pa.cl_node[k] = cl_node[k].as<uint32_t>(); pa.cl_box[k] = cl_box[k].as<Box6>(); }
+        pa.left = left.as<uint32_t>(); pa.right = right.as<uint32_t>(); pa.size = size.as<uint32_t>(); pa.parent = parent.as<uint32_t>();
+        pa.node_box = node_box.as<Box6>();
+        // 136 KiB of dynamic LDS: above the default 64 KiB limit of a launch (the attribute is per device, set every build)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ploc_tail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TailLds)) != hipSuccess) {
+            rt_set_error("PLOC tail: cannot reserve %zu bytes of LDS", sizeof(TailLds));
+            rc = RT_ERR_HIP;
+            break;
+        }
+
         k_ploc_init<<<gr(n), PB, 0, st>>>(m->blas.nodes.as<rt_bvh_node>(), n, cl_node[0].as<uint32_t>(), cl_box[0].as<Box6>(),
-                                         size.as<uint32_t>(), parent.as<uint32_t>());
+                                         size.as<uint32_t>(), parent.as<uint32_t>(), pa.round, pa.arrivals);
         k_ploc_leaf_boxes<<<gr(n), PB, 0, st>>>(cl_box[0].as<Box6>(), n, node_box.as<Box6>());
-        uint32_t c = n, next_node = n;
-        int cur = 0;
-        for (int round = 0; c > PLOC_TAIL && round < 4096; round++) {
-            k_ploc_nn<<<gr(c), PB, 0, st>>>(cl_box[cur].as<Box6>(), c, nn.as<uint32_t>());
-            k_ploc_flags<<<gr(c), PB, 0, st>>>(nn.as<uint32_t>(), c, keep.as<uint32_t>(), merge.as<uint32_t>());
-            // scans run over c+1 elements so that element c holds the totals (its input flag is garbage-free: set to 0)
-            (void)hipMemsetAsync(keep.as<uint32_t>() + c, 0, 4, st);
-            (void)hipMemsetAsync(merge.as<uint32_t>() + c, 0, 4, st);
-            size_t tb = tmp_bytes;
-            (void)rocprim::exclusive_scan(scan_tmp.p, tb, keep.as<uint32_t>(), keep_pos.as<uint32_t>(), 0u, (size_t)c + 1, rocprim::plus<uint32_t>(), st);
-            tb = tmp_bytes;
-            (void)rocprim::exclusive_scan(scan_tmp.p, tb, merge.as<uint32_t>(), merge_pos.as<uint32_t>(), 0u, (size_t)c + 1, rocprim::plus<uint32_t>(), st);
-            k_ploc_apply<<<gr(c), PB, 0, st>>>(nn.as<uint32_t>(), keep.as<uint32_t>(), merge.as<uint32_t>(), keep_pos.as<uint32_t>(),
-                                              merge_pos.as<uint32_t>(), c, n, next_node, cl_node[cur].as<uint32_t>(), cl_box[cur].as<Box6>(),
-                                              cl_node[cur ^ 1].as<uint32_t>(), cl_box[cur ^ 1].as<Box6>(), left.as<uint32_t>(),
-                                              right.as<uint32_t>(), node_box.as<Box6>(), size.as<uint32_t>(), parent.as<uint32_t>());
-            uint32_t stack_totals[2];
-            uint32_t *totals = ctx->pinned ? ctx->pinned : stack_totals;      // page-locked: no staging copy
-            if (hipMemcpyAsync(&totals[0], keep_pos.as<uint32_t>() + c, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipMemcpyAsync(&totals[1], merge_pos.as<uint32_t>() + c, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess) {
-                rt_set_error("PLOC round %d failed: %s", round, hipGetErrorString(hipGetLastError()));
+        // Rounds are launched in batches without looking at the cluster count: every launch covers the count the batch
+        // started with (workgroups past the live count leave at once), a round past the tail threshold costs two empty
+        // launches, and the tail kernel closes the batch.  A round keeps ~0.76 of its clusters on the scenes measured;
+        // the estimate below assumes 0.78 and a batch that falls short is simply followed by another.
+        PlocRound res = {n, n, 0u, 0u};
+        for (int batchno = 0; batchno < 4096; batchno++) {
+            uint32_t rounds = 0;
+            for (double x = (double)res.c; x > (double)PLOC_TAIL && rounds < PLOC_MAX_BATCH; x *= 0.78) rounds++;
+            if (rounds > 0 && rounds < PLOC_MAX_BATCH) rounds++;
+            for (uint32_t r = 0; r < rounds; r++) {
+                k_ploc_pair<<<gr(res.c), PB, 0, st>>>(pa, r);
+                k_ploc_apply<<<gr(res.c), PB, 0, st>>>(pa, r, n);
+            }
+            k_ploc_tail<<<1, TAIL_BLOCK, sizeof(TailLds), st>>>(pa, rounds, n, d_result);
+            PlocRound *host = ctx->pinned ? (PlocRound *)ctx->pinned : &res;      // page-locked: no staging copy
+            if (hipMemcpyAsync(host, d_result, sizeof(PlocRound), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
+                hipGetLastError() != hipSuccess) {
+                rt_set_error("PLOC rounds failed: %s", hipGetErrorString(hipGetLastError()));
                 rc = RT_ERR_HIP;
                 break;
             }
-            if (totals[1] == 0 || totals[0] != c - totals[1]) {
-                rt_set_error("PLOC round %d made no progress (%u clusters, %u merges)", round, c, totals[1]);
+            const uint32_t before = res.c;
+            res = *host;
+            if (res.error || (res.c > PLOC_TAIL && res.c >= before)) {
+                rt_set_error("PLOC made no progress (%u clusters)", res.c);
                 rc = RT_ERR_STATE;
                 break;
             }
-            c = totals[0];
-            next_node += totals[1];
-            cur ^= 1;
+            if (res.c <= PLOC_TAIL) break;
+            // short of the tail: the next batch starts from where this one stopped
+            if (hipMemcpyAsync(pa.round, d_result, sizeof(PlocRound), hipMemcpyDeviceToDevice, st) != hipSuccess) { rt_set_error("PLOC: state copy failed"); rc = RT_ERR_HIP; break; }
         }
         if (rc != RT_OK) break;
-        if (c > 1) {
-            PlocArrays pa;
-            pa.nn = nn.as<uint32_t>(); pa.keep = keep.as<uint32_t>(); pa.merge = merge.as<uint32_t>();
-            pa.keep_pos = keep_pos.as<uint32_t>(); pa.merge_pos = merge_pos.as<uint32_t>();
-            for (int k = 0; k < 2; k++) { pa.cl_node[k] = cl_node[k].as<uint32_t>(); pa.cl_box[k] = cl_box[k].as<Box6>(); }
-            pa.left = left.as<uint32_t>(); pa.right = right.as<uint32_t>(); pa.size = size.as<uint32_t>(); pa.parent = parent.as<uint32_t>();
-            pa.node_box = node_box.as<Box6>();
-            uint32_t *d_res = depth.as<uint32_t>();              // (two words: reserved below)
-            k_ploc_tail<<<1, TAIL_BLOCK, 0, st>>>(pa, c, n, next_node, cur, d_res);
-            uint32_t res[2] = {0, 0};
-            if (hipMemcpyAsync(res, d_res, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-                rt_set_error("PLOC tail failed: %s", hipGetErrorString(hipGetLastError()));
-                rc = RT_ERR_HIP;
-                break;
-            }
-            c = res[0];
-            next_node = res[1];
-        }
+        const uint32_t c = res.c, next_node = res.next_node;
         if (c != 1 || next_node != 2 * n - 1) {
             rt_set_error("PLOC did not converge (%u clusters, %u nodes)", c, next_node);
             rc = RT_ERR_STATE;

@@ -8,7 +8,7 @@
 // child boxes are quantised to one byte per plane on a power-of-two grid anchored at the node's own box, which fits
 // origin, scales, 24 plane bytes and four child codes in 64 B and halves the lines per ray.
 //
-// Collapse: breadth first, one round per level.  A frontier element is a binary node that becomes a wide node: its two
+// Collapse: breadth first, two launches per level and no host round trip inside a batch of levels (rt_level_scan.h).  A frontier element is a binary node that becomes a wide node: its two
 // children are taken, and while fewer than four, the child with the largest surface that is not a leaf is replaced by
 // its own two children (surface-area greedy, as in Wald et al. 2008 / Ylitie et al. 2017).  Node numbers come from
 // prefix sums (deterministic), level after level, so the array is in breadth-first order and its first RT_TOP_NODES
@@ -20,13 +20,16 @@
 // candidate the canonical definition accepts.
 #include "rt_internal.h"
 
+#include "rt_level_scan.h"
+
+#include <cstddef>
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 namespace {
 
 constexpr unsigned WB = 256;
 constexpr uint32_t NO_KID = 0xFFFFFFFFu;
+constexpr uint32_t RT_WIDE_MAX_LEVELS = 254;            // of wide nodes; a collapsed level spans one to two binary levels
 
 struct Box6 { float lo[3]; float hi[3]; };
 
@@ -49,41 +52,80 @@ struct TreeView {
     }
 };
 
-// one frontier element -> its (up to four) children, largest surface first, and how many of them are wide nodes themselves
-__global__ void __launch_bounds__(WB) k_wide_expand(TreeView t, const uint32_t *__restrict__ frontier, uint32_t count,
-                                                    uint32_t *__restrict__ kids, uint32_t *__restrict__ n_internal)
+// what the levels of one collapse share in device memory
+struct WideLevel { uint32_t count, base; };                 // frontier size, index of its first wide node
+struct WideState {
+    uint32_t arrivals, error;
+    WideLevel level[RT_WIDE_MAX_LEVELS + 2];
+};
+
+__global__ void k_wide_init(WideState *__restrict__ ws, uint32_t *__restrict__ frontier0, uint32_t root)
 {
+    ws->level[0].count = 1;
+    ws->level[0].base = 0;
+    ws->arrivals = 0;
+    ws->error = 0;
+    frontier0[0] = root;
+}
+
+// one frontier element -> its (up to four) children, largest surface first; the workgroups' tallies of children that are
+// wide nodes themselves become the offsets of the next frontier, and the last workgroup writes the next level's size
+__global__ void __launch_bounds__(WB) k_wide_expand(TreeView t, const uint32_t *__restrict__ frontier, WideState *__restrict__ ws, uint32_t lvl,
+                                                    uint32_t *__restrict__ kids, uint32_t *__restrict__ tally, uint32_t fcap)
+{
+    __shared__ uint32_t lds[WB];
+    __shared__ uint32_t lds_flag;
+    const WideLevel L = ws->level[lvl];
+    if (L.count == 0) {                                 // past the last level of this tree: hand the end on
+        if (blockIdx.x == 0 && threadIdx.x == 0) ws->level[lvl + 1] = L;
+        return;
+    }
+    const uint32_t nblocks = (L.count + WB - 1) / WB;
+    if (blockIdx.x >= nblocks) return;
     const uint32_t f = blockIdx.x * WB + threadIdx.x;
-    if (f >= count) return;
-    const uint32_t b = frontier[f];
-    uint32_t kid[4] = {t.left[b - t.n], t.right[b - t.n], NO_KID, NO_KID};
-    int nk = 2;
-    while (nk < 4) {
-        int best = -1;
-        float best_area = -1.0f;
-        for (int k = 0; k < nk; k++) {
-            if (t.is_leaf(kid[k])) continue;
-            const float a = box_area(t.box[kid[k]]);
-            if (a > best_area || best < 0) { best = k; best_area = a; }
-        }
-        if (best < 0) break;
-        const uint32_t id = kid[best];
-        kid[best] = t.left[id - t.n];
-        kid[nk++] = t.right[id - t.n];
-    }
-    float ar[4];
-    for (int k = 0; k < nk; k++) ar[k] = box_area(t.box[kid[k]]);
-    for (int i = 1; i < nk; i++)                       // insertion sort, larger surface first, stable
-        for (int j = i; j > 0 && ar[j] > ar[j - 1]; j--) {
-            const float ta = ar[j]; ar[j] = ar[j - 1]; ar[j - 1] = ta;
-            const uint32_t tk = kid[j]; kid[j] = kid[j - 1]; kid[j - 1] = tk;
-        }
     uint32_t cnt = 0;
-    for (int k = 0; k < 4; k++) {
-        kids[4 * (size_t)f + k] = k < nk ? kid[k] : NO_KID;
-        if (k < nk && !t.is_leaf(kid[k])) cnt++;
+    if (f < L.count) {
+        const uint32_t b = frontier[f];
+        uint32_t kid[4] = {t.left[b - t.n], t.right[b - t.n], NO_KID, NO_KID};
+        int nk = 2;
+        while (nk < 4) {
+            int best = -1;
+            float best_area = -1.0f;
+            for (int k = 0; k < nk; k++) {
+                if (t.is_leaf(kid[k])) continue;
+                const float a = box_area(t.box[kid[k]]);
+                if (a > best_area || best < 0) { best = k; best_area = a; }
+            }
+            if (best < 0) break;
+            const uint32_t id = kid[best];
+            kid[best] = t.left[id - t.n];
+            kid[nk++] = t.right[id - t.n];
+        }
+        float ar[4];
+        for (int k = 0; k < nk; k++) ar[k] = box_area(t.box[kid[k]]);
+        for (int i = 1; i < nk; i++)                       // insertion sort, larger surface first, stable
+            for (int j = i; j > 0 && ar[j] > ar[j - 1]; j--) {
+                const float ta = ar[j]; ar[j] = ar[j - 1]; ar[j - 1] = ta;
+                const uint32_t tk = kid[j]; kid[j] = kid[j - 1]; kid[j - 1] = tk;
+            }
+        for (int k = 0; k < 4; k++) {
+            kids[4 * (size_t)f + k] = k < nk ? kid[k] : NO_KID;
+            if (k < nk && !t.is_leaf(kid[k])) cnt++;
+        }
     }
-    n_internal[f] = cnt;
+    uint32_t block_total;
+    (void)rt_scan::block_exclusive<WB>(cnt, lds, block_total);
+    if (!rt_scan::publish_and_arrive(tally, block_total, &ws->arrivals, nblocks, &lds_flag)) return;
+    const uint32_t total = rt_scan::scan_tallies<uint32_t, WB>(tally, nblocks, lds);
+    if (threadIdx.x == 0) {
+        WideLevel nx = {total, L.base + L.count};
+        if (lvl + 1 > RT_WIDE_MAX_LEVELS || total > fcap || (size_t)nx.base + total > (size_t)t.n - 1) {
+            ws->error = 1 + lvl;                        // the host reports it
+            nx.count = 0;
+        }
+        ws->level[lvl + 1] = nx;
+        ws->arrivals = 0;
+    }
 }
 
 // quantises the planes of one axis of up to four boxes onto origin + q * scale; returns false if 255 steps do not reach
@@ -109,25 +151,36 @@ __device__ bool quantise_axis(const Box6 *cb, int nk, int axis, float origin, fl
     return ok;
 }
 
-__global__ void __launch_bounds__(WB) k_wide_emit(TreeView t, const uint32_t *__restrict__ frontier, uint32_t count, uint32_t base,
-                                                  const uint32_t *__restrict__ kids, const uint32_t *__restrict__ pos,
+__global__ void __launch_bounds__(WB) k_wide_emit(TreeView t, const uint32_t *__restrict__ frontier, const WideState *__restrict__ ws, uint32_t lvl,
+                                                  const uint32_t *__restrict__ kids, const uint32_t *__restrict__ tally,
                                                   uint32_t *__restrict__ next_frontier, WNode *__restrict__ out)
 {
+    __shared__ uint32_t lds[WB / 64];
+    const WideLevel L = ws->level[lvl];
+    const uint32_t count = L.count, base = L.base;
+    if (blockIdx.x * WB >= count) return;
     const uint32_t f = blockIdx.x * WB + threadIdx.x;
+    uint32_t kid[4] = {NO_KID, NO_KID, NO_KID, NO_KID}, internal = 0, mine = 0;
+    if (f < count)
+        for (int k = 0; k < 4; k++) {
+            kid[k] = kids[4 * (size_t)f + k];
+            if (kid[k] != NO_KID && !t.is_leaf(kid[k])) { internal |= 1u << k; mine++; }
+        }
+    uint32_t block_total;
+    uint32_t next = tally[blockIdx.x] + rt_scan::block_exclusive<WB>(mine, lds, block_total);
     if (f >= count) return;
     const uint32_t b = frontier[f];
     const Box6 nb = t.box[b];
     Box6 cb[4];
     int code[4];
     int nk = 0;
-    uint32_t next = pos[f];
     for (int k = 0; k < 4; k++) {
-        const uint32_t id = kids[4 * (size_t)f + k];
+        const uint32_t id = kid[k];
         code[k] = RT_NODE_NONE;
         if (id == NO_KID) continue;
         nk = k + 1;                                     // (kids are packed at the front)
         cb[k] = t.box[id];
-        if (t.is_leaf(id)) code[k] = t.leaf_code(id);
+        if (!((internal >> k) & 1u)) code[k] = t.leaf_code(id);
         else {
             next_frontier[next] = id;
             code[k] = (int)(base + count + next);       // the next level starts right behind this one
@@ -188,11 +241,11 @@ inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace
 
-// two frontiers, the children of a frontier, counts and their prefix sums, scan scratch
+// two frontiers, the children of a frontier, one tally per workgroup of a level, the level table
 size_t rt_wide_temp_bytes(uint32_t n)
 {
     const size_t f = (size_t)n / 2 + 2;
-    return 2 * up256(4 * f) + up256(16 * f) + 2 * up256(4 * (f + 1)) + ((size_t)1 << 20);
+    return 2 * up256(4 * f) + up256(16 * f) + up256(4 * (size_t)gr(f)) + up256(sizeof(WideState));
 }
 
 int rt_build_wide_layout(rt_context *ctx, BvhDev &bv, uint32_t n, uint32_t root, const uint32_t *left, const uint32_t *right,
@@ -212,49 +265,54 @@ int rt_build_wide_layout(rt_context *ctx, BvhDev &bv, uint32_t n, uint32_t root,
         return RT_OK;
     }
     const size_t fcap = (size_t)n / 2 + 2;
-    size_t scan_bytes = 0;
-    if (rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, fcap + 1, rocprim::plus<uint32_t>(), st) != hipSuccess) {
-        rt_set_error("rocprim::exclusive_scan sizing failed");
-        return RT_ERR_HIP;
-    }
-    const size_t need = 2 * up256(4 * fcap) + up256(16 * fcap) + 2 * up256(4 * (fcap + 1)) + up256(scan_bytes);
+    const size_t need = rt_wide_temp_bytes(n);
     DevBuf own;                        // only if the caller's slice is too small
     char *p = (char *)tmp;
     if (need > tmp_bytes) { RT_TRY(own.reserve(need)); p = (char *)own.p; }
     uint32_t *frontier[2] = {(uint32_t *)p, (uint32_t *)(p + up256(4 * fcap))};
     p += 2 * up256(4 * fcap);
     uint32_t *kids = (uint32_t *)p; p += up256(16 * fcap);
-    uint32_t *cnt = (uint32_t *)p; p += up256(4 * (fcap + 1));
-    uint32_t *pos = (uint32_t *)p; p += up256(4 * (fcap + 1));
-    void *scan_tmp = p;
+    uint32_t *tally = (uint32_t *)p; p += up256(4 * (size_t)gr(fcap));
+    WideState *ws = (WideState *)p;
     int rc = RT_OK;
     do {
         if ((rc = bv.wide.reserve(sizeof(WNode) * (size_t)(n - 1))) != RT_OK) break;
-        if (hipMemcpyAsync(frontier[0], &root, 4, hipMemcpyHostToDevice, st) != hipSuccess) { rt_set_error("wide layout: upload failed"); rc = RT_ERR_HIP; break; }
-        uint32_t count = 1, base = 0, levels = 0;
-        int cur = 0;
-        while (count > 0) {
-            if ((size_t)count > fcap || (size_t)base + count > (size_t)n - 1) { rt_set_error("wide layout: frontier of %u nodes at level %u does not fit", count, levels); rc = RT_ERR_STATE; break; }
-            k_wide_expand<<<gr(count), WB, 0, st>>>(t, frontier[cur], count, kids, cnt);
-            (void)hipMemsetAsync(cnt + count, 0, 4, st);
-            size_t sb = scan_bytes;
-            (void)rocprim::exclusive_scan(scan_tmp, sb, cnt, pos, 0u, (size_t)count + 1, rocprim::plus<uint32_t>(), st);
-            k_wide_emit<<<gr(count), WB, 0, st>>>(t, frontier[cur], count, base, kids, pos, frontier[cur ^ 1], bv.wide.as<WNode>());
-            uint32_t stack_total = 0;
-            uint32_t *total = ctx->pinned ? ctx->pinned : &stack_total;
-            if (hipMemcpyAsync(total, pos + count, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
+        k_wide_init<<<1, 1, 0, st>>>(ws, frontier[0], root);
+        // Levels are launched in batches without looking at their sizes: a level has at most four times the nodes of the
+        // one before (and never more than fcap), a level past the end of the tree costs two empty launches.  The first
+        // batch is sized for a tree half again as deep as a balanced one; the host reads the level table after each batch.
+        uint32_t lvl = 0, levels = 0, wide_n = 0;
+        uint64_t bound = 1;                                   // upper bound of the frontier at level lvl
+        uint32_t batch = 6;
+        for (uint32_t m = n; m > 1; m >>= 2) batch++;
+        WideState host_state;
+        bool done = false;
+        while (!done) {
+            const uint32_t end = lvl + batch < RT_WIDE_MAX_LEVELS + 1 ? lvl + batch : RT_WIDE_MAX_LEVELS + 1;
+            for (; lvl < end; lvl++) {
+                const unsigned blocks = gr((size_t)(bound < fcap ? bound : fcap));
+                k_wide_expand<<<blocks, WB, 0, st>>>(t, frontier[lvl & 1], ws, lvl, kids, tally, (uint32_t)fcap);
+                k_wide_emit<<<blocks, WB, 0, st>>>(t, frontier[lvl & 1], ws, lvl, kids, tally, frontier[(lvl & 1) ^ 1], bv.wide.as<WNode>());
+                bound = bound < fcap ? bound * 4 : fcap;
+            }
+            const size_t bytes = offsetof(WideState, level) + sizeof(WideLevel) * (lvl + 1);
+            WideState *back = (ctx->pinned && bytes <= 64 * sizeof(uint32_t)) ? (WideState *)ctx->pinned : &host_state;      // page-locked: no staging copy
+            if (hipMemcpyAsync(back, ws, bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
                 hipGetLastError() != hipSuccess) {
-                rt_set_error("wide layout level %u failed: %s", levels, hipGetErrorString(hipGetLastError()));
+                rt_set_error("wide layout failed: %s", hipGetErrorString(hipGetLastError()));
                 rc = RT_ERR_HIP;
                 break;
             }
-            base += count;
-            count = *total;
-            cur ^= 1;
-            levels++;
+            const WideLevel *table = back->level;
+            if (back->error) { rt_set_error("wide layout: the frontier of level %u does not fit (%u primitives)", back->error, n); rc = RT_ERR_STATE; break; }
+            for (uint32_t l = 0; l <= lvl; l++)
+                if (table[l].count == 0) { levels = l; wide_n = table[l].base; done = true; break; }
+            if (!done && lvl >= RT_WIDE_MAX_LEVELS + 1) { rt_set_error("wide layout: deeper than %u levels", RT_WIDE_MAX_LEVELS); rc = RT_ERR_STATE; break; }
+            bound = table[lvl].count;
+            batch = 8;
         }
         if (rc != RT_OK) break;
-        bv.wide_n = base;
+        bv.wide_n = wide_n;
         bv.root_code = 0;
         bv.fast_depth = 3 * levels;        // a step leaves at most three siblings behind
     } while (0);
