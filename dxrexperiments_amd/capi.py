@@ -80,6 +80,8 @@ SIGNATURES = {
     "rt_scene_bvh_info": (_i, [_p, _i, _pu, _pu, _pu]),
     "rt_scene_bvh_read": (_i, [_p, _i, _p, _p, _p]),
     "rt_scene_instance_info": (_i, [_p, _u32, _p, _p]),
+    "rt_scene_wide_info": (_i, [_p, _i, _pu, C.POINTER(C.c_int32), _pu]),
+    "rt_scene_wide_read": (_i, [_p, _i, _p, _p]),
     "rt_scene_build_ms": (_i, [_p, C.POINTER(_f)]),
     "rt_trace_batch": (_i, [_p, _p, _p, _p, _sz, _u32, _u32, _u32, _p, _p, _p, _p, _p, _p, _p]),
     "rt_trace_last_ms": (_i, [_p, C.POINTER(_f)]),
@@ -350,6 +352,16 @@ class Scene:
         parents = np.empty(nn.value, np.uint32)
         _check(lib().rt_scene_bvh_read(self.h, which, _ptr(nodes), _ptr(keys), _ptr(parents)))
         return nodes, keys, parents, md.value
+
+    def wide_read(self, which=0):
+        """The production traversal layout: (nodes uint32[n, 16] (64-B four-wide nodes, raw words), root_code,
+        records float32[m, 12] (BLAS triangle records; empty for the TLAS))."""
+        n, root, m = C.c_uint32(), C.c_int32(), C.c_uint32()
+        _check(lib().rt_scene_wide_info(self.h, which, C.byref(n), C.byref(root), C.byref(m)))
+        nodes = np.empty((n.value, 16), np.uint32)
+        recs = np.empty((m.value, 12), np.float32)
+        _check(lib().rt_scene_wide_read(self.h, which, _ptr(nodes), _ptr(recs)))
+        return nodes, root.value, recs
 
     def instance_info(self, i):
         box = np.empty(6, np.float32)

@@ -124,7 +124,7 @@ static int context_create(int device, void *stream, bool own, rt_context **out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         c->cu_count = (uint32_t)prop.multiProcessorCount;
-    if (hipHostMalloc((void **)&c->pinned, 64 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) c->pinned = nullptr;
+    if (hipHostMalloc((void **)&c->pinned, RT_PINNED_WORDS * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) c->pinned = nullptr;
     const char *lt = getenv("RT_LDS_TOP");
     if (lt && atoi(lt) == 0) c->lds_top = false;
     const char *sr = getenv("RT_LDS_STACK_ROWS");
@@ -430,6 +430,26 @@ int rt_scene_bvh_read(const rt_scene *s, int which, rt_bvh_node *nodes, uint64_t
     if (nodes) HIP_TRY(hipMemcpy(nodes, b->nodes.p, sizeof(rt_bvh_node) * nn, hipMemcpyDeviceToHost));
     if (sorted_keys) HIP_TRY(hipMemcpy(sorted_keys, b->keys.p, sizeof(uint64_t) * b->n, hipMemcpyDeviceToHost));
     if (parents) HIP_TRY(hipMemcpy(parents, b->parents.p, sizeof(uint32_t) * nn, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_scene_wide_info(const rt_scene *s, int which, uint32_t *n_nodes, int32_t *root_code, uint32_t *n_records)
+{
+    const BvhDev *b = pick_bvh(s, which);
+    if (!b) { rt_set_error("rt_scene_wide_info: scene not built or index out of range"); return RT_ERR_STATE; }
+    if (n_nodes) *n_nodes = b->wide_n;
+    if (root_code) *root_code = b->root_code;
+    if (n_records) *n_records = which < 0 ? 0u : b->n;
+    return RT_OK;
+}
+
+int rt_scene_wide_read(const rt_scene *s, int which, void *nodes, void *records)
+{
+    const BvhDev *b = pick_bvh(s, which);
+    if (!b) { rt_set_error("rt_scene_wide_read: scene not built or index out of range"); return RT_ERR_STATE; }
+    RT_TRY(use_device(s->ctx));
+    if (nodes && b->wide_n) HIP_TRY(hipMemcpy(nodes, b->wide.p, sizeof(WNode) * (size_t)b->wide_n, hipMemcpyDeviceToHost));
+    if (records && which >= 0) HIP_TRY(hipMemcpy(records, s->inst[which].model->tris.p, sizeof(TriRec) * (size_t)b->n, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -205,12 +205,14 @@ __global__ void k_karras(const uint64_t *__restrict__ keys, int n, rt_bvh_node *
 
 // Bottom-up union, every internal node visited ONCE (Karras 2012): a thread starts at its leaf and climbs; at a parent the
 // first arriver stops, the second unites the two child boxes and goes on.  The per-XCD L2s of this chip are not coherent
-// with each other, so everything two threads exchange goes through device-scope atomics, which execute at the memory side:
-// a thread publishes its node's box and depth with returning atomic exchanges (returned = performed), only then bumps the
-// parent's arrival counter, and the second arriver -- ordered behind the first by that counter -- reads the sibling with
-// atomic reads.  ~14 atomics per node; round 1's min/max climb issued ~180 per leaf (0.27 ms and 189 MB of atomic writes
-// for 262 k triangles).  min / max are exact and order independent, so the boxes are those of the oracle bit for bit.
-// scratch per node: 6 box words + depth + arrival counter = 8 words, zero-initialised.
+// with each other, so everything two threads exchange is stored and loaded at AGENT scope (write-through / read-through
+// past the local L2): a thread publishes its node's box and depth with four 64-bit stores, waits until they are
+// acknowledged, only then bumps the parent's arrival counter (a device-scope atomic, executed at the memory side), and the
+// second arriver -- ordered behind the first by that counter -- reads the sibling with four agent-scope loads.  One
+// read-modify-write per node; the first round-2 version exchanged every word with one (14 per node, 0.15 ms for 262 k
+// triangles), round 1's min/max climb issued ~180 per leaf.  min / max are exact and order independent, so the boxes are
+// those of the oracle bit for bit.
+// scratch per node: 6 box words + depth + arrival counter = 8 words (four 64-bit pairs), zero-initialised.
 __global__ void k_refit(const rt_bvh_node *__restrict__ nodes, const uint32_t *__restrict__ parents, uint32_t n,
                         uint32_t *__restrict__ scratch, uint32_t *__restrict__ max_depth)
 {
@@ -219,31 +221,35 @@ __global__ void k_refit(const rt_bvh_node *__restrict__ nodes, const uint32_t *_
     const rt_bvh_node nd = nodes[n - 1 + k];
     float lo[3] = {nd.bmin[0], nd.bmin[1], nd.bmin[2]}, hi[3] = {nd.bmax[0], nd.bmax[1], nd.bmax[2]};
     uint32_t depth = 0, cur = n - 1 + k;
+    auto pack = [](uint32_t a, uint32_t b) { return (uint64_t)a | ((uint64_t)b << 32); };
     for (;;) {
         const uint32_t parent = parents[cur];
         if (parent == 0xFFFFFFFFu) { atomicMax(max_depth, depth); return; }       // cur is the root
         // publish this node (leaves too: the sibling's climber reads them the same way), then arrive
-        uint32_t *mine = scratch + (size_t)cur * 8;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            (void)atomicExch(&mine[c], __float_as_uint(lo[c]));
-            (void)atomicExch(&mine[3 + c], __float_as_uint(hi[c]));
-        }
-        (void)atomicExch(&mine[6], depth);
-        // every exchange must have RETURNED (= been performed at the memory side) before the arrival is counted; inline asm,
-        // because the compiler may drop a wait it believes redundant (MI355X_MICROARCH.md, "Compiler hazard")
+        uint64_t *mine = reinterpret_cast<uint64_t *>(scratch + (size_t)cur * 8);
+        __hip_atomic_store(&mine[0], pack(__float_as_uint(lo[0]), __float_as_uint(lo[1])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&mine[1], pack(__float_as_uint(lo[2]), __float_as_uint(hi[0])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&mine[2], pack(__float_as_uint(hi[1]), __float_as_uint(hi[2])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (word 7 of a node is its arrival counter: the depth is published as a 32-bit store so that it is left alone)
+        __hip_atomic_store(scratch + (size_t)cur * 8 + 6, depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // every store must have been ACKNOWLEDGED before the arrival is counted; inline asm, because the compiler may drop a
+        // wait it believes redundant (MI355X_MICROARCH.md, "Compiler hazard")
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t arrived = atomicAdd(&scratch[(size_t)parent * 8 + 7], 1u);
         if (arrived == 0u) return;                       // the sibling's climber will take over from here
         const rt_bvh_node pn = nodes[parent];
         const uint32_t sib = pn.left == cur ? pn.right : pn.left;
-        uint32_t *other = scratch + (size_t)sib * 8;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            lo[c] = fminf(lo[c], __uint_as_float(atomicOr(&other[c], 0u)));
-            hi[c] = fmaxf(hi[c], __uint_as_float(atomicOr(&other[3 + c], 0u)));
-        }
-        const uint32_t od = atomicOr(&other[6], 0u);
+        const uint64_t *other = reinterpret_cast<const uint64_t *>(scratch + (size_t)sib * 8);
+        const uint64_t o0 = __hip_atomic_load(&other[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t o1 = __hip_atomic_load(&other[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t o2 = __hip_atomic_load(&other[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t od = __hip_atomic_load(scratch + (size_t)sib * 8 + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lo[0] = fminf(lo[0], __uint_as_float((uint32_t)o0));
+        lo[1] = fminf(lo[1], __uint_as_float((uint32_t)(o0 >> 32)));
+        lo[2] = fminf(lo[2], __uint_as_float((uint32_t)o1));
+        hi[0] = fmaxf(hi[0], __uint_as_float((uint32_t)(o1 >> 32)));
+        hi[1] = fmaxf(hi[1], __uint_as_float((uint32_t)o2));
+        hi[2] = fmaxf(hi[2], __uint_as_float((uint32_t)(o2 >> 32)));
         depth = (depth > od ? depth : od) + 1u;
         cur = parent;
     }
@@ -332,10 +338,12 @@ int lbvh_from_boxes(rt_context *ctx, BvhDev &bv, const Box6 *boxes, uint32_t n, 
     RT_TRY(tmp_depth.reserve(sizeof(uint32_t)));
 
     k_morton<<<grid_for(n, B), B, 0, st>>>(boxes, n, d_bounds, tmp_keys.as<uint64_t>());
+    // keys are (30-bit Morton code << 32) | index with the indices ascending on input: a STABLE sort of the code bits alone
+    // gives the order of the full 64-bit keys (the oracle's) with half the radix passes
     size_t sort_bytes = 0;
-    HIP_TRY(rocprim::radix_sort_keys(nullptr, sort_bytes, tmp_keys.as<uint64_t>(), bv.keys.as<uint64_t>(), n, 0, 62, st));
+    HIP_TRY(rocprim::radix_sort_keys(nullptr, sort_bytes, tmp_keys.as<uint64_t>(), bv.keys.as<uint64_t>(), n, 32, 62, st));
     RT_TRY(tmp_sort.reserve(sort_bytes));
-    HIP_TRY(rocprim::radix_sort_keys(tmp_sort.p, sort_bytes, tmp_keys.as<uint64_t>(), bv.keys.as<uint64_t>(), n, 0, 62, st));
+    HIP_TRY(rocprim::radix_sort_keys(tmp_sort.p, sort_bytes, tmp_keys.as<uint64_t>(), bv.keys.as<uint64_t>(), n, 32, 62, st));
 
     rt_bvh_node *nodes = bv.nodes.as<rt_bvh_node>();
     uint32_t *parents = bv.parents.as<uint32_t>();
@@ -349,10 +357,24 @@ int lbvh_from_boxes(rt_context *ctx, BvhDev &bv, const Box6 *boxes, uint32_t n, 
         k_refit_decode<<<grid_for(n - 1, B), B, 0, st>>>(tmp_enc.as<uint32_t>(), nodes, n - 1);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&bv.max_depth, tmp_depth.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(bv.bounds, d_bounds, 6 * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    // depth and bounds come back through page-locked memory and are picked up by lbvh_collect() once the caller has queued
+    // the rest of the build: no host round trip in the middle of it
+    uint32_t *back = ctx->pinned ? ctx->pinned + RT_PINNED_LBVH : nullptr;
+    HIP_TRY(hipMemcpyAsync(back ? (void *)back : (void *)&bv.max_depth, tmp_depth.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(back ? (void *)(back + 1) : (void *)bv.bounds, d_bounds, 6 * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (!back) HIP_TRY(hipStreamSynchronize(st));
     (void)tlas;
+    return RT_OK;
+}
+
+// joins the stream and takes the depth and bounds lbvh_from_boxes queued for read-back
+int lbvh_collect(rt_context *ctx, BvhDev &bv)
+{
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->pinned) {
+        bv.max_depth = ctx->pinned[RT_PINNED_LBVH];
+        memcpy(bv.bounds, ctx->pinned + RT_PINNED_LBVH + 1, 6 * sizeof(float));
+    }
     return RT_OK;
 }
 
@@ -393,7 +415,7 @@ int rt_build_blas(rt_context *ctx, rt_model *m)
         mark("LBVH");
         k_gather_tris<<<grid_for(n, B), B, 0, st>>>(m->blas.keys.as<uint64_t>(), m->d_verts.as<rt_vertex>(),
                                                     m->d_idx.as<uint32_t>(), n, m->tris.as<TriRec>());
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        if (hipGetLastError() != hipSuccess) {
             rt_set_error("BLAS build kernels failed");
             rc = RT_ERR_HIP;
             break;
@@ -406,6 +428,7 @@ int rt_build_blas(rt_context *ctx, rt_model *m)
         mark("PLOC + wide layout");
         if (!ploc_done && (rc = rt_build_wide_from_lbvh(ctx, m->blas, false, ctx->leaf_max)) != RT_OK) break;
         mark("wide layout (LBVH)");
+        if ((rc = lbvh_collect(ctx, m->blas)) != RT_OK) break;
         m->built = true;
     } while (0);
     boxes.release(); enc.release(); bounds.release(); tkeys.release(); tsort.release(); tenc.release(); tdepth.release();
@@ -508,6 +531,7 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
         if ((rc = lbvh_from_boxes(ctx, s->tlas, boxes.as<Box6>(), n, bounds.as<float>(), true, tkeys, tsort, tenc, tdepth)) != RT_OK) break;
         // the TLAS is walked in the same four-wide layout (a single instance: the root is the leaf of instance 0)
         if ((rc = rt_build_wide_from_lbvh(ctx, s->tlas, true, 1)) != RT_OK) break;
+        if ((rc = lbvh_collect(ctx, s->tlas)) != RT_OK) break;
         // a step leaves at most three siblings behind; two-level walks add the TLAS path and the sentinel that marks the
         // bottom of a BLAS walk
         s->two_level = !(n == 1 && (s->h_inst[0].flags & RT_INST_IDENTITY));

@@ -23,10 +23,18 @@
 
 namespace {
 
+// Search window.  Measured on the three bench scenes, frame ms (1080p 262 k triangles / 4K 10 M triangles, 4 bounces / 4K 4096
+// instances): radius 2: 2.75 / 16.3 / 6.28, 3: 2.70 / 15.9, 4: 2.64 / 15.4 / 6.20, 6: 2.83 / 15.6, 8: 2.76 / 15.4 / 6.24,
+// 12: 2.82 / 15.9 / 6.17, 16: 2.87 / 16.3 -- a few per cent of tree-quality noise, no trend towards wide windows once the
+// binary tree is collapsed four wide; 4 is also the cheapest to build.
 #ifndef RT_PLOC_RADIUS
-#define RT_PLOC_RADIUS 8
+#define RT_PLOC_RADIUS 4
 #endif
 constexpr int PLOC_RADIUS = RT_PLOC_RADIUS;
+#ifndef RT_PLOC_TAIL_RADIUS
+#define RT_PLOC_TAIL_RADIUS RT_PLOC_RADIUS
+#endif
+constexpr int PLOC_TAIL_RADIUS = RT_PLOC_TAIL_RADIUS;       // window of the single-workgroup rounds at the top of the tree
 constexpr unsigned PB = 256;
 
 struct Box6 { float lo[3]; float hi[3]; };
@@ -47,7 +55,7 @@ struct View {
 
 // where the clustering stands before round r (device memory, one entry per round of a batch)
 struct PlocRound { uint32_t c, next_node, cur, error; };
-constexpr uint32_t PLOC_TAIL = 4096, TAIL_BLOCK = 1024, PLOC_MAX_BATCH = 64;
+constexpr uint32_t PLOC_TAIL = 2048, TAIL_BLOCK = 1024, PLOC_MAX_BATCH = 64;   // (tail at 4096: 0.20 ms in the one workgroup; a multi-kernel round costs ~12 us)
 
 // the arrays the PLOC rounds read and write
 struct PlocArrays {
@@ -188,13 +196,13 @@ __global__ void __launch_bounds__(PB) k_ploc_apply(PlocArrays a, uint32_t r, uin
 // The tail of the clustering: once PLOC_TAIL or fewer clusters are left, ONE workgroup runs all the remaining rounds
 // (nearest neighbour, mutual-pair flags, the two prefix sums, merge) back to back with barriers in between -- the same
 // arithmetic and the same node numbering as the multi-kernel rounds, without ~40 rounds of launches and host round trips
-// for a handful of clusters each.  The cluster array (boxes, node ids) lives in LDS for the whole tail: 4096 x 28 B =
-// 112 KiB of the CU's 160; round 2 kept it in global memory and spent 0.36 ms of a 2.5 ms build on round trips.
+// for a handful of clusters each.  The cluster array (boxes, node ids, sizes) lives in LDS for the whole tail: 2048 x 34 B
+// = 68 KiB of the CU's 160; the first version kept it in global memory and spent 0.36 ms of a 2.5 ms build on round trips.
 struct TailLds {
     Box6 box[PLOC_TAIL];
-    uint32_t node[PLOC_TAIL];
+    uint32_t node[PLOC_TAIL], size[PLOC_TAIL];
     uint16_t nn[PLOC_TAIL];
-    uint32_t part_keep[TAIL_BLOCK], part_merge[TAIL_BLOCK];
+    uint32_t scan[TAIL_BLOCK / 64];
 };
 __global__ void __launch_bounds__(TAIL_BLOCK) k_ploc_tail(PlocArrays a, uint32_t r, uint32_t n, PlocRound *__restrict__ result)
 {
@@ -209,14 +217,19 @@ __global__ void __launch_bounds__(TAIL_BLOCK) k_ploc_tail(PlocArrays a, uint32_t
     TailLds &L = *reinterpret_cast<TailLds *>(tail_smem);
     constexpr uint32_t PER = PLOC_TAIL / TAIL_BLOCK;
     const uint32_t t = threadIdx.x;
-    for (uint32_t i = t; i < c; i += TAIL_BLOCK) { L.box[i] = a.cl_box[cur][i]; L.node[i] = a.cl_node[cur][i]; }
+    for (uint32_t i = t; i < c; i += TAIL_BLOCK) {
+        const uint32_t id = a.cl_node[cur][i];
+        L.box[i] = a.cl_box[cur][i];
+        L.node[i] = id;
+        L.size[i] = a.size[id];
+    }
     __syncthreads();
     while (c > 1) {
-        for (uint32_t i = t; i < c; i += TAIL_BLOCK) {               // nearest neighbour (k_ploc_nn)
+        for (uint32_t i = t; i < c; i += TAIL_BLOCK) {               // nearest neighbour (as k_ploc_pair)
             const Box6 me = L.box[i];
             float best = __uint_as_float(0x7f800000u);
             uint32_t arg = i;
-            for (int d = -PLOC_RADIUS; d <= PLOC_RADIUS; d++) {
+            for (int d = -PLOC_TAIL_RADIUS; d <= PLOC_TAIL_RADIUS; d++) {
                 const int j = (int)i + d;
                 if (d == 0 || j < 0 || j >= (int)c) continue;
                 const float ar = merged_area(me, L.box[j]);
@@ -225,8 +238,8 @@ __global__ void __launch_bounds__(TAIL_BLOCK) k_ploc_tail(PlocArrays a, uint32_t
             L.nn[i] = (uint16_t)arg;
         }
         __syncthreads();
-        // flags (k_ploc_flags), PER consecutive clusters per thread; the thread keeps its flags in registers
-        uint32_t k_sum = 0, m_sum = 0, keep_bits = 0, merge_bits = 0;
+        // flags, PER consecutive clusters per thread, kept in registers; tallies packed kept | created << 16
+        uint32_t mine = 0, keep_bits = 0, merge_bits = 0;
         for (uint32_t e = 0; e < PER; e++) {
             const uint32_t i = t * PER + e;
             if (i >= c) break;
@@ -235,25 +248,16 @@ __global__ void __launch_bounds__(TAIL_BLOCK) k_ploc_tail(PlocArrays a, uint32_t
             const uint32_t mg = (mutual && i < j) ? 1u : 0u, kp = (mutual && i > j) ? 0u : 1u;
             merge_bits |= mg << e;
             keep_bits |= kp << e;
-            k_sum += kp;
-            m_sum += mg;
+            mine += kp | (mg << 16);
         }
-        L.part_keep[t] = k_sum;
-        L.part_merge[t] = m_sum;
-        __syncthreads();
-        for (uint32_t off = 1; off < TAIL_BLOCK; off <<= 1) {         // inclusive scan of the per-thread sums
-            const uint32_t pk = t >= off ? L.part_keep[t - off] : 0u, pm = t >= off ? L.part_merge[t - off] : 0u;
-            __syncthreads();
-            L.part_keep[t] += pk;
-            L.part_merge[t] += pm;
-            __syncthreads();
-        }
-        uint32_t k_run = L.part_keep[t] - k_sum, m_run = L.part_merge[t] - m_sum;      // exclusive prefix of this thread's run
-        const uint32_t kept = L.part_keep[TAIL_BLOCK - 1], merged = L.part_merge[TAIL_BLOCK - 1];
+        uint32_t total;
+        const uint32_t before = rt_scan::block_exclusive<TAIL_BLOCK>(mine, L.scan, total);
+        uint32_t k_run = before & 0xFFFFu, m_run = before >> 16;
+        const uint32_t kept = total & 0xFFFFu, merged = total >> 16;
         if (merged == 0 || kept != c - merged) break;                 // no progress: reported by the host (block-uniform)
-        // what this thread's clusters become (ploc_apply_one), computed into registers before anybody overwrites the array
+        // what this thread's clusters become, computed into registers before anybody overwrites the array
         Box6 out_box[PER];
-        uint32_t out_node[PER], out_pos[PER];
+        uint32_t out_node[PER], out_size[PER], out_pos[PER];
         for (uint32_t e = 0; e < PER; e++) {
             const uint32_t i = t * PER + e;
             out_pos[e] = 0xFFFFFFFFu;
@@ -261,29 +265,31 @@ __global__ void __launch_bounds__(TAIL_BLOCK) k_ploc_tail(PlocArrays a, uint32_t
             out_pos[e] = k_run;
             if ((merge_bits >> e) & 1u) {
                 const uint32_t j = L.nn[i], m = next_node + m_run;
-                const uint32_t na = L.node[i], nb = L.node[j];
+                const uint32_t na = L.node[i], nb = L.node[j], sz = L.size[i] + L.size[j];
                 const Box6 ba = L.box[i], bb = L.box[j];
                 Box6 u;
                 for (int k = 0; k < 3; k++) { u.lo[k] = fminf(ba.lo[k], bb.lo[k]); u.hi[k] = fmaxf(ba.hi[k], bb.hi[k]); }
                 a.left[m - n] = na;
                 a.right[m - n] = nb;
                 a.node_box[m] = u;
-                a.size[m] = a.size[na] + a.size[nb];
+                a.size[m] = sz;
                 a.parent[na] = m;
                 a.parent[nb] = m;
                 a.parent[m] = 0xFFFFFFFFu;
                 out_node[e] = m;
                 out_box[e] = u;
+                out_size[e] = sz;
                 m_run++;
             } else {
                 out_node[e] = L.node[i];
                 out_box[e] = L.box[i];
+                out_size[e] = L.size[i];
             }
             k_run++;
         }
         __syncthreads();
         for (uint32_t e = 0; e < PER; e++)
-            if (out_pos[e] != 0xFFFFFFFFu) { L.box[out_pos[e]] = out_box[e]; L.node[out_pos[e]] = out_node[e]; }
+            if (out_pos[e] != 0xFFFFFFFFu) { L.box[out_pos[e]] = out_box[e]; L.node[out_pos[e]] = out_node[e]; L.size[out_pos[e]] = out_size[e]; }
         __syncthreads();
         c = kept;
         next_node += merged;
@@ -374,7 +380,7 @@ int rt_build_ploc_layout(rt_context *ctx, rt_model *m, bool *done)
         for (int k = 0; k < 2; k++) { pa.cl_node[k] = cl_node[k].as<uint32_t>(); pa.cl_box[k] = cl_box[k].as<Box6>(); }
         pa.left = left.as<uint32_t>(); pa.right = right.as<uint32_t>(); pa.size = size.as<uint32_t>(); pa.parent = parent.as<uint32_t>();
         pa.node_box = node_box.as<Box6>();
-        // 136 KiB of dynamic LDS: above the default 64 KiB limit of a launch (the attribute is per device, set every build)
+        // 68 KiB of dynamic LDS: above the default 64 KiB limit of a launch (the attribute is per device, set every build)
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ploc_tail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TailLds)) != hipSuccess) {
             rt_set_error("PLOC tail: cannot reserve %zu bytes of LDS", sizeof(TailLds));
             rc = RT_ERR_HIP;

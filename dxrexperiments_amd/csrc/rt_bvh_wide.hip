@@ -101,6 +101,8 @@ __global__ void __launch_bounds__(WB) k_wide_expand(TreeView t, const uint32_t *
             kid[best] = t.left[id - t.n];
             kid[nk++] = t.right[id - t.n];
         }
+        // (Filling the slots that are still free with the halves of multi-triangle leaves -- 3.0 -> 3.9 children per node, the
+        // step tests four boxes either way -- was measured: 3 % fewer triangle tests, but more leaf visits, frame 2.67 -> 2.83 ms.)
         float ar[4];
         for (int k = 0; k < nk; k++) ar[k] = box_area(t.box[kid[k]]);
         for (int i = 1; i < nk; i++)                       // insertion sort, larger surface first, stable

@@ -126,6 +126,8 @@ struct SceneDev {
 
 // ---- host objects --------------------------------------------------------------
 
+#define RT_PINNED_WORDS 128
+#define RT_PINNED_LBVH 64
 struct rt_context {
     int refs = 1;                // handle + every model / scene / pipeline created on it
     int device = 0;
@@ -141,7 +143,8 @@ struct rt_context {
     uint32_t lds_stack_rows = 0;            // RT_LDS_STACK_ROWS=6: the small-stack instantiation (tests of the deep-stack path)
     DevBuf pool;                 // ray-pool counters of rt_trace_batch
     DevBuf deep_stack;           // global stack rows of the traversal kernels (rt_scene_dev_for_launch)
-    uint32_t *pinned = nullptr;  // 64 words of page-locked host memory: small device-to-host read-backs without staging
+    uint32_t *pinned = nullptr;  // RT_PINNED_WORDS of page-locked host memory: small device-to-host read-backs without staging
+                                 // (words 0..63: whoever synchronises next; RT_PINNED_LBVH..+6: depth and bounds of an LBVH in flight)
     DevBuf build_arena;          // temporaries of the acceleration-structure builds: one allocation, sliced (hipMalloc
                                  // and hipFree synchronise the device and cost more than the kernels of a small build)
     DevBuf scratch[8];           // staging for host-pointer batch calls

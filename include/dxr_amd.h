@@ -96,6 +96,13 @@ int rt_scene_destroy(rt_scene *s);
 int rt_scene_bvh_info(const rt_scene *s, int which, uint32_t *n_prims, uint32_t *n_nodes, uint32_t *max_depth);
 int rt_scene_bvh_read(const rt_scene *s, int which, rt_bvh_node *nodes, uint64_t *sorted_keys, uint32_t *parents);
 int rt_scene_instance_info(const rt_scene *s, uint32_t instance, float world_box[6], float world_to_object[12]);
+/* Inspection of the PRODUCTION traversal layout of the same structures (tests, tools): four-wide quantised nodes of 64 B
+ * (float4 origin.xyz + scale.x | lo.x[4] hi.x[4] lo.y[4] hi.y[4] bytes | lo.z[4] hi.z[4] bytes, scale.y, scale.z | four
+ * int32 child codes: >= 0 node index, INT32_MIN unused, otherwise ~code with code = instance (TLAS) or
+ * first_record << 3 | (count - 1) (BLAS)), plane = fma(byte, scale, origin); BLAS records are 48 B: nine floats p0 p1 p2,
+ * the uint32 primitive index, 8 B padding.  root_code: 0 = node 0, negative = the whole structure is one leaf. */
+int rt_scene_wide_info(const rt_scene *s, int which, uint32_t *n_nodes, int32_t *root_code, uint32_t *n_records);
+int rt_scene_wide_read(const rt_scene *s, int which, void *nodes, void *records);
 /* milliseconds the last rt_scene_build spent on the GPU (BLAS + TLAS) */
 int rt_scene_build_ms(const rt_scene *s, float *ms);
 
