@@ -320,7 +320,7 @@ int rt_model_destroy(rt_model *m)
     if (!m) return RT_OK;
     if (--m->refs > 0) return RT_OK;
     (void)hipSetDevice(m->ctx->device);
-    m->d_verts.release(); m->d_idx.release(); m->tris.release(); m->blas.release();
+    m->d_verts.release(); m->d_idx.release(); m->tris.release(); m->normals.release(); m->blas.release();
     rt_context *ctx = m->ctx;
     delete m;
     rt_context_release(ctx);

@@ -294,6 +294,21 @@ __global__ void k_gather_tris(const uint64_t *__restrict__ keys, const rt_vertex
     tris[k] = t;
 }
 
+// the vertex normals of every primitive, gathered once per build into one record per primitive (shading reads them per hit)
+__global__ void k_normal_records(const rt_vertex *__restrict__ verts, const uint32_t *__restrict__ idx, uint32_t n, TriRec *__restrict__ out)
+{
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const rt_float3 n0 = verts[idx[3 * p + 0]].normal;
+    const rt_float3 n1 = verts[idx[3 * p + 1]].normal;
+    const rt_float3 n2 = verts[idx[3 * p + 2]].normal;
+    TriRec t;
+    t.a = make_float4(n0.x, n0.y, n0.z, n1.x);
+    t.b = make_float4(n1.y, n1.z, n2.x, n2.y);
+    t.c = make_float4(n2.z, 0.0f, 0.0f, 0.0f);
+    out[p] = t;
+}
+
 inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
 // Temporaries of a build over n primitives as slices of the context's build arena (sized for the larger of
@@ -405,6 +420,7 @@ int rt_build_blas(rt_context *ctx, rt_model *m)
         if ((rc = enc.reserve(6 * sizeof(uint32_t))) != RT_OK) break;
         if ((rc = bounds.reserve(6 * sizeof(float))) != RT_OK) break;
         if ((rc = m->tris.reserve(sizeof(TriRec) * (size_t)n)) != RT_OK) break;
+        if ((rc = m->normals.reserve(sizeof(TriRec) * (size_t)n)) != RT_OK) break;
         mark("tris alloc");
         k_init_bounds<<<1, 64, 0, st>>>(enc.as<uint32_t>());
         k_tri_boxes<<<grid_for(n, BOUNDS_BLOCK), BOUNDS_BLOCK, 0, st>>>(m->d_verts.as<rt_vertex>(), m->d_idx.as<uint32_t>(), n, boxes.as<Box6>(),
@@ -415,6 +431,7 @@ int rt_build_blas(rt_context *ctx, rt_model *m)
         mark("LBVH");
         k_gather_tris<<<grid_for(n, B), B, 0, st>>>(m->blas.keys.as<uint64_t>(), m->d_verts.as<rt_vertex>(),
                                                     m->d_idx.as<uint32_t>(), n, m->tris.as<TriRec>());
+        k_normal_records<<<grid_for(n, B), B, 0, st>>>(m->d_verts.as<rt_vertex>(), m->d_idx.as<uint32_t>(), n, m->normals.as<TriRec>());
         if (hipGetLastError() != hipSuccess) {
             rt_set_error("BLAS build kernels failed");
             rc = RT_ERR_HIP;
@@ -505,6 +522,7 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
         r.cnodes = m->blas.nodes.as<rt_bvh_node>();
         r.verts = m->d_verts.as<rt_vertex>();
         r.indices = m->d_idx.as<uint32_t>();
+        r.normals = m->normals.as<TriRec>();
         r.n_prims = m->n_tris;
         r.material = i;
         for (int c = 0; c < 3; c++) { hb[i].lo[c] = r.wlo[c]; hb[i].hi[c] = r.whi[c]; }

@@ -103,6 +103,8 @@ struct InstanceRec {
     const rt_bvh_node *cnodes;  // canonical nodes of the BLAS
     const rt_vertex *verts;
     const uint32_t *indices;
+    const TriRec *normals;      // the three vertex normals of primitive p in ONE 48-B record (n0.xyz n1.x | n1.yz n2.xy | n2.z):
+                                //   a shaded hit fetches one record instead of three indices and three scattered vertices
     uint32_t n_prims;
     uint32_t material;
 };
@@ -173,6 +175,7 @@ struct rt_model {
     std::vector<uint32_t> h_idx;
     DevBuf d_verts, d_idx;
     DevBuf tris;                 // TriRec[n_tris] in sorted order
+    DevBuf normals;              // TriRec[n_tris] in primitive order: the vertex normals (InstanceRec::normals)
     BvhDev blas;
     bool built = false;
 };

@@ -222,12 +222,11 @@ RT_DEV RayD primary_ray(const PipeDev &pd, uint32_t px, uint32_t py)
 RT_DEV f3 hit_normal(const InstanceRec &in, uint32_t prim, float bu, float bv)
 {
     const float b0 = 1.0f - bu - bv;
-    const rt_float3 n0 = in.verts[in.indices[3 * prim + 0]].normal;
-    const rt_float3 n1 = in.verts[in.indices[3 * prim + 1]].normal;
-    const rt_float3 n2 = in.verts[in.indices[3 * prim + 2]].normal;
-    f3 n = mk3(n0.x, n0.y, n0.z) * b0;
-    n = n + mk3(n1.x, n1.y, n1.z) * bu;
-    n = n + mk3(n2.x, n2.y, n2.z) * bv;
+    // verts[indices[3 prim + k]].normal, gathered per primitive at build time (InstanceRec::normals): one 48-B record
+    const TriRec nr = in.normals[prim];
+    f3 n = mk3(nr.a.x, nr.a.y, nr.a.z) * b0;
+    n = n + mk3(nr.a.w, nr.b.x, nr.b.y) * bu;
+    n = n + mk3(nr.b.z, nr.b.w, nr.c.x) * bv;
     return n;
 }
 
