@@ -124,6 +124,30 @@ def test_wide_node_culling_stays_conservative_in_hard_places(gpu, oracle, capi):
     pick = r.integers(0, hill.shape[0], n)
     O[:, :3] = hill["position"][pick]
     compare_all(p, O, D, brute=True)
+    # (d) microscopic clusters seen from far away: nodes whose whole extent lies inside the culling margin, where even the
+    # inverted interval of an UNUSED child slot passes the plane test and only its code (RT_NODE_NONE) keeps the walk out;
+    # odd cluster sizes leave slots unused at every level
+    parts = []
+    for k, (cnt, size) in enumerate([(3, 1e-6), (5, 1e-7), (7, 3e-6), (11, 1e-8), (2, 1e-5), (37, 1e-6)]):
+        cv, ci = triangle_soup(cnt, seed=200 + k, extent=size * 4, size=size)
+        cv["position"] += r.uniform(-2, 2, 3).astype(np.float32)
+        parts.append(cv)
+    v = np.concatenate(parts)
+    i = np.arange(v.shape[0], dtype=np.uint32).reshape(-1, 3)
+    p = Pair(oracle, capi, gpu, [(v, i)], [(0, None)])
+    tri = v["position"].reshape(-1, 3, 3)
+    n = 20000
+    O = np.zeros((n, 4), np.float32); D = np.zeros((n, 4), np.float32)
+    target = tri[r.integers(0, tri.shape[0], n)]
+    w = r.dirichlet((1, 1, 1), n).astype(np.float32)
+    aim = (target * w[:, :, None]).sum(axis=1) + (r.normal(size=(n, 3)) * 1e-7).astype(np.float32)
+    dirs = r.normal(size=(n, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    dist = 10.0 ** r.uniform(0, 4, n)                               # 1 .. 10^4 units away
+    O[:, :3] = (aim - dirs * dist[:, None]).astype(np.float32)
+    D[:, :3] = dirs.astype(np.float32)
+    D[:, 3] = 1e38
+    compare_all(p, O, D, brute=True)
 
 
 def test_small_lds_stack_spills_to_global_rows():
