@@ -35,9 +35,9 @@ GATHER_PEAK_GBS = 8600.0
 LINE_BYTES = 64
 RAY_BYTES, NODE_BYTES, TRI_BYTES = 48, 32, 36   # 32 B ray in + 16 B hit out; node; triangle
 # what the production kernels request per unit (DESIGN.md sections 3 / 4): one 64-B node per step that is not served by the
-# LDS-resident top of the tree, one 48-B record per triangle test, one 112-B instance record per instance entry, and the
+# LDS-resident top of the tree, one 48-B record per triangle test, the 96-B traversal prefix of an instance record per instance entry, and the
 # ray in / result out of the stage
-NODE_LINE_BYTES, TRIREC_BYTES, INSTANCE_BYTES = 64, 48, 112
+NODE_LINE_BYTES, TRIREC_BYTES, INSTANCE_BYTES = 64, 48, 96
 STAGE_IO_BYTES = {"primary": 0 + 20, "secondary": 32 + 20, "shadow": 32 + 4}
 # stage -> (rt_stats time fields, kernel, rt_pipeline_count_work stages whose rays the launch traces)
 TRACE_STAGES = {"primary": (("ms_primary",), "k_primary", ("primary",)),

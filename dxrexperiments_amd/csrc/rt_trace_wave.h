@@ -229,7 +229,7 @@ RT_DEV unsigned long long lanemask_lt()
 //   struct Sink { void store(uint32_t i, const HitD &h, bool traced) const; };
 
 // COUNT: the walk-counting instantiation (rt_pipeline_count_walk): the same walk, plus per-lane tallies of what it
-// fetches -- 64-B nodes from global memory, nodes from the LDS-resident top, 48-B triangle records, 112-B
+// fetches -- 64-B nodes from global memory, nodes from the LDS-resident top, 48-B triangle records, the 96-B traversal prefix of
 // instance records -- summed into walk[0..5] = rays, nodes from global memory, nodes from LDS, triangles, instance entries,
 // distinct 64-B lines (node lines de-duplicated across the lanes of each wave step + the lines the triangle records span);
 // walk[6] = max over rays of (node steps << 32 | ray index), the longest single walk (a tail detector).

@@ -164,7 +164,7 @@ typedef struct rt_stage_walk {
     uint64_t nodes_global;       /* 64-B four-wide nodes loaded from global memory, per lane      */
     uint64_t nodes_lds;          /* nodes read from the LDS-resident top of the tree              */
     uint64_t tris;               /* 48-B triangle records loaded                                */
-    uint64_t instance_entries;   /* 112-B instance records visited (two-level scenes)           */
+    uint64_t instance_entries;   /* instance records entered (two-level scenes; 96 B read each) */
     uint64_t lines;              /* distinct 64-B lines fetched: node lines de-duplicated over the lanes of each wave step +
                                     the one or two lines each triangle record spans                                   */
     uint64_t longest_walk;       /* node steps of the stage's longest single ray (persistent kernels end with their slowest lane) */
