@@ -88,6 +88,7 @@ struct PipeDev {
     uint32_t max_rad, max_shadow;
     uint32_t accum_mode;
     uint32_t skip_unlit;                // do not traverse shadow rays of lights with N.L == 0 (their visibility is multiplied by 0)
+    uint32_t shadow_compact;            // shadow queues hold ONE float4 per shaded hit (QueueSrc, "light rays")
     uint32_t kind;                      // RT_PIPELINE_PROGRESSIVE / RT_PIPELINE_REALTIME
     float4 *accum;
     float4 *aov_direct, *aov_indirect;  // realtime pipeline outputs (RealtimeRaytracing.hlsl:3-4)
@@ -423,20 +424,36 @@ struct EmitIO {
     const PipeDev &pd;
     int L;
     uint32_t idx, q;            // compact hit index at level L, pixel slot
-    uint32_t shadow_mask, sec_mask;
-    RT_DEV EmitIO(const PipeDev &p, int level, uint32_t i, uint32_t qq) : pd(p), L(level), idx(i), q(qq), shadow_mask(0), sec_mask(0) {}
+    uint32_t shadow_mask, skip_mask, sec_mask;
+    f3 shadow_origin;           // compact shadow queues: the hit point both light rays start from
+    RT_DEV EmitIO(const PipeDev &p, int level, uint32_t i, uint32_t qq) : pd(p), L(level), idx(i), q(qq), shadow_mask(0), skip_mask(0), sec_mask(0)
+    {
+        shadow_origin = mk3(0.0f, 0.0f, 0.0f);
+    }
     // matters = false: whatever this ray finds is multiplied by zero by the caller
     RT_DEV float shadow(int s, f3 o, f3 d, float tmin, float tmax, uint32_t depth, bool matters)
     {
         if (depth >= pd.max_shadow) return 1.0f;
-        if (!matters && pd.skip_unlit) {          // tmax = -2: "emitted but not worth traversing"; the trace kernel counts these
-            store_ray(pd.lv[L].shO, pd.lv[L].shD, (size_t)s * hcap(pd, L) + idx, mk3(0.0f, 0.0f, 0.0f), 0.0f, mk3(0.0f, 0.0f, 0.0f), RT_TMAX_SKIPPED);
-            shadow_mask |= 1u << s;
+        const bool skipped = !matters && pd.skip_unlit;     // "emitted but not worth traversing"; the trace kernel counts these
+        shadow_mask |= 1u << s;
+        if (skipped) skip_mask |= 1u << s;
+        if (pd.shadow_compact) {                            // the ray is rebuilt from the hit point by QueueSrc::load
+            shadow_origin = o;
             return 1.0f;
         }
-        store_ray(pd.lv[L].shO, pd.lv[L].shD, (size_t)s * hcap(pd, L) + idx, o, tmin, d, tmax);
-        shadow_mask |= 1u << s;
+        if (skipped) store_ray(pd.lv[L].shO, pd.lv[L].shD, (size_t)s * hcap(pd, L) + idx, mk3(0.0f, 0.0f, 0.0f), 0.0f, mk3(0.0f, 0.0f, 0.0f), RT_TMAX_SKIPPED);
+        else store_ray(pd.lv[L].shO, pd.lv[L].shD, (size_t)s * hcap(pd, L) + idx, o, tmin, d, tmax);
         return 1.0f;
+    }
+    // the shadow slots of this hit that no ray went to are marked "not traced"
+    RT_DEV void finish_shadows(uint32_t shadow_slots) const
+    {
+        if (pd.shadow_compact) {
+            pd.lv[L].shO[idx] = make_float4(shadow_origin.x, shadow_origin.y, shadow_origin.z, __uint_as_float(shadow_mask | (skip_mask << 2)));
+            return;
+        }
+        for (uint32_t s = 0; s < shadow_slots; s++)
+            if (!(shadow_mask & (1u << s))) store_invalid(pd.lv[L].shO, pd.lv[L].shD, (size_t)s * hcap(pd, L) + idx);
     }
     RT_DEV f3 secondary(int w, f3 o, f3 d, float tmin, uint32_t depth)
     {
@@ -595,8 +612,7 @@ __global__ void __launch_bounds__(PBLOCK) k_shade_emit(PipeDev pd, int level, ui
     const float4 h = pd.lv[L].hit[slot];
     EmitIO io(pd, L, idx, q);
     (void)closest_hit(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.lv[L].inst[slot], (uint32_t)L, px + py * pd.width);
-    for (uint32_t s = 0; s < shadow_slots; s++)
-        if (!(io.shadow_mask & (1u << s))) store_invalid(pd.lv[L].shO, pd.lv[L].shD, (size_t)s * hcap(pd, L) + idx);
+    io.finish_shadows(shadow_slots);
     if (emit_next) {
         if (L == 0) {
             for (uint32_t w = 0; w < 2; w++)
@@ -605,17 +621,52 @@ __global__ void __launch_bounds__(PBLOCK) k_shade_emit(PipeDev pd, int level, ui
     }
 }
 
-// a ray queue of `batches` batches of *count rays; batch b lives at [b*stride, b*stride + *count)
+// a ray queue of `batches` batches of *count rays; batch b lives at [b*stride, b*stride + *count).
+// Shadow queues are normally COMPACT ("light rays"): both shadow rays of a shaded hit start at the hit point and go to the
+// frame's two lights, so the emit pass stores one float4 per hit -- the point and, in the bits of w, which of the two rays
+// exist (bits 0-1) and which need not be traversed (bits 2-3) -- and this loader rebuilds ray b of hit k with the very
+// expressions of evaluateDirectionalLight / evaluatePointLight (RaytracingCommon.hlsli:126-147; directional_light /
+// point_light above): 16 B written and read per hit instead of 128 B.  The four rays of the ambient-occlusion view have
+// random directions and keep the explicit origin / direction form.
+struct LightRays {
+    uint32_t on;
+    float dir_to_light[3];      // normalize(-directionalLight.forwardDir), computed once per frame on the host with the
+                                //   device's expression (IEEE sqrt and division, left-to-right sums, no contraction)
+    float point_pos[3];         // pointLight.worldPos
+};
 struct QueueSrc {
     const float4 *O, *D;
     const uint32_t *count_ptr;
     uint32_t stride, batches, fl;
+    LightRays lights;
     RT_DEV uint32_t n() const { return *count_ptr; }
     RT_DEV uint32_t count() const { return n() * batches; }
     RT_DEV uint32_t flags() const { return fl; }
     RT_DEV size_t slot(uint32_t i) const { const uint32_t c = n(); return (size_t)(i / c) * stride + i % c; }
     RT_DEV bool load(uint32_t i, RayD &r) const
     {
+        if (lights.on) {
+            const uint32_t c = n(), b = i / c;
+            const v4f a = ldg16(O, (size_t)(i % c) * 16);
+            const uint32_t bits = __float_as_uint(a.w);
+            r.o = mk3(a.x, a.y, a.z);
+            r.d = mk3(0.0f, 0.0f, 0.0f);
+            r.tmin = 0.0f;
+            r.tmax = -1.0f;                                  // no such ray: never traced
+            if (!((bits >> b) & 1u)) return false;
+            if ((bits >> (2u + b)) & 1u) { r.tmax = RT_TMAX_SKIPPED; return false; }
+            r.tmin = RAY_EPSILON;
+            if (b == 0u) {
+                r.d = mk3(lights.dir_to_light[0], lights.dir_to_light[1], lights.dir_to_light[2]);
+                r.tmax = RAY_MAX_T;
+            } else {
+                const f3 path = mk3(lights.point_pos[0], lights.point_pos[1], lights.point_pos[2]) - r.o;
+                const float dist = length(path);
+                r.d = normalize(path);
+                r.tmax = dist - RAY_EPSILON;
+            }
+            return r.tmax > r.tmin;
+        }
         const size_t sl = slot(i);
         const v4f a = ldg16(O, sl * 16), b = ldg16(D, sl * 16);
         r.o = mk3(a.x, a.y, a.z); r.tmin = a.w;
@@ -623,6 +674,26 @@ struct QueueSrc {
         return r.tmax > r.tmin;
     }
 };
+static inline LightRays light_rays(const PipeDev &pd)
+{
+    LightRays l;
+    l.on = pd.shadow_compact;
+    const rt_float4 f = pd.pfc.directionalLight.forwardDir, w = pd.pfc.pointLight.worldPos;
+    const float x = -f.x, y = -f.y, z = -f.z;              // normalize(): v * (1 / sqrt(dot(v, v))), dot summed left to right
+    float d = x * x;
+    d += y * y;
+    d += z * z;
+    const float inv = 1.0f / sqrtf(d);
+    l.dir_to_light[0] = x * inv; l.dir_to_light[1] = y * inv; l.dir_to_light[2] = z * inv;
+    l.point_pos[0] = w.x; l.point_pos[1] = w.y; l.point_pos[2] = w.z;
+    return l;
+}
+static inline LightRays no_light_rays()
+{
+    LightRays l;
+    memset(&l, 0, sizeof l);
+    return l;
+}
 
 struct SecondarySink {
     QueueSrc q;
@@ -782,19 +853,18 @@ RT_DEV void wave_add64(unsigned long long v, unsigned long long *counter)
 
 // canonical-order re-trace of a queue: sums rays / nodes / triangles into out[0..2]
 __global__ void __launch_bounds__(PBLOCK)
-k_count_queue(SceneDev sc, const float4 *__restrict__ O, const float4 *__restrict__ D, const uint32_t *__restrict__ count,
-              uint32_t stride, uint32_t batches, uint32_t flags, unsigned long long *__restrict__ out)
+k_count_queue(SceneDev sc, QueueSrc src, unsigned long long *__restrict__ out)
 {
-    const uint32_t n = *count;
+    const uint32_t n = src.n();
     const uint32_t idx = blockIdx.x * PBLOCK + threadIdx.x;
     const uint32_t per = (n + PBLOCK - 1) / PBLOCK * PBLOCK;
-    const uint32_t b = per ? idx / per : batches, k = per ? idx % per : 0;
+    const uint32_t b = per ? idx / per : src.batches, k = per ? idx % per : 0;
     unsigned long long rays = 0, nodes = 0, tris = 0;
-    if (b < batches && k < n) {
-        const RayD r = load_ray(O, D, (size_t)b * stride + k);
-        if (r.tmax > r.tmin) {
+    if (b < src.batches && k < n) {
+        RayD r;
+        if (src.load(b * n + k, r)) {
             uint32_t cn, ct;
-            (void)trace_canonical(sc, r, flags, cn, ct);
+            (void)trace_canonical(sc, r, src.fl, cn, ct);
             rays = 1; nodes = cn; tris = ct;
         }
     }
@@ -937,13 +1007,14 @@ hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots
     if (T) record(ev[2], st);
     ShadowSrcN shadows;
     memset(&shadows, 0, sizeof shadows);
-    shadows.q[0] = QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, shadow_slots, any};         // RaytracingCommon.hlsli:94
+    const LightRays lr = light_rays(pd), none = no_light_rays();
+    shadows.q[0] = QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, shadow_slots, any, lr};     // RaytracingCommon.hlsli:94
     shadows.vis[0] = pd.lv[0].vis;
     shadows.nq = 1;
     size_t shadow_max = (size_t)cap * shadow_slots;
     for (uint32_t l = 1; l <= levels; l++) {
         // level 1: the diffuse and the specular batch of the primary hits; deeper: one ray per hit of level l-1
-        const QueueSrc rays = {pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE};   // ProgressiveRaytracing.hlsl:53
+        const QueueSrc rays = {pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE, none};   // ProgressiveRaytracing.hlsl:53
         k_trace_secondary<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_secondary<STACK, TWO_LEVEL>, PBLOCK, (size_t)cap * 2), PBLOCK, 0, st>>>(
             pd.sc, rays, pd.lv[l].hit, pd.lv[l].inst, pd.pools + (size_t)l * RT_POOL_GROUPS * RT_POOL_STRIDE, &pd.counters[C_SECONDARY]);
         k_compact_level<<<(2 * cap + CTILES * CBLOCK - 1) / (CTILES * CBLOCK), CBLOCK, 0, st>>>(pd, (int)l);
@@ -952,7 +1023,7 @@ hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots
         if (casts_shadows || spawns) k_shade_emit<false><<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd, (int)l, 2u, spawns ? 1u : 0u);
         if (T) record(ev[4 + 2 * (l - 1)], st);
         if (casts_shadows) {
-            shadows.q[shadows.nq] = QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any};
+            shadows.q[shadows.nq] = QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any, lr};
             shadows.vis[shadows.nq] = pd.lv[l].vis;
             shadows.nq++;
             shadow_max += (size_t)cap * 4;
@@ -985,13 +1056,14 @@ static int count_walk_launch(rt_pipeline *p, unsigned long long *w)
     k_walk_primary<TWO_LEVEL><<<rt_persistent_grid(ctx, k_walk_primary<TWO_LEVEL>, PBLOCK, cap), PBLOCK, 0, st>>>(pd, w + 7 * RT_STAGE_PRIMARY);
     const unsigned gq = rt_persistent_grid(ctx, k_walk_queue<TWO_LEVEL>, PBLOCK, (size_t)cap * 2);
     const unsigned gs = rt_persistent_grid(ctx, k_walk_shadow<TWO_LEVEL>, PBLOCK, (size_t)cap * 2);
-    k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any}, w + 7 * RT_STAGE_SHADOW0);
+    const LightRays lr = light_rays(pd), none = no_light_rays();
+    k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any, lr}, w + 7 * RT_STAGE_SHADOW0);
     const uint32_t levels = pd.max_rad < (uint32_t)MAXD ? pd.max_rad : (uint32_t)MAXD;
     for (uint32_t l = 1; l <= levels; l++) {
-        k_walk_queue<TWO_LEVEL><<<gq, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE},
+        k_walk_queue<TWO_LEVEL><<<gq, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE, none},
                                                        w + 7 * RT_STAGE_SECONDARY);
         if (l < pd.max_shadow)
-            k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any}, w + 7 * RT_STAGE_SHADOW1);
+            k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any, lr}, w + 7 * RT_STAGE_SHADOW1);
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -1246,6 +1318,7 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     pd.max_rad = p->max_rad; pd.max_shadow = p->max_shadow;
     pd.accum_mode = p->accum_mode;
     pd.skip_unlit = p->skip_unlit;
+    pd.shadow_compact = p->pfc.options.showAmbientOcclusionOnly ? 0u : 1u;     // the AO view's four rays have random directions
     pd.kind = p->kind;
     pd.accum = p->accum;
     pd.aov_direct = p->accum;                       // realtime: output 0 = direct lighting, output 1 = indirect specular
@@ -1525,16 +1598,17 @@ int rt_pipeline_count_work(rt_pipeline *p, rt_stage_work *out)
     const uint32_t cap = pd.cap, ss = p->last_shadow_slots;
     const uint32_t any = RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH | RT_RAY_FLAG_SKIP_CLOSEST_HIT_SHADER;
     k_count_primary<<<blocks(cap), PBLOCK, 0, st>>>(pd, w + 3 * RT_STAGE_PRIMARY);
-    k_count_queue<<<(blocks(cap) + 1) * ss, PBLOCK, 0, st>>>(pd.sc, pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any,
+    const LightRays lr = light_rays(pd), none = no_light_rays();
+    k_count_queue<<<(blocks(cap) + 1) * ss, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any, lr},
                                                              w + 3 * RT_STAGE_SHADOW0);
     const uint32_t levels = pd.max_rad < (uint32_t)MAXD ? pd.max_rad : (uint32_t)MAXD;
     for (uint32_t l = 1; l <= levels; l++) {        // every secondary level adds into the same two rows
         const uint32_t batches = l == 1 ? 2u : 1u;
-        k_count_queue<<<(blocks((size_t)cap * 2) + 1) * batches, PBLOCK, 0, st>>>(pd.sc, pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, batches,
-                                                                                   RT_RAY_FLAG_NONE, w + 3 * RT_STAGE_SECONDARY);
+        k_count_queue<<<(blocks((size_t)cap * 2) + 1) * batches, PBLOCK, 0, st>>>(
+            pd.sc, QueueSrc{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, batches, RT_RAY_FLAG_NONE, none}, w + 3 * RT_STAGE_SECONDARY);
         if (l < pd.max_shadow)
-            k_count_queue<<<(blocks((size_t)cap * 2) + 1) * 2, PBLOCK, 0, st>>>(pd.sc, pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2 * cap, 2, any,
-                                                                                w + 3 * RT_STAGE_SHADOW1);
+            k_count_queue<<<(blocks((size_t)cap * 2) + 1) * 2, PBLOCK, 0, st>>>(
+                pd.sc, QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2 * cap, 2, any, lr}, w + 3 * RT_STAGE_SHADOW1);
     }
     HIP_TRY(hipGetLastError());
     unsigned long long h[RT_STAGE_COUNT * 3];
