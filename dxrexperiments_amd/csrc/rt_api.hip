@@ -133,6 +133,8 @@ static int context_create(int device, void *stream, bool own, rt_context **out)
     if (pb && atoi(pb) >= 1 && atoi(pb) <= 16) c->blocks_per_cu_override = (uint32_t)atoi(pb);
     const char *fb = getenv("RT_FAST_BVH");
     if (fb && strcmp(fb, "lbvh") == 0) c->use_ploc = false;
+    const char *bb = getenv("RT_BUILD_BATCH");
+    if (bb && atoi(bb) >= 1 && atoi(bb) <= 64) c->build_batch = (uint32_t)atoi(bb);
     const char *lm = getenv("RT_LEAF_MAX");
     if (lm) {
         int v = atoi(lm);

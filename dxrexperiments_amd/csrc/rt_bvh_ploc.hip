@@ -399,6 +399,7 @@ int rt_build_ploc_layout(rt_context *ctx, rt_model *m, bool *done)
             uint32_t rounds = 0;
             for (double x = (double)res.c; x > (double)PLOC_TAIL && rounds < PLOC_MAX_BATCH; x *= 0.78) rounds++;
             if (rounds > 0 && rounds < PLOC_MAX_BATCH) rounds++;
+            if (ctx->build_batch && rounds > ctx->build_batch) rounds = ctx->build_batch;      // (tests: force short batches)
             for (uint32_t r = 0; r < rounds; r++) {
                 k_ploc_pair<<<gr(res.c), PB, 0, st>>>(pa, r);
                 k_ploc_apply<<<gr(res.c), PB, 0, st>>>(pa, r, n);

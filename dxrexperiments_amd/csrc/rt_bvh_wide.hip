@@ -287,6 +287,7 @@ int rt_build_wide_layout(rt_context *ctx, BvhDev &bv, uint32_t n, uint32_t root,
         uint64_t bound = 1;                                   // upper bound of the frontier at level lvl
         uint32_t batch = 6;
         for (uint32_t m = n; m > 1; m >>= 2) batch++;
+        if (ctx->build_batch) batch = ctx->build_batch;      // (tests: force short batches)
         WideState host_state;
         bool done = false;
         while (!done) {
@@ -311,7 +312,7 @@ int rt_build_wide_layout(rt_context *ctx, BvhDev &bv, uint32_t n, uint32_t root,
                 if (table[l].count == 0) { levels = l; wide_n = table[l].base; done = true; break; }
             if (!done && lvl >= RT_WIDE_MAX_LEVELS + 1) { rt_set_error("wide layout: deeper than %u levels", RT_WIDE_MAX_LEVELS); rc = RT_ERR_STATE; break; }
             bound = table[lvl].count;
-            batch = 8;
+            batch = ctx->build_batch ? ctx->build_batch : 8;
         }
         if (rc != RT_OK) break;
         bv.wide_n = wide_n;

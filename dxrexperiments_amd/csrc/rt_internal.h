@@ -145,6 +145,8 @@ struct rt_context {
     uint32_t lds_stack_rows = 0;            // RT_LDS_STACK_ROWS=6: the small-stack instantiation (tests of the deep-stack path)
     DevBuf pool;                 // ray-pool counters of rt_trace_batch
     DevBuf deep_stack;           // global stack rows of the traversal kernels (rt_scene_dev_for_launch)
+    uint32_t build_batch = 0;    // test hook (RT_BUILD_BATCH): PLOC rounds / collapse levels launched between two looks at the
+                                 //   device-side state; 0 = the builders' own estimates
     uint32_t *pinned = nullptr;  // RT_PINNED_WORDS of page-locked host memory: small device-to-host read-backs without staging
                                  // (words 0..63: whoever synchronises next; RT_PINNED_LBVH..+6: depth and bounds of an LBVH in flight)
     DevBuf build_arena;          // temporaries of the acceleration-structure builds: one allocation, sliced (hipMalloc

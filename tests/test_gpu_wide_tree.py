@@ -83,3 +83,24 @@ def test_single_instance_tlas(gpu, capi):
     sc = build(capi, gpu, [(v, i)], [(0, None)])
     nodes, root, recs = sc.wide_read(-1)
     assert nodes.shape[0] == 0 and root == ~0
+
+
+@pytest.mark.parametrize("batch", ["1", "3"])
+def test_short_build_batches_give_the_same_tree(gpu, capi, batch):
+    """The builders launch PLOC rounds and collapse levels in batches sized by an estimate and continue with another batch
+    when the device-side state says the estimate was short.  RT_BUILD_BATCH forces batches of 1 / 3 rounds, so every
+    build goes through that continuation many times; node numbering comes from prefix sums, so the tree must come out
+    bit for bit the same as with one batch."""
+    import os
+    v, i = triangle_soup(40000, seed=4242)
+    want_nodes, want_root, want_recs = build(capi, gpu, [(v, i)], [(0, None)]).wide_read(0)
+    os.environ["RT_BUILD_BATCH"] = batch
+    try:
+        ctx2 = capi.Context(0)
+    finally:
+        del os.environ["RT_BUILD_BATCH"]
+    sc = build(capi, ctx2, [(v, i)], [(0, None)])
+    nodes, root, recs = sc.wide_read(0)
+    assert root == want_root and np.array_equal(nodes, want_nodes) and np.array_equal(recs.view(np.uint32), want_recs.view(np.uint32))
+    tn, tr, _ = sc.wide_read(-1)
+    assert tn.shape[0] == 0 and tr == ~0
