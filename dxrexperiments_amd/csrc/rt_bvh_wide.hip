@@ -56,25 +56,53 @@ struct TreeView {
 struct WideLevel { uint32_t count, base; };                 // frontier size, index of its first wide node
 struct WideState {
     uint32_t arrivals, error;
+    uint32_t done, pad;                                     // levels below `done` were built by k_wide_top
     WideLevel level[RT_WIDE_MAX_LEVELS + 2];
 };
 
-__global__ void k_wide_init(WideState *__restrict__ ws, uint32_t *__restrict__ frontier0, uint32_t root)
+// the (up to four) children of frontier node b, largest surface first; returns how many of them are wide nodes themselves.
+// (Fetching a child's own children's ids together with its size and box -- one trip less per opened child -- was measured:
+// the large levels pay more for the extra loads than the small ones gain.)
+__device__ __forceinline__ uint32_t expand_node(const TreeView &t, uint32_t b, uint32_t kid[4])
 {
-    ws->level[0].count = 1;
-    ws->level[0].base = 0;
-    ws->arrivals = 0;
-    ws->error = 0;
-    frontier0[0] = root;
+    kid[0] = t.left[b - t.n]; kid[1] = t.right[b - t.n]; kid[2] = NO_KID; kid[3] = NO_KID;
+    int nk = 2;
+    while (nk < 4) {
+        int best = -1;
+        float best_area = -1.0f;
+        for (int k = 0; k < nk; k++) {
+            if (t.is_leaf(kid[k])) continue;
+            const float a = box_area(t.box[kid[k]]);
+            if (a > best_area || best < 0) { best = k; best_area = a; }
+        }
+        if (best < 0) break;
+        const uint32_t id = kid[best];
+        kid[best] = t.left[id - t.n];
+        kid[nk++] = t.right[id - t.n];
+    }
+    // (Filling the slots that are still free with the halves of multi-triangle leaves -- 3.0 -> 3.9 children per node, the
+    // step tests four boxes either way -- was measured: 3 % fewer triangle tests, but more leaf visits, frame 2.67 -> 2.83 ms.)
+    float ar[4];
+    for (int k = 0; k < nk; k++) ar[k] = box_area(t.box[kid[k]]);
+    for (int i = 1; i < nk; i++)                       // insertion sort, larger surface first, stable
+        for (int j = i; j > 0 && ar[j] > ar[j - 1]; j--) {
+            const float ta = ar[j]; ar[j] = ar[j - 1]; ar[j - 1] = ta;
+            const uint32_t tk = kid[j]; kid[j] = kid[j - 1]; kid[j - 1] = tk;
+        }
+    uint32_t cnt = 0;
+    for (int k = 0; k < nk; k++)
+        if (!t.is_leaf(kid[k])) cnt++;
+    return cnt;
 }
 
-// one frontier element -> its (up to four) children, largest surface first; the workgroups' tallies of children that are
-// wide nodes themselves become the offsets of the next frontier, and the last workgroup writes the next level's size
+// one frontier element -> its children; the workgroups' tallies of children that are wide nodes themselves become the
+// offsets of the next frontier, and the last workgroup writes the next level's size
 __global__ void __launch_bounds__(WB) k_wide_expand(TreeView t, const uint32_t *__restrict__ frontier, WideState *__restrict__ ws, uint32_t lvl,
                                                     uint32_t *__restrict__ kids, uint32_t *__restrict__ tally, uint32_t fcap)
 {
     __shared__ uint32_t lds[WB];
     __shared__ uint32_t lds_flag;
+    if (lvl < ws->done) return;                         // k_wide_top has been here
     const WideLevel L = ws->level[lvl];
     if (L.count == 0) {                                 // past the last level of this tree: hand the end on
         if (blockIdx.x == 0 && threadIdx.x == 0) ws->level[lvl + 1] = L;
@@ -85,35 +113,9 @@ __global__ void __launch_bounds__(WB) k_wide_expand(TreeView t, const uint32_t *
     const uint32_t f = blockIdx.x * WB + threadIdx.x;
     uint32_t cnt = 0;
     if (f < L.count) {
-        const uint32_t b = frontier[f];
-        uint32_t kid[4] = {t.left[b - t.n], t.right[b - t.n], NO_KID, NO_KID};
-        int nk = 2;
-        while (nk < 4) {
-            int best = -1;
-            float best_area = -1.0f;
-            for (int k = 0; k < nk; k++) {
-                if (t.is_leaf(kid[k])) continue;
-                const float a = box_area(t.box[kid[k]]);
-                if (a > best_area || best < 0) { best = k; best_area = a; }
-            }
-            if (best < 0) break;
-            const uint32_t id = kid[best];
-            kid[best] = t.left[id - t.n];
-            kid[nk++] = t.right[id - t.n];
-        }
-        // (Filling the slots that are still free with the halves of multi-triangle leaves -- 3.0 -> 3.9 children per node, the
-        // step tests four boxes either way -- was measured: 3 % fewer triangle tests, but more leaf visits, frame 2.67 -> 2.83 ms.)
-        float ar[4];
-        for (int k = 0; k < nk; k++) ar[k] = box_area(t.box[kid[k]]);
-        for (int i = 1; i < nk; i++)                       // insertion sort, larger surface first, stable
-            for (int j = i; j > 0 && ar[j] > ar[j - 1]; j--) {
-                const float ta = ar[j]; ar[j] = ar[j - 1]; ar[j - 1] = ta;
-                const uint32_t tk = kid[j]; kid[j] = kid[j - 1]; kid[j - 1] = tk;
-            }
-        for (int k = 0; k < 4; k++) {
-            kids[4 * (size_t)f + k] = k < nk ? kid[k] : NO_KID;
-            if (k < nk && !t.is_leaf(kid[k])) cnt++;
-        }
+        uint32_t kid[4];
+        cnt = expand_node(t, frontier[f], kid);
+        for (int k = 0; k < 4; k++) kids[4 * (size_t)f + k] = kid[k];
     }
     uint32_t block_total;
     (void)rt_scan::block_exclusive<WB>(cnt, lds, block_total);
@@ -153,25 +155,11 @@ __device__ bool quantise_axis(const Box6 *cb, int nk, int axis, float origin, fl
     return ok;
 }
 
-__global__ void __launch_bounds__(WB) k_wide_emit(TreeView t, const uint32_t *__restrict__ frontier, const WideState *__restrict__ ws, uint32_t lvl,
-                                                  const uint32_t *__restrict__ kids, const uint32_t *__restrict__ tally,
-                                                  uint32_t *__restrict__ next_frontier, WNode *__restrict__ out)
+// writes wide node `base + f` for frontier node b with children kid[] (internal ones: bits of `internal`), whose own wide
+// nodes start at index `first_child` of the array and at position `next` of the next frontier
+__device__ __forceinline__ void emit_node(const TreeView &t, uint32_t b, const uint32_t kid[4], uint32_t internal, uint32_t node_index,
+                                          uint32_t next_level_base, uint32_t next, uint32_t *__restrict__ next_frontier, WNode *__restrict__ out)
 {
-    __shared__ uint32_t lds[WB / 64];
-    const WideLevel L = ws->level[lvl];
-    const uint32_t count = L.count, base = L.base;
-    if (blockIdx.x * WB >= count) return;
-    const uint32_t f = blockIdx.x * WB + threadIdx.x;
-    uint32_t kid[4] = {NO_KID, NO_KID, NO_KID, NO_KID}, internal = 0, mine = 0;
-    if (f < count)
-        for (int k = 0; k < 4; k++) {
-            kid[k] = kids[4 * (size_t)f + k];
-            if (kid[k] != NO_KID && !t.is_leaf(kid[k])) { internal |= 1u << k; mine++; }
-        }
-    uint32_t block_total;
-    uint32_t next = tally[blockIdx.x] + rt_scan::block_exclusive<WB>(mine, lds, block_total);
-    if (f >= count) return;
-    const uint32_t b = frontier[f];
     const Box6 nb = t.box[b];
     Box6 cb[4];
     int code[4];
@@ -185,7 +173,7 @@ __global__ void __launch_bounds__(WB) k_wide_emit(TreeView t, const uint32_t *__
         if (!((internal >> k) & 1u)) code[k] = t.leaf_code(id);
         else {
             next_frontier[next] = id;
-            code[k] = (int)(base + count + next);       // the next level starts right behind this one
+            code[k] = (int)(next_level_base + next);    // the next level starts right behind this one
             next++;
         }
     }
@@ -209,7 +197,71 @@ __global__ void __launch_bounds__(WB) k_wide_emit(TreeView t, const uint32_t *__
     w.q1 = make_float4(__uint_as_float(lo4[0]), __uint_as_float(hi4[0]), __uint_as_float(lo4[1]), __uint_as_float(hi4[1]));
     w.q2 = make_float4(__uint_as_float(lo4[2]), __uint_as_float(hi4[2]), scale[1], scale[2]);
     w.q3 = make_float4(__int_as_float(code[0]), __int_as_float(code[1]), __int_as_float(code[2]), __int_as_float(code[3]));
-    out[base + f] = w;
+    out[node_index] = w;
+}
+
+
+__global__ void __launch_bounds__(WB) k_wide_emit(TreeView t, const uint32_t *__restrict__ frontier, const WideState *__restrict__ ws, uint32_t lvl,
+                                                  const uint32_t *__restrict__ kids, const uint32_t *__restrict__ tally,
+                                                  uint32_t *__restrict__ next_frontier, WNode *__restrict__ out)
+{
+    __shared__ uint32_t lds[WB / 64];
+    if (lvl < ws->done) return;
+    const WideLevel L = ws->level[lvl];
+    const uint32_t count = L.count, base = L.base;
+    if (blockIdx.x * WB >= count) return;
+    const uint32_t f = blockIdx.x * WB + threadIdx.x;
+    uint32_t kid[4] = {NO_KID, NO_KID, NO_KID, NO_KID}, internal = 0, mine = 0;
+    if (f < count)
+        for (int k = 0; k < 4; k++) {
+            kid[k] = kids[4 * (size_t)f + k];
+            if (kid[k] != NO_KID && !t.is_leaf(kid[k])) { internal |= 1u << k; mine++; }
+        }
+    uint32_t block_total;
+    const uint32_t next = tally[blockIdx.x] + rt_scan::block_exclusive<WB>(mine, lds, block_total);
+    if (f >= count) return;
+    emit_node(t, frontier[f], kid, internal, base + f, base + count, next, next_frontier, out);
+}
+
+// The top of the tree in ONE workgroup: while a level has at most TOPW nodes, expand, number and emit it between two
+// barriers -- a level is ~6 dependent loads whatever its size, and as two launches each it cost 27 us.  Levels 0 .. 4
+// (4^4 = 256) are certain to be handled here; the per-level launches start behind them and skip whatever else this
+// kernel got to (ws->done).  (256 threads: the emit code wants 156 VGPRs, a 1024-thread workgroup would spill.)
+constexpr uint32_t TOPW = 256, TOP_SURE = 5;            // levels 0 .. TOP_SURE-1 have at most 4^l <= TOPW nodes
+__global__ void __launch_bounds__(TOPW) k_wide_top(TreeView t, uint32_t *__restrict__ frontier0, uint32_t *__restrict__ frontier1,
+                                                    WideState *__restrict__ ws, uint32_t root, uint32_t fcap, WNode *__restrict__ out)
+{
+    __shared__ uint32_t lds[TOPW / 64];
+    uint32_t *frontier[2] = {frontier0, frontier1};
+    uint32_t count = 1, base = 0, lvl = 0, error = 0;
+    if (threadIdx.x == 0) frontier0[0] = root;
+    __syncthreads();
+    while (count > 0 && count <= TOPW) {
+        const uint32_t f = threadIdx.x;
+        uint32_t kid[4] = {NO_KID, NO_KID, NO_KID, NO_KID}, internal = 0, mine = 0, b = 0;
+        if (f < count) {
+            b = frontier[lvl & 1u][f];
+            mine = expand_node(t, b, kid);
+            for (int k = 0; k < 4; k++)
+                if (kid[k] != NO_KID && !t.is_leaf(kid[k])) internal |= 1u << k;
+        }
+        uint32_t total;
+        const uint32_t next = rt_scan::block_exclusive<TOPW>(mine, lds, total);
+        if (f < count) emit_node(t, b, kid, internal, base + f, base + count, next, frontier[(lvl & 1u) ^ 1u], out);
+        if (threadIdx.x == 0) ws->level[lvl].count = count, ws->level[lvl].base = base;
+        base += count;
+        count = total;
+        lvl++;
+        if (lvl > RT_WIDE_MAX_LEVELS || count > fcap || (size_t)base + count > (size_t)t.n - 1) { error = lvl; count = 0; }
+        __syncthreads();                                // the next frontier is in global memory: written above, read below
+    }
+    if (threadIdx.x == 0) {
+        // (a tree that ends before level TOP_SURE -- where the per-level launches start -- has its end handed on to there)
+        for (uint32_t l = lvl; l <= (count == 0 && lvl < TOP_SURE ? TOP_SURE : lvl); l++) { ws->level[l].count = count; ws->level[l].base = base; }
+        ws->done = lvl;
+        ws->arrivals = 0;
+        ws->error = error;
+    }
 }
 
 // canonical LBVH (rt_bvh_node[2n-1] + leaf ranges) -> cluster numbering: leaf k -> id k, internal c -> id n + c
@@ -279,14 +331,16 @@ int rt_build_wide_layout(rt_context *ctx, BvhDev &bv, uint32_t n, uint32_t root,
     int rc = RT_OK;
     do {
         if ((rc = bv.wide.reserve(sizeof(WNode) * (size_t)(n - 1))) != RT_OK) break;
-        k_wide_init<<<1, 1, 0, st>>>(ws, frontier[0], root);
+        k_wide_top<<<1, TOPW, 0, st>>>(t, frontier[0], frontier[1], ws, root, (uint32_t)fcap, bv.wide.as<WNode>());
         // Levels are launched in batches without looking at their sizes: a level has at most four times the nodes of the
         // one before (and never more than fcap), a level past the end of the tree costs two empty launches.  The first
         // batch is sized for a tree half again as deep as a balanced one; the host reads the level table after each batch.
-        uint32_t lvl = 0, levels = 0, wide_n = 0;
-        uint64_t bound = 1;                                   // upper bound of the frontier at level lvl
+        // k_wide_top has certainly built levels 0 .. TOP_SURE-1 (a level has at most 4^l nodes, it takes every level of <= TOPW)
+        uint32_t lvl = TOP_SURE, levels = 0, wide_n = 0;
+        uint64_t bound = 4 * TOPW;                            // upper bound of the frontier at level lvl
         uint32_t batch = 6;
         for (uint32_t m = n; m > 1; m >>= 2) batch++;
+        batch = batch > TOP_SURE + 2 ? batch - TOP_SURE : 2; // (the first levels are k_wide_top's)
         if (ctx->build_batch) batch = ctx->build_batch;      // (tests: force short batches)
         WideState host_state;
         bool done = false;
