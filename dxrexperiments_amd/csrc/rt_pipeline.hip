@@ -93,6 +93,7 @@ struct PipeDev {
     float4 *accum;
     float4 *aov_direct, *aov_indirect;  // realtime pipeline outputs (RealtimeRaytracing.hlsl:3-4)
     uint32_t *counters;
+    unsigned long long *totals;         // running sums over frames (rt_pipeline_get_totals); updated by the frame's last kernel
     uint32_t *pools;            // chunk counters of the persistent launches: [1 + MAXD][RT_POOL_GROUPS], 128 B apart
     LevelDev lv[MAXD + 1];
 };
@@ -535,6 +536,10 @@ template <int STACK, bool TWO_LEVEL>
 __global__ void __launch_bounds__(PBLOCK) k_primary(PipeDev pd)
 {
     __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
+    // the frame's counters and chunk pools start at zero: its first kernel clears them (nothing here uses them, every later
+    // kernel of the frame does) instead of a 20-KB fill launch of its own
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < (uint32_t)(POOL_OFFSET_WORDS + POOL_BYTES / 4); i += PBLOCK) pd.counters[i] = 0u;
     PrimarySrc src = {pd};
     PrimarySink sink = {pd};
     trace_wave<STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, nullptr, smem, nullptr);   // one 8x8 tile per wave, dealt by the hardware dispatcher
@@ -794,10 +799,23 @@ __global__ void __launch_bounds__(PBLOCK) k_walk_shadow(SceneDev sc, QueueSrc sr
     trace_wave<RT_LDS_STACK_ROWS, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK, RT_SHADOW_UNORDERED != 0, true>(sc, src, sink, nullptr, smem, nullptr, walk);
 }
 
+// the frame's ray / hit counts into the running totals (one thread, once per frame)
+RT_DEV void add_totals(const uint32_t *__restrict__ counters, unsigned long long *__restrict__ totals, uint32_t cap)
+{
+    totals[0] += cap;
+    totals[1] += counters[C_SECONDARY];
+    totals[2] += counters[C_SHADOW] + counters[C_SHADOW_SKIPPED];
+    totals[6] += counters[C_SHADOW_SKIPPED];
+    totals[3] += counters[C_NHIT + 0];
+    for (int l = 1; l <= MAXD; l++) totals[4] += counters[C_NHIT + l];
+    totals[5] += 1;
+}
+
 template <int MAXL>
 __global__ void __launch_bounds__(PBLOCK) k_resolve(PipeDev pd)
 {
     const uint32_t q = blockIdx.x * PBLOCK + threadIdx.x;
+    if (q == 0) add_totals(pd.counters, pd.totals, pd.n_pixels);      // every counter of the frame is final when this kernel starts
     if (q >= pd.cap) return;
     uint32_t px, py;
     if (!pix_xy(pd, q, px, py)) return;
@@ -831,18 +849,6 @@ __global__ void __launch_bounds__(PBLOCK) k_resolve(PipeDev pd)
         o = make_float4((n * prev.x + cur.x) / n1, (n * prev.y + cur.y) / n1, (n * prev.z + cur.z) / n1, (n * prev.w + cur.w) / n1);
     }
     *dst = o;
-}
-
-__global__ void k_add_totals(const uint32_t *__restrict__ counters, unsigned long long *__restrict__ totals, uint32_t cap)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    totals[0] += cap;
-    totals[1] += counters[C_SECONDARY];
-    totals[2] += counters[C_SHADOW] + counters[C_SHADOW_SKIPPED];
-    totals[6] += counters[C_SHADOW_SKIPPED];
-    totals[3] += counters[C_NHIT + 0];
-    for (int l = 1; l <= MAXD; l++) totals[4] += counters[C_NHIT + l];
-    totals[5] += 1;
 }
 
 RT_DEV void wave_add64(unsigned long long v, unsigned long long *counter)
@@ -1035,7 +1041,6 @@ hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots
     if (levels <= 1) k_resolve<1><<<blocks(cap), PBLOCK, 0, st>>>(pd);
     else k_resolve<MAXD><<<blocks(cap), PBLOCK, 0, st>>>(pd);
     if (T) { record(ev[EV_RESOLVE], st); p->ring_levels[ring_slot] = (uint8_t)levels; p->ring_pos++; }
-    k_add_totals<<<1, 64, 0, st>>>(pd.counters, p->totals.as<unsigned long long>(), pd.n_pixels);
     return first_error;
 }
 
@@ -1333,7 +1338,7 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     }
     static_assert(C_COUNT <= POOL_OFFSET_WORDS, "scalar counters overlap the chunk pools");
     pd.pools = pd.counters + POOL_OFFSET_WORDS;
-    HIP_TRY(hipMemsetAsync(pd.counters, 0, POOL_OFFSET_WORDS * 4 + POOL_BYTES, st));
+    pd.totals = p->totals.as<unsigned long long>();
     // 18 LDS stack rows + the 8-row top table = 26 KiB per 256-thread block = 6 resident blocks per CU, whatever
     // the depth of the tree; the rare deeper walk continues in global rows (rt_trace_wave.h)
     HIP_TRY(ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST ? launch_frame_any<RT_LDS_STACK_ROWS_TEST>(p, pd, shadow_slots)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a rendered frame spends its time between kernels: reads the kernel trace rocprofv3 wrote for a bench run
 (rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 bench.py ...) and prints, averaged over the last frames
-(k_primary ... k_add_totals), the span, the time kernels are busy, the idle gaps, and every kernel's share."""
+(k_primary ... k_resolve), the span, the time kernels are busy, the idle gaps, and every kernel's share."""
 import csv
 import glob
 import sys
@@ -20,7 +20,7 @@ for s, e, k in rows:
         cur = []
     if cur is not None:
         cur.append((s, e, k))
-        if k == "k_add_totals":
+        if k == "k_resolve":
             frames.append(cur)
             cur = None
 frames = frames[-int(sys.argv[2]) if len(sys.argv) > 2 else -8:]
