@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(PBLOCK) k_primary(PipeDev pd)
 // thread remembers its CTILES flags in a bit mask), reserves its output range with ONE atomic, then writes tile after
 // tile in slot order -- same-address returning atomics serialise at ~11 ns, and one per 1024 slots (2,000 - 4,000 per
 // launch at 1080p) was most of this kernel's 36 us.
-constexpr int CTILES = 16;
+constexpr int CTILES = 8;            // (tiles per workgroup 4 / 8 / 16: 41 / 40 / 45 us for the frame's two compactions)
 __global__ void __launch_bounds__(CBLOCK) k_compact_level(PipeDev pd, int L)
 {
     __shared__ uint32_t wave_total[CBLOCK / 64];
