@@ -69,6 +69,7 @@ struct LevelDev {
     uint32_t *slot_j, *jlist;   // slot -> compact hit index (RT_NO_HIT if none), compact index -> slot
     uint32_t *pix;              // slot -> pixel slot q (unused at level 0)
     float4 *shO, *shD; uint32_t *vis;
+    float4 *color;              // deep paths (more than one radiance level): the shaded colour of every hit of this level, by slot
 };
 
 struct PipeDev {
@@ -498,6 +499,33 @@ struct ResolveIO {
     }
 };
 
+// The same pass for paths of more than one bounce, level by level from the deepest up (k_shade_level, then k_resolve_flat):
+// the colour of a secondary hit is not recomputed by compile-time recursion -- five nested shade() bodies cost 142 VGPRs,
+// three waves per SIMD -- but read from the colour buffer the pass of the level below has just written.  It is the value
+// the recursion would have produced (same function, same inputs), so the image does not change by a bit.
+struct LevelResolveIO {
+    const PipeDev &pd;
+    int L;
+    uint32_t idx;
+    RT_DEV LevelResolveIO(const PipeDev &p, int level, uint32_t i) : pd(p), L(level), idx(i) {}
+    RT_DEV float shadow(int s, f3, f3, float, float, uint32_t depth, bool matters)
+    {
+        if (depth >= pd.max_shadow) return 1.0f;
+        if (!matters && pd.skip_unlit) return 1.0f;
+        return pd.lv[L].vis[(size_t)s * hcap(pd, L) + idx] ? 1.0f : 0.0f;
+    }
+    RT_DEV f3 secondary(int w, f3, f3 d, float, uint32_t depth)
+    {
+        if (depth >= pd.max_rad || L >= MAXD) return mk3(0.0f, 0.0f, 0.0f);
+        const size_t slot = L == 0 ? (size_t)w * pd.cap + idx : idx;
+        const float4 h = pd.lv[L + 1].hit[slot];
+        if (h.x == HIT_MISS) return sample_environment(pd, d);             // PrimaryMiss, :160-164
+        if (h.x == HIT_UNTRACED) return mk3(0.0f, 0.0f, 0.0f);
+        const float4 c = pd.lv[L + 1].color[slot];
+        return mk3(c.x, c.y, c.z);
+    }
+};
+
 // ---- compaction ----------------------------------------------------------------------
 constexpr int CBLOCK = 1024;
 // every lane of the wave must call this (no early exits before it)
@@ -811,27 +839,12 @@ RT_DEV void add_totals(const uint32_t *__restrict__ counters, unsigned long long
     totals[5] += 1;
 }
 
-template <int MAXL>
-__global__ void __launch_bounds__(PBLOCK) k_resolve(PipeDev pd)
+// what the frame's last kernel does with the colour of pixel slot q (RayGen's tail, ProgressiveRaytracing.hlsl:36-38 /
+// RealtimeRaytracing.hlsl:44-45)
+RT_DEV void write_pixel(const PipeDev &pd, uint32_t px, uint32_t py, const Shaded &sh)
 {
-    const uint32_t q = blockIdx.x * PBLOCK + threadIdx.x;
-    if (q == 0) add_totals(pd.counters, pd.totals, pd.n_pixels);      // every counter of the frame is final when this kernel starts
-    if (q >= pd.cap) return;
-    uint32_t px, py;
-    if (!pix_xy(pd, q, px, py)) return;
-    const RayD r = primary_ray(pd, px, py);
-    const float4 h = pd.lv[0].hit[q];
-    Shaded sh;
-    if (h.x == HIT_MISS) {
-        sh.color = sample_environment(pd, r.d);             // PrimaryMiss
-        sh.aov_direct = sh.color;                           // RealtimeRaytracing.hlsl:119-126
-        sh.aov_indirect = mk3(0.0f, 0.0f, 0.0f);
-    } else {
-        ResolveIO<0, MAXL> io(pd, pd.lv[0].slot_j[q], px + py * pd.width);
-        sh = closest_hit_aov(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.lv[0].inst[q], 0u, px + py * pd.width);
-    }
     const size_t pixel = (size_t)py * pd.width + px;
-    if (pd.kind == RT_PIPELINE_REALTIME) {                  // RealtimeRaytracing.hlsl:44-45: two AOVs, no accumulation
+    if (pd.kind == RT_PIPELINE_REALTIME) {                  // two AOVs, no accumulation
         pd.aov_direct[pixel] = make_float4(fmax2(sh.aov_direct.x, 0.0f), fmax2(sh.aov_direct.y, 0.0f), fmax2(sh.aov_direct.z, 0.0f), 1.0f);
         pd.aov_indirect[pixel] = make_float4(fmax2(sh.aov_indirect.x, 0.0f), fmax2(sh.aov_indirect.y, 0.0f), fmax2(sh.aov_indirect.z, 0.0f), 1.0f);
         return;
@@ -849,6 +862,49 @@ __global__ void __launch_bounds__(PBLOCK) k_resolve(PipeDev pd)
         o = make_float4((n * prev.x + cur.x) / n1, (n * prev.y + cur.y) / n1, (n * prev.z + cur.z) / n1, (n * prev.w + cur.w) / n1);
     }
     *dst = o;
+}
+
+// FLAT = false: one bounce at most, the secondary hits are shaded inline (ResolveIO<0, 1>); FLAT = true: their colours
+// come from k_shade_level (LevelResolveIO)
+template <bool FLAT>
+__global__ void __launch_bounds__(PBLOCK) k_resolve(PipeDev pd)
+{
+    const uint32_t q = blockIdx.x * PBLOCK + threadIdx.x;
+    if (q == 0) add_totals(pd.counters, pd.totals, pd.n_pixels);      // every counter of the frame is final when this kernel starts
+    if (q >= pd.cap) return;
+    uint32_t px, py;
+    if (!pix_xy(pd, q, px, py)) return;
+    const RayD r = primary_ray(pd, px, py);
+    const float4 h = pd.lv[0].hit[q];
+    Shaded sh;
+    if (h.x == HIT_MISS) {
+        sh.color = sample_environment(pd, r.d);             // PrimaryMiss
+        sh.aov_direct = sh.color;                           // RealtimeRaytracing.hlsl:119-126
+        sh.aov_indirect = mk3(0.0f, 0.0f, 0.0f);
+    } else if (FLAT) {
+        LevelResolveIO io(pd, 0, pd.lv[0].slot_j[q]);
+        sh = closest_hit_aov(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.lv[0].inst[q], 0u, px + py * pd.width);
+    } else {
+        ResolveIO<0, 1> io(pd, pd.lv[0].slot_j[q], px + py * pd.width);
+        sh = closest_hit_aov(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.lv[0].inst[q], 0u, px + py * pd.width);
+    }
+    write_pixel(pd, px, py, sh);
+}
+
+// deep paths: the colour of every hit of level L >= 1 (its shadow rays are traced, the hits of level L + 1 already shaded)
+__global__ void __launch_bounds__(PBLOCK) k_shade_level(PipeDev pd, int L)
+{
+    const uint32_t idx = blockIdx.x * PBLOCK + threadIdx.x;
+    if (idx >= pd.counters[C_NHIT + L]) return;
+    const uint32_t slot = pd.lv[L].jlist[idx];
+    const uint32_t q = pd.lv[L].pix[slot];
+    uint32_t px, py;
+    (void)pix_xy(pd, q, px, py);
+    const RayD r = load_ray(pd.lv[L].O, pd.lv[L].D, slot);
+    const float4 h = pd.lv[L].hit[slot];
+    LevelResolveIO io(pd, L, idx);
+    const f3 c = closest_hit(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.lv[L].inst[slot], (uint32_t)L, px + py * pd.width);
+    pd.lv[L].color[slot] = make_float4(c.x, c.y, c.z, 0.0f);
 }
 
 RT_DEV void wave_add64(unsigned long long v, unsigned long long *counter)
@@ -943,7 +999,7 @@ struct rt_pipeline {
     uint32_t skip_unlit = 0;           // off by default: every shadow ray the reference traces is traversed (rt_pipeline_set_skip_unlit_shadow_rays)
     // queues (sized for `cap` pixels)
     uint32_t cap = 0, sh0_batches = 0, levels = 0;
-    struct LevelBuf { DevBuf O, D, hit, inst, slot_j, jlist, pix, shO, shD, vis; } lv[MAXD + 1];
+    struct LevelBuf { DevBuf O, D, hit, inst, slot_j, jlist, pix, shO, shD, vis, color; } lv[MAXD + 1];
     DevBuf counters;
     DevBuf half_out;
     std::vector<hipEvent_t> ring;      // EV_COUNT events per remembered frame
@@ -980,6 +1036,7 @@ int ensure_queues(rt_pipeline *p, uint32_t cap, uint32_t sh0_batches, uint32_t l
         RT_TRY(b.hit.reserve(slots * 16)); RT_TRY(b.inst.reserve(slots * 4));
         RT_TRY(b.slot_j.reserve(slots * 4)); RT_TRY(b.jlist.reserve(slots * 4));
         RT_TRY(b.shO.reserve(shadow * 16)); RT_TRY(b.shD.reserve(shadow * 16)); RT_TRY(b.vis.reserve(shadow * 4));
+        if (l > 0 && nl > 1) RT_TRY(b.color.reserve(slots * 16));          // deep paths only (k_shade_level)
     }
     p->cap = (uint32_t)c;
     p->sh0_batches = (uint32_t)sb;
@@ -1038,8 +1095,11 @@ hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots
     k_trace_shadow<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL>, PBLOCK, shadow_max), PBLOCK, 0, st>>>(
         pd.sc, shadows, pd.pools, &pd.counters[C_SHADOW]);
     if (T) record(ev[EV_SHADOW], st);
-    if (levels <= 1) k_resolve<1><<<blocks(cap), PBLOCK, 0, st>>>(pd);
-    else k_resolve<MAXD><<<blocks(cap), PBLOCK, 0, st>>>(pd);
+    if (levels <= 1) k_resolve<false><<<blocks(cap), PBLOCK, 0, st>>>(pd);      // (level by level is slower here: 0.143 vs 0.118 ms at 1080p)
+    else {
+        for (uint32_t l = levels; l >= 1; l--) k_shade_level<<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd, (int)l);
+        k_resolve<true><<<blocks(cap), PBLOCK, 0, st>>>(pd);
+    }
     if (T) { record(ev[EV_RESOLVE], st); p->ring_levels[ring_slot] = (uint8_t)levels; p->ring_pos++; }
     return first_error;
 }
@@ -1101,7 +1161,7 @@ int rt_pipeline_destroy(rt_pipeline *p)
     DevBuf *all[] = {&p->d_mats, &p->d_env, &p->accum_own, &p->aov_own, &p->counters, &p->half_out, &p->totals, &p->work};
     for (DevBuf *b : all) b->release();
     for (rt_pipeline::LevelBuf &l : p->lv) {
-        DevBuf *lb[] = {&l.O, &l.D, &l.hit, &l.inst, &l.slot_j, &l.jlist, &l.pix, &l.shO, &l.shD, &l.vis};
+        DevBuf *lb[] = {&l.O, &l.D, &l.hit, &l.inst, &l.slot_j, &l.jlist, &l.pix, &l.shO, &l.shD, &l.vis, &l.color};
         for (DevBuf *b : lb) b->release();
     }
     for (hipEvent_t e : p->ring) if (e) (void)hipEventDestroy(e);
@@ -1334,7 +1394,7 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
         LevelDev &d = pd.lv[l];
         d.O = b.O.as<float4>(); d.D = b.D.as<float4>(); d.hit = b.hit.as<float4>(); d.inst = b.inst.as<uint32_t>();
         d.slot_j = b.slot_j.as<uint32_t>(); d.jlist = b.jlist.as<uint32_t>(); d.pix = b.pix.as<uint32_t>();
-        d.shO = b.shO.as<float4>(); d.shD = b.shD.as<float4>(); d.vis = b.vis.as<uint32_t>();
+        d.shO = b.shO.as<float4>(); d.shD = b.shD.as<float4>(); d.vis = b.vis.as<uint32_t>(); d.color = b.color.as<float4>();
     }
     static_assert(C_COUNT <= POOL_OFFSET_WORDS, "scalar counters overlap the chunk pools");
     pd.pools = pd.counters + POOL_OFFSET_WORDS;
