@@ -82,6 +82,7 @@ SIGNATURES = {
     "rt_scene_instance_info": (_i, [_p, _u32, _p, _p]),
     "rt_scene_wide_info": (_i, [_p, _i, _pu, C.POINTER(C.c_int32), _pu]),
     "rt_scene_wide_read": (_i, [_p, _i, _p, _p]),
+    "rt_debug_wide_write": (_i, [_p, _i, _p, _u32]),
     "rt_scene_build_ms": (_i, [_p, C.POINTER(_f)]),
     "rt_trace_batch": (_i, [_p, _p, _p, _p, _sz, _u32, _u32, _u32, _p, _p, _p, _p, _p, _p, _p]),
     "rt_trace_last_ms": (_i, [_p, C.POINTER(_f)]),
@@ -362,6 +363,10 @@ class Scene:
         recs = np.empty((m.value, 12), np.float32)
         _check(lib().rt_scene_wide_read(self.h, which, _ptr(nodes), _ptr(recs)))
         return nodes, root.value, recs
+
+    def wide_write(self, nodes, which=0):
+        nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
+        _check(lib().rt_debug_wide_write(self.h, which, _ptr(nodes), nodes.shape[0]))
 
     def instance_info(self, i):
         box = np.empty(6, np.float32)

@@ -455,6 +455,16 @@ int rt_scene_wide_read(const rt_scene *s, int which, void *nodes, void *records)
     return RT_OK;
 }
 
+/* layout experiments (tools/layout_estimate.py): replaces the node array by a renumbering of itself */
+int rt_debug_wide_write(rt_scene *s, int which, const void *nodes, uint32_t n_nodes)
+{
+    const BvhDev *b = pick_bvh(s, which);
+    if (!b || !nodes || n_nodes != b->wide_n) { rt_set_error("rt_debug_wide_write: scene not built, or a different node count"); return RT_ERR_STATE; }
+    RT_TRY(use_device(s->ctx));
+    HIP_TRY(hipMemcpy(b->wide.p, nodes, sizeof(WNode) * (size_t)n_nodes, hipMemcpyHostToDevice));
+    return RT_OK;                                      // (same device pointers, same node count: nothing cached goes stale)
+}
+
 int rt_scene_instance_info(const rt_scene *s, uint32_t instance, float world_box[6], float world_to_object[12])
 {
     RT_REQUIRE(s, "null scene");

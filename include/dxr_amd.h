@@ -103,6 +103,9 @@ int rt_scene_instance_info(const rt_scene *s, uint32_t instance, float world_box
  * the uint32 primitive index, 8 B padding.  root_code: 0 = node 0, negative = the whole structure is one leaf. */
 int rt_scene_wide_info(const rt_scene *s, int which, uint32_t *n_nodes, int32_t *root_code, uint32_t *n_records);
 int rt_scene_wide_read(const rt_scene *s, int which, void *nodes, void *records);
+/* test / experiment hook: overwrite the node array with a RENUMBERING of itself (same count; node 0 stays the root and the
+ * first nodes the breadth-first top the traversal keeps in LDS).  Results do not depend on node numbers. */
+int rt_debug_wide_write(rt_scene *s, int which, const void *nodes, uint32_t n_nodes);
 /* milliseconds the last rt_scene_build spent on the GPU (BLAS + TLAS) */
 int rt_scene_build_ms(const rt_scene *s, float *ms);
 
