@@ -104,3 +104,33 @@ def test_short_build_batches_give_the_same_tree(gpu, capi, batch):
     assert root == want_root and np.array_equal(nodes, want_nodes) and np.array_equal(recs.view(np.uint32), want_recs.view(np.uint32))
     tn, tr, _ = sc.wide_read(-1)
     assert tn.shape[0] == 0 and tr == ~0
+
+
+def test_node_numbers_do_not_matter(gpu, capi):
+    """Results depend on the set of boxes and triangles a ray meets, not on where a node lives in the array.
+    The tree is read back, renumbered at random behind the LDS-resident top (child codes rewritten accordingly), written
+    back through rt_debug_wide_write, and the same rays must return the same hits, bit for bit."""
+    from util import ANY, random_rays
+    v, i = triangle_soup(20000, seed=77)
+    sc = build(capi, gpu, [(v, i)], [(0, None)])
+    O, D = random_rays(50000, 5, np.full(3, -10.0), np.full(3, 10.0))
+    want = sc.trace(O, D)
+    want_any = sc.trace(O, D, flags=ANY)
+    nodes, root, _ = sc.wide_read(0)
+    n = nodes.shape[0]
+    top = 128
+    assert n > 4 * top
+    r = np.random.default_rng(3)
+    perm = np.arange(n)
+    perm[top:] = top + r.permutation(n - top)               # old index -> new index
+    out = np.empty_like(nodes)
+    out[perm] = nodes
+    code = out[:, 12:16].view(np.int32)
+    m = code >= 0
+    code[m] = perm[code[m]]
+    sc.wide_write(out)
+    got = sc.trace(O, D)
+    got_any = sc.trace(O, D, flags=ANY)
+    for k in ("t", "u", "v", "prim", "inst"):
+        assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), k
+    assert np.array_equal(got_any["inst"] == 0xFFFFFFFF, want_any["inst"] == 0xFFFFFFFF)
