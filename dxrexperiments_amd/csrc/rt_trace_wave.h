@@ -249,7 +249,9 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 #endif
     const uint32_t total = src.count();
     const uint32_t flags = src.flags();
-    const bool first = (flags & RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH) != 0;
+    // ANYHIT instantiations (unordered walks) are only launched for ACCEPT_FIRST_HIT searches: as a compile-time fact it lets the
+    // running best hit -- which then never changes before the ray ends -- out of the registers
+    const bool first = ANYHIT ? true : (flags & RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH) != 0;
     const bool cull = (flags & RT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES) != 0;
     LaneStack<STACK, BLOCK> st;
     st.lds = smem + threadIdx.x;
@@ -366,7 +368,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 const uint32_t dl = distinct_node_lines(node, !((uint32_t)node < top_lim));
                 if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_read_exec())) wk_lines += dl;
             }
-            wide_step<false, ANYHIT>(nodes, topl, top_lim, cur.ri, r.tmin, best.t, st, node, sp);
+            wide_step<false, ANYHIT>(nodes, topl, top_lim, cur.ri, r.tmin, ANYHIT ? r.tmax : best.t, st, node, sp);
 #ifdef RT_TRACE_STATS
             st_maxsp = sp > st_maxsp ? sp : st_maxsp;
 #endif
@@ -383,7 +385,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 const uint32_t dl = distinct_node_lines(node, !((uint32_t)node < top_lim));
                 if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_read_exec())) wk_lines += dl;
             }
-            wide_step<true, ANYHIT>(nodes, topl, top_lim, cur.ri, r.tmin, best.t, st, node, sp);
+            wide_step<true, ANYHIT>(nodes, topl, top_lim, cur.ri, r.tmin, ANYHIT ? r.tmax : best.t, st, node, sp);
 #ifdef RT_TRACE_STATS
             st_maxsp = sp > st_maxsp ? sp : st_maxsp;
 #endif
@@ -399,7 +401,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 atomicAdd(&g_trace_sp_hist[st_maxsp < 63 ? st_maxsp : 63], 1ull);
                 st_maxsp = 0;
 #endif
-                sink.store(idx, best, true);
+                sink.store(idx, ANYHIT ? make_miss(r) : best, true);
                 alive = false;
                 pop = false;
                 if (COUNT) { const unsigned long long w = ((unsigned long long)(wk_glob + wk_top - wk_ray0) << 32) | idx; wk_longest = w > wk_longest ? w : wk_longest; }
@@ -437,9 +439,11 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     const char *tp = (const char *)(tris + first_tri + k);
                     const v4f a = ldg16(tp, 0), b = ldg16(tp, 16), c = ldg16(tp, 32);
                     const uint32_t prim = __float_as_uint(c.y);
-                    if (accept_candidate(*in, ii, prim, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), r, wri, cur, cull,
-                                         best) && first) {
-                        sink.store(idx, best, true);
+                    HitD found = ANYHIT ? make_miss(r) : best;          // (any-hit: the running best never changes before the ray ends)
+                    const bool accepted = accept_candidate(*in, ii, prim, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), r, wri, cur, cull, found);
+                    if (!ANYHIT) best = found;
+                    if (accepted && first) {
+                        sink.store(idx, found, true);
                         alive = false;
                         pop = false;
                         if (COUNT) { const unsigned long long w = ((unsigned long long)(wk_glob + wk_top - wk_ray0) << 32) | idx; wk_longest = w > wk_longest ? w : wk_longest; }
