@@ -58,6 +58,8 @@ def parse():
                     "committed profiles/<round>/traffic.json only")
     ap.add_argument("--hbm-frames", type=int, default=8, help="frames of the HBM-bound 10 M-triangle 4K workload timed for roofline_hbm "
                     "(rank 0, N=1 only); 0 = skip")
+    ap.add_argument("--batch", type=int, default=1, help="frames per rt_pipeline_render_batch call (1 = one render() per frame, the headline; "
+                    "up to 8 frames share one set of launches: the sample-batch mode of BASELINE configs[2])")
     ap.add_argument("--workload", choices=("c2", "c5"), default="c2", help="c5: ONLY the 10 M-triangle workload (profiling passes)")
     ap.add_argument("--partition", choices=("samples", "tiles"), default="samples",
                     help="samples (default, the headline): frames sharded over the GPUs, one all-reduce.  tiles: BASELINE configs[4], the "
@@ -458,12 +460,22 @@ def main():
     mine = D.shard_frames(rank, world, total_frames)
     pipe.set_accumulation_mode(T.ACCUM_SUM if world > 1 else T.ACCUM_RUNNING_MEAN)
 
+    S = max(1, args.batch)
+
     def step(i):
         pipe.update(pfcs[mine[i]])
         pipe.render()
 
-    for i in range(Wu):
-        step(i)
+    def steps(lo, hi):
+        """frames lo..hi-1 of this rank: one render() each, or rt_pipeline_render_batch calls of S frames"""
+        if S == 1:
+            for i in range(lo, hi):
+                step(i)
+        else:
+            for i in range(lo, hi, S):
+                pipe.render_batch([pfcs[mine[j]] for j in range(i, min(i + S, hi))])
+
+    steps(0, Wu)
     if world > 1:                       # warm the collective too
         dist.all_reduce(torch.zeros_like(acc))
     torch.cuda.synchronize()
@@ -475,8 +487,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(Wu, Wu + K):
-        step(i)
+    steps(Wu, Wu + K)
     if world > 1:
         mean, n_frames = D.reduce_accumulation(acc, Wu + K)
     torch.cuda.synchronize()
@@ -507,7 +518,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: Sponza-class procedural atrium (seed 42, %d triangles), %dx%d, 1 spp/frame "
                                    "progressive accumulation, reference default material/lights/options" % (tris.shape[0], W, H),
                        "frames_per_gpu": K, "parallelism": "sample-sharded x%d, one RCCL all-reduce of the fp32 accumulation buffer" % world
-                       if world > 1 else "single GPU", "accumulation": "sum+allreduce" if world > 1 else "running mean"},
+                       if world > 1 else "single GPU", "accumulation": "sum+allreduce" if world > 1 else "running mean",
+                       "frames_per_launch_set": S},
             "primary_mrays_per_s": primary_all / elapsed / 1e6,
             "frames_per_s": K * world / elapsed,
             "rays_per_frame": rays_all / (K * world),

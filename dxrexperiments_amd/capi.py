@@ -80,6 +80,7 @@ SIGNATURES = {
     "rt_scene_bvh_info": (_i, [_p, _i, _pu, _pu, _pu]),
     "rt_scene_bvh_read": (_i, [_p, _i, _p, _p, _p]),
     "rt_scene_instance_info": (_i, [_p, _u32, _p, _p]),
+    "rt_wide_layout_info": (_i, [_pu, _pu]),
     "rt_scene_wide_info": (_i, [_p, _i, _pu, C.POINTER(C.c_int32), _pu]),
     "rt_scene_wide_read": (_i, [_p, _i, _p, _p]),
     "rt_debug_wide_write": (_i, [_p, _i, _p, _u32]),
@@ -104,6 +105,7 @@ SIGNATURES = {
     "rt_pipeline_clear_output": (_i, [_p]),
     "rt_pipeline_update": (_i, [_p, _p]),
     "rt_pipeline_render": (_i, [_p, _u32, _u32]),
+    "rt_pipeline_render_batch": (_i, [_p, _u32, _u32, _p, _u32]),
     "rt_pipeline_render_tile": (_i, [_p, _u32, _u32, _u32, _u32, _u32, _u32]),
     "rt_pipeline_get_num_outputs": (_i, [_p, C.POINTER(_i)]),
     "rt_pipeline_get_output_device_ptr": (_i, [_p, _u32, _pp]),
@@ -196,6 +198,13 @@ def device_count():
     if n < 0:
         raise RtError(n, lib().rt_last_error().decode(errors="replace"))
     return n
+
+
+def wide_layout():
+    """(children per traversal node, bytes per node) of the loaded library: (4, 64), or (8, 128) for a -DRT_WIDE=8 build"""
+    w, b = C.c_uint32(), C.c_uint32()
+    _check(lib().rt_wide_layout_info(C.byref(w), C.byref(b)))
+    return w.value, b.value
 
 
 class Context:
@@ -355,11 +364,11 @@ class Scene:
         return nodes, keys, parents, md.value
 
     def wide_read(self, which=0):
-        """The production traversal layout: (nodes uint32[n, 16] (64-B four-wide nodes, raw words), root_code,
-        records float32[m, 12] (BLAS triangle records; empty for the TLAS))."""
+        """The production traversal layout: (nodes uint32[n, 16] (64-B four-wide nodes, raw words; [n, 32] from a library built
+        with -DRT_WIDE=8), root_code, records float32[m, 12] (BLAS triangle records; empty for the TLAS))."""
         n, root, m = C.c_uint32(), C.c_int32(), C.c_uint32()
         _check(lib().rt_scene_wide_info(self.h, which, C.byref(n), C.byref(root), C.byref(m)))
-        nodes = np.empty((n.value, 16), np.uint32)
+        nodes = np.empty((n.value, wide_layout()[1] // 4), np.uint32)
         recs = np.empty((m.value, 12), np.float32)
         _check(lib().rt_scene_wide_read(self.h, which, _ptr(nodes), _ptr(recs)))
         return nodes, root.value, recs
@@ -486,6 +495,13 @@ class Pipeline:
             _check(lib().rt_pipeline_render(self.h, self.width, self.height))
         else:
             _check(lib().rt_pipeline_render_tile(self.h, self.width, self.height, *tile))
+
+    def render_batch(self, constants):
+        """len(constants) frames = len x (update, render), bit for bit, through shared sets of launches (sample batches,
+        BASELINE configs[2]).  constants: a sequence of 188-byte per-frame constant buffers (as ProgressiveHost.update returns)."""
+        buf = np.ascontiguousarray(np.stack([np.frombuffer(np.asarray(c).tobytes(), np.uint8) for c in constants]))
+        assert buf.shape[1] == 188
+        _check(lib().rt_pipeline_render_batch(self.h, self.width, self.height, _ptr(buf), buf.shape[0]))
 
     def render_bands(self, band_rows, rank, world):
         """One frame over this rank's interleaved row bands (tile-partitioned multi-GPU runs)."""

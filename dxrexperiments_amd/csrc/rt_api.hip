@@ -140,6 +140,11 @@ static int context_create(int device, void *stream, bool own, rt_context **out)
         int v = atoi(lm);
         if (v >= 1 && v <= 8) c->leaf_max = (uint32_t)v;
     }
+    const char *wd = getenv("RT_WIDE_SAH");               // 1: surface-area-optimal collapse instead of the area-greedy one
+    if (wd) c->wide_sah = atoi(wd) != 0;
+    const char *cn = getenv("RT_SAH_NODE"), *cp = getenv("RT_SAH_PRIM");
+    if (cn && atof(cn) > 0.0) c->sah_node = (float)atof(cn);
+    if (cp && atof(cp) > 0.0) c->sah_prim = (float)atof(cp);
     *out = c;
     return RT_OK;
 }
@@ -442,6 +447,13 @@ int rt_scene_wide_info(const rt_scene *s, int which, uint32_t *n_nodes, int32_t 
     if (n_nodes) *n_nodes = b->wide_n;
     if (root_code) *root_code = b->root_code;
     if (n_records) *n_records = which < 0 ? 0u : b->n;
+    return RT_OK;
+}
+
+int rt_wide_layout_info(uint32_t *width, uint32_t *node_bytes)
+{
+    if (width) *width = RT_WIDE;
+    if (node_bytes) *node_bytes = (uint32_t)sizeof(WNode);
     return RT_OK;
 }
 

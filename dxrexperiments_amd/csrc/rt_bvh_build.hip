@@ -342,8 +342,8 @@ int lbvh_from_boxes(rt_context *ctx, BvhDev &bv, const Box6 *boxes, uint32_t n, 
 {
     hipStream_t st = ctx->stream;
     const unsigned B = 256;
-    // the traversal addresses a 64-B node as base + (index << 6) with a 32-bit byte offset (rt_trace_wave.h)
-    if (n > (1u << 26)) { rt_set_error("acceleration structure over %u primitives: the limit is 2^26 (67,108,864)", n); return RT_ERR_UNSUPPORTED; }
+    // the traversal addresses a 128-B node as base + (index << 7) with a 32-bit byte offset (rt_trace_wave.h)
+    if (n > (1u << 25)) { rt_set_error("acceleration structure over %u primitives: the limit is 2^25 (33,554,432)", n); return RT_ERR_UNSUPPORTED; }
     bv.n = n;
     RT_TRY(bv.nodes.reserve(sizeof(rt_bvh_node) * (2 * (size_t)n - 1)));
     RT_TRY(bv.keys.reserve(sizeof(uint64_t) * n));
@@ -438,10 +438,16 @@ int rt_build_blas(rt_context *ctx, rt_model *m)
             break;
         }
         // production traversal layout: re-cluster the same leaves with PLOC (rt_bvh_ploc.hip), then collapse the binary
-        // tree into four-wide quantised nodes (rt_bvh_wide.hip); tiny meshes and RT_FAST_BVH=lbvh collapse the LBVH itself
+        // tree into wide quantised nodes (rt_bvh_wide.hip); tiny meshes and RT_FAST_BVH=lbvh collapse the LBVH itself
         mark("gather");
         bool ploc_done = false;
-        if (ctx->use_ploc && (rc = rt_build_ploc_layout(ctx, m, &ploc_done)) != RT_OK) break;
+        if (ctx->use_ploc) {
+            rc = rt_build_ploc_layout(ctx, m, &ploc_done);
+            // PLOC's nearest-neighbour rounds make no progress on boxes whose surface is not finite (NaN / inf vertices,
+            // extents that overflow): such a mesh keeps the LBVH as its traversal layout (m->tris is still in LBVH order)
+            if (rc == RT_ERR_STATE) { rc = RT_OK; ploc_done = false; }
+            if (rc != RT_OK) break;
+        }
         mark("PLOC + wide layout");
         if (!ploc_done && (rc = rt_build_wide_from_lbvh(ctx, m->blas, false, ctx->leaf_max)) != RT_OK) break;
         mark("wide layout (LBVH)");

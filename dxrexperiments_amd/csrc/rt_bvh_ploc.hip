@@ -343,7 +343,7 @@ inline unsigned gr(size_t n) { return (unsigned)((n + PB - 1) / PB); }
 size_t rt_ploc_temp_bytes(uint32_t n)
 {
     const size_t nn2 = 2 * (size_t)n;
-    return 8 * (size_t)n + 2 * sizeof(Box6) * (size_t)n + 8 * (size_t)n + 8 * ((size_t)n / PB + 1) + 8 * (size_t)n + sizeof(Box6) * nn2 + 12 * nn2 +
+    return 8 * (size_t)n + 2 * sizeof(Box6) * (size_t)n + 8 * (size_t)n + 8 * ((size_t)n / PB + 1) + 64 * (size_t)n + 8 * (size_t)n + sizeof(Box6) * nn2 + 12 * nn2 +
            sizeof(PlocRound) * (PLOC_MAX_BATCH + 2) + 16 + 16 * 256;
 }
 
@@ -357,13 +357,15 @@ int rt_build_ploc_layout(rt_context *ctx, rt_model *m, bool *done)
     hipStream_t st = ctx->stream;
     // every temporary of the build is carved out of ONE allocation (hipMalloc / hipFree synchronise the
     // device and cost more than the kernels of a small build)
-    View cl_node[2], cl_box[2], nn, flags, tally, left, right, node_box, size, parent, offset, state;
+    View cl_node[2], cl_box[2], nn, flags, tally, wide_extra, left, right, node_box, size, parent, offset, state;
     int rc = RT_OK;
     do {
         const size_t nn2 = 2 * (size_t)n - 1;
         struct Want { View *v; size_t bytes; };
         const Want wants[] = {{&cl_node[0], 4 * (size_t)n}, {&cl_node[1], 4 * (size_t)n}, {&cl_box[0], sizeof(Box6) * (size_t)n}, {&cl_box[1], sizeof(Box6) * (size_t)n},
-                              {&nn, 4 * (size_t)n}, {&flags, 4 * (size_t)n}, {&tally, 8 * (size_t)gr(n)}, {&left, 4 * (size_t)(n - 1)}, {&right, 4 * (size_t)(n - 1)},
+                              {&nn, 4 * (size_t)n}, {&flags, 4 * (size_t)n}, {&tally, 8 * (size_t)gr(n)},
+                              {&wide_extra, 64 * (size_t)n},           // (only widens the slice the collapse uses as its scratch: rt_wide_temp_bytes)
+                              {&left, 4 * (size_t)(n - 1)}, {&right, 4 * (size_t)(n - 1)},
                               {&node_box, sizeof(Box6) * nn2}, {&size, 4 * nn2}, {&parent, 4 * nn2}, {&offset, 4 * nn2},
                               {&state, sizeof(PlocRound) * (PLOC_MAX_BATCH + 2) + 16}};
         size_t total = 0;
@@ -437,7 +439,7 @@ int rt_build_ploc_layout(rt_context *ctx, rt_model *m, bool *done)
         if (hipGetLastError() != hipSuccess) { rt_set_error("PLOC layout kernels failed"); rc = RT_ERR_HIP; break; }
         // four-wide nodes from the binary tree (root = the last node created); the cluster arrays of the rounds are free now
         // and serve as its scratch
-        if ((rc = rt_build_wide_layout(ctx, m->blas, n, 2 * n - 2, left.as<uint32_t>(), right.as<uint32_t>(), (const float *)node_box.p,
+        if ((rc = rt_build_wide_layout(ctx, m->blas, n, 2 * n - 2, left.as<uint32_t>(), right.as<uint32_t>(), parent.as<uint32_t>(), (const float *)node_box.p,
                                        size.as<uint32_t>(), offset.as<uint32_t>(), nullptr, ctx->leaf_max, cl_node[0].p,
                                        (size_t)((char *)left.p - (char *)cl_node[0].p))) != RT_OK) break;
         *done = true;

@@ -69,12 +69,10 @@ struct DevBuf {
 
 // ---- device-visible records -------------------------------------------------
 
-// One traversal node = FOUR children in one 64-B line (fetched as 4 x dwordx4): the chip delivers a fixed number of
-// distinct 64-B lines per second to divergent lanes whatever part of a line a lane reads (profiles/r02/slab_fetch.txt),
-// so a node must spend its one line on as many children as fit.  Child boxes are quantised to 8 bits per plane on a
-// grid anchored at the node's own box: plane = fma(q, scale, origin), the builder rounds lo planes down and hi planes up
-// WITH THIS SAME EXPRESSION until the decoded box contains the child's true box, so culling against it is conservative
-// and the candidate validation of rt_trace_device.h keeps every result bit-identical to the canonical definition.
+// One traversal node = FOUR children in one 64-B line (fetched as 4 x dwordx4).  Child boxes are quantised to 8 bits per plane
+// on a power-of-two grid anchored at the node's own box: plane = fma(q, scale, origin), the builder rounds lo planes down and
+// hi planes up WITH THIS SAME EXPRESSION until the decoded box contains the child's true box, so culling against it is
+// conservative and the candidate validation of rt_trace_device.h keeps every result bit-identical to the canonical definition.
 //   q0 = origin.x origin.y origin.z scale.x
 //   q1 = lo.x[4] hi.x[4] lo.y[4] hi.y[4]        (one byte per child, child k in bits 8k..8k+7)
 //   q2 = lo.z[4] hi.z[4] scale.y scale.z
@@ -82,8 +80,31 @@ struct DevBuf {
 // Child code: >= 0 index of an internal node of the same array; < 0 leaf: ~code = (first << 3) | (count-1) for a BLAS
 // (triangles first..first+count-1 of the sorted triangle array), or the instance index for the TLAS; RT_NODE_NONE for an
 // unused slot.  Nodes are numbered breadth first, so the first top_n nodes ARE the top of the tree (LDS resident in the
-// traversal kernels).  Slot order: larger surface first (any-hit rays walk unordered and try the likelier occluder first).
+// traversal kernels).  Children are packed at the front, larger surface first (any-hit rays walk unordered and try the
+// likelier occluder first); closest-hit rays sort the hit children by entry distance.  A scale of +inf (with q = 0 planes)
+// marks an axis the builder could not quantise: its planes decode to NaN and never cull.
+//
+// RT_WIDE = 8 (build option -DRT_WIDE=8; round 3's experiment, measured SLOWER and kept reproducible: DESIGN.md section 4,
+// profiles/r03/wide8_experiment.md): EIGHT children in one 128-B-aligned record of which the traversal reads 96 B,
+//   q0 = origin.xyz meta      meta = ex | ey << 8 | ez << 16 | valid << 24: biased exponents of the three scales (255: not
+//                             quantised) and the mask of the slots in use
+//   q1 = lo.x[0..3] lo.x[4..7] hi.x[0..3] hi.x[4..7]    q2, q3 = the same for y, z    q4 = code[0..3]    q5 = code[4..7]
+//   q6 = first internal child, internal-slot mask, source binary node, 0 (inspection only)    q7 = 0
+// The internal children of a node are consecutive in slot order.  Slots: the builder puts the child that lies towards
+// the (+,+,+) corner of the node in slot 7, towards (-,-,-) in slot 0, ... so that (slot XOR direction octant) ascending is
+// a front-to-back order and the traversal never sorts by distance (Ylitie, Karras, Laine 2017).
+#ifndef RT_WIDE
+#define RT_WIDE 4
+#endif
+#if RT_WIDE == 8
+struct __attribute__((aligned(128))) WNode { float4 q0, q1, q2, q3, q4, q5, q6, q7; };
+#define RT_NODE_SHIFT 7               // log2(sizeof(WNode))
+#define RT_TOP_WORDS 24               // ints of a node kept in LDS (the part the traversal reads)
+#else
 struct WNode { float4 q0, q1, q2, q3; };
+#define RT_NODE_SHIFT 6
+#define RT_TOP_WORDS 16
+#endif
 #define RT_NODE_NONE ((int)0x80000000)
 
 // One triangle in leaf order: the three ORIGINAL vertex positions (so that the
@@ -121,10 +142,14 @@ struct SceneDev {
 };
 
 #ifndef RT_TOP_NODES
-#define RT_TOP_NODES  128             // nodes of the LDS-resident top: 8 KiB of LDS per 256-thread block (with four-wide nodes the
-                                      //   size hardly matters: 32 .. 192 nodes all within 1 %; 256 nodes cost the stack rows: +3 %)
+#if RT_WIDE == 8
+#define RT_TOP_NODES  80              // nodes of the LDS-resident top, 96 B each (the part of a node the traversal reads): 7.5 KiB of
+                                      //   LDS per 256-thread block; levels 0 .. 2 of an eight-wide tree have at most 73 nodes
+#else
+#define RT_TOP_NODES  128             // 8 KiB (with four-wide nodes the size hardly matters: 32 .. 192 nodes all within 1 %)
 #endif
-#define RT_TOP_ROWS(BLOCK) (RT_TOP_NODES * 16 / (BLOCK))      // LDS rows (of BLOCK ints) the top table takes
+#endif
+#define RT_TOP_ROWS(BLOCK) ((RT_TOP_NODES * RT_TOP_WORDS + (BLOCK) - 1) / (BLOCK))      // LDS rows (of BLOCK ints) the top table takes
 
 // ---- host objects --------------------------------------------------------------
 
@@ -139,6 +164,9 @@ struct rt_context {
     float last_trace_ms = 0.0f;
     uint32_t leaf_max = 2;       // triangles per collapsed leaf in the traversal layout (RT_LEAF_MAX; 2 measured best: 1 4.05, 2 3.69, 3 3.80, 4 3.87, 8 4.23 ms/frame)
     bool use_ploc = true;        // RT_FAST_BVH=lbvh keeps the canonical LBVH as the traversal layout
+    bool wide_sah = false;       // RT_WIDE_SAH=1: the collapse into wide nodes minimises the surface-area cost (rt_bvh_wide.hip); default: area-greedy
+                                 //   (measured, profiles/r03/wide8_experiment.md: no faster on either layout)
+    float sah_node = 1.0f, sah_prim = 0.5f;     // cost of one wide-node step / one triangle test (RT_SAH_NODE, RT_SAH_PRIM)
     uint32_t cu_count = 256;     // compute units of the device
     uint32_t blocks_per_cu_override = 0;    // RT_PERSISTENT_BLOCKS_PER_CU: 0 = ask the occupancy API per kernel
     bool lds_top = true;                    // RT_LDS_TOP=0: every node comes from global memory
@@ -224,11 +252,11 @@ int rt_build_ploc_layout(rt_context *ctx, rt_model *m, bool *done);
 
 // rt_bvh_wide.hip: collapses a binary tree into the four-wide traversal layout (bv.wide, wide_n, fast_depth, root_code).
 // The binary tree is given in "cluster" numbering: leaves 0..n-1 in sorted-key order, internal nodes n..2n-2;
-// left / right are indexed by id - n; box6 = {lo[3], hi[3]} per id; size = leaves below; offset = leaves before (depth
+// left / right are indexed by id - n; parent by id (0xFFFFFFFF for the root); box6 = {lo[3], hi[3]} per id; size = leaves below; offset = leaves before (depth
 // first); leaf_prim (TLAS only) maps a leaf to its instance.  Temporaries come from the arena slice [tmp, tmp + tmp_bytes).
 size_t rt_wide_temp_bytes(uint32_t n);
 size_t rt_wide_lbvh_temp_bytes(uint32_t n);
-int rt_build_wide_layout(rt_context *ctx, BvhDev &bv, uint32_t n, uint32_t root, const uint32_t *left, const uint32_t *right,
+int rt_build_wide_layout(rt_context *ctx, BvhDev &bv, uint32_t n, uint32_t root, const uint32_t *left, const uint32_t *right, const uint32_t *parent,
                          const float *box6, const uint32_t *size, const uint32_t *offset, const uint32_t *leaf_prim, uint32_t leaf_max,
                          void *tmp, size_t tmp_bytes);
 // the same from the canonical LBVH arrays of bv (TLAS, tiny meshes, RT_FAST_BVH=lbvh)

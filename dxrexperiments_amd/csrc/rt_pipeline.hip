@@ -72,9 +72,24 @@ struct LevelDev {
     float4 *color;              // deep paths (more than one radiance level): the shaded colour of every hit of this level, by slot
 };
 
+// the frame's two light rays as the shadow-queue loader rebuilds them (QueueSrc::load)
+struct LightRays {
+    uint32_t on;
+    float dir_to_light[3];      // normalize(-directionalLight.forwardDir), computed once per frame on the host with the
+                                //   device's expression (IEEE sqrt and division, left-to-right sums, no contraction)
+    float point_pos[3];         // pointLight.worldPos
+};
+
+#define RT_MAX_BATCH 16u                // frames one set of launches renders (rt_pipeline_render_batch)
+
 struct PipeDev {
     SceneDev sc;
-    rt_per_frame_constants pfc;
+    rt_per_frame_constants pfc;         // the frame's constants (a batch: of its first frame; kernels take pfcs[frame])
+    // a BATCH of frames in one set of launches (config 3, rt_pipeline_render_batch): frame f owns the pixel slots
+    // [f * fcap, (f + 1) * fcap), every queue is n_frames times as long, a slot's frame selects constants and lights
+    uint32_t n_frames, fcap;            // single frame: 1, cap
+    const rt_per_frame_constants *pfcs; // device array [n_frames] (batches only)
+    const LightRays *frame_lights;      // device array [n_frames] (batches only)
     const rt_material_params *mats;
     uint32_t nmats;
     const float4 *env;
@@ -82,7 +97,7 @@ struct PipeDev {
     uint32_t env_filter;                // RT_CUBE_SEAMLESS / RT_CUBE_FACE_CLAMP
     float env_const[3];
     uint32_t width, height;
-    uint32_t x0, y0, tw, th, cap;       // tile rectangle; cap = tiles_x * tiles_y * 64 pixel slots
+    uint32_t x0, y0, tw, th, cap;       // tile rectangle; cap = n_frames * tiles_x * tiles_y * 64 pixel slots
     uint32_t tiles_x;
     uint32_t band_rows, band_rank, band_world;      // band_rows != 0: the rectangle's rows are interleaved bands of the image
     uint32_t n_pixels;                  // pixels of the image this launch covers
@@ -203,9 +218,8 @@ RT_DEV bool pix_xy(const PipeDev &pd, uint32_t q, uint32_t &px, uint32_t &py)
 }
 
 // ---- RayGen (ProgressiveRaytracing.hlsl:18-32)
-RT_DEV RayD primary_ray(const PipeDev &pd, uint32_t px, uint32_t py)
+RT_DEV RayD primary_ray(const PipeDev &pd, const rt_camera_params &cp, uint32_t px, uint32_t py)
 {
-    const rt_camera_params &cp = pd.pfc.cameraParams;
     const float dx = ((float)px + 0.5f) / (float)pd.width * 2.0f - 1.0f;
     const float dy = ((float)py + 0.5f) / (float)pd.height * 2.0f - 1.0f;
     const float js = pd.kind == RT_PIPELINE_REALTIME ? 10.0f : 30.0f;   // ProgressiveRaytracing.hlsl:26 / RealtimeRaytracing.hlsl:33
@@ -219,6 +233,16 @@ RT_DEV RayD primary_ray(const PipeDev &pd, uint32_t px, uint32_t py)
     r.tmin = 0.0f;
     r.tmax = RAY_MAX_T;
     return r;
+}
+RT_DEV RayD primary_ray(const PipeDev &pd, uint32_t px, uint32_t py) { return primary_ray(pd, pd.pfc.cameraParams, px, py); }
+
+// The frame a pixel slot belongs to, and the slot inside that frame (single frames: 0 and q itself)
+RT_DEV uint32_t slot_frame(const PipeDev &pd, uint32_t q, uint32_t &q_in_frame)
+{
+    if (pd.n_frames <= 1u) { q_in_frame = q; return 0u; }
+    const uint32_t f = q / pd.fcap;
+    q_in_frame = q - f * pd.fcap;
+    return f;
 }
 
 // ---- interpolateVertexAttributes (RaytracingCommon.hlsli:53-82), normal only
@@ -426,9 +450,10 @@ struct EmitIO {
     const PipeDev &pd;
     int L;
     uint32_t idx, q;            // compact hit index at level L, pixel slot
+    uint32_t frame;             // frame of the batch the hit belongs to (single frames: 0)
     uint32_t shadow_mask, skip_mask, sec_mask;
     f3 shadow_origin;           // compact shadow queues: the hit point both light rays start from
-    RT_DEV EmitIO(const PipeDev &p, int level, uint32_t i, uint32_t qq) : pd(p), L(level), idx(i), q(qq), shadow_mask(0), skip_mask(0), sec_mask(0)
+    RT_DEV EmitIO(const PipeDev &p, int level, uint32_t i, uint32_t qq, uint32_t f) : pd(p), L(level), idx(i), q(qq), frame(f), shadow_mask(0), skip_mask(0), sec_mask(0)
     {
         shadow_origin = mk3(0.0f, 0.0f, 0.0f);
     }
@@ -451,7 +476,7 @@ struct EmitIO {
     RT_DEV void finish_shadows(uint32_t shadow_slots) const
     {
         if (pd.shadow_compact) {
-            pd.lv[L].shO[idx] = make_float4(shadow_origin.x, shadow_origin.y, shadow_origin.z, __uint_as_float(shadow_mask | (skip_mask << 2)));
+            pd.lv[L].shO[idx] = make_float4(shadow_origin.x, shadow_origin.y, shadow_origin.z, __uint_as_float(shadow_mask | (skip_mask << 2) | (frame << 8)));
             return;
         }
         for (uint32_t s = 0; s < shadow_slots; s++)
@@ -544,9 +569,13 @@ struct PrimarySrc {
     RT_DEV uint32_t flags() const { return RT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES; }      // ProgressiveRaytracing.hlsl:34
     RT_DEV bool load(uint32_t q, RayD &r) const
     {
-        uint32_t px, py;
-        const bool valid = pix_xy(pd, q, px, py);
-        r = primary_ray(pd, px, py);
+        uint32_t px, py, ql;
+        // (64 consecutive slots = one tile = one chunk of a wave: the frame is the same for every lane that loads here)
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_frame(pd, q, ql));
+        const bool valid = pix_xy(pd, ql, px, py);
+        rt_camera_params cp = pd.pfc.cameraParams;
+        if (pd.n_frames > 1u) cp = pd.pfcs[f].cameraParams;
+        r = primary_ray(pd, cp, px, py);
         return valid;
     }
 };
@@ -630,28 +659,42 @@ __global__ void __launch_bounds__(CBLOCK) k_compact_level(PipeDev pd, int L)
 
 // closest-hit shading of the compacted hits of level L in emit mode: writes their shadow rays and the rays
 // of level L+1; slots a hit does not use are marked "not traced"
-template <bool PRIMARY>
-__global__ void __launch_bounds__(PBLOCK) k_shade_emit(PipeDev pd, int level, uint32_t shadow_slots, uint32_t emit_next)
+// BATCH: the launch covers several frames; a hit takes the constants of the frame its pixel slot lies in
+// (LC >= 0: the level as a compile-time constant.  The batch kernels work on a per-thread copy of the arguments whose pfc
+// they replace; with a run-time level the copy's lv[] would be indexed dynamically and live in scratch memory.)
+template <bool PRIMARY, bool BATCH, int LC>
+RT_DEV void shade_emit_body(const PipeDev &pd_arg, int level, uint32_t shadow_slots, uint32_t emit_next)
 {
-    const int L = PRIMARY ? 0 : level;          // (depth 0 compiles to its own kernel: it alone samples indirect diffuse)
+    PipeDev pd = pd_arg;
+    const int L = PRIMARY ? 0 : (LC >= 0 ? LC : level);          // (depth 0 compiles to its own kernel: it alone samples indirect diffuse)
     __builtin_assume(PRIMARY || L >= 1);
     const uint32_t idx = blockIdx.x * PBLOCK + threadIdx.x;
     if (idx >= pd.counters[C_NHIT + L]) return;
     const uint32_t slot = pd.lv[L].jlist[idx];
     const uint32_t q = L == 0 ? slot : pd.lv[L].pix[slot];
-    uint32_t px, py;
-    (void)pix_xy(pd, q, px, py);
+    uint32_t px, py, ql = q, frame = 0;
+    if (BATCH) { frame = slot_frame(pd, q, ql); pd.pfc = pd.pfcs[frame]; }
+    (void)pix_xy(pd, ql, px, py);
     const RayD r = L == 0 ? primary_ray(pd, px, py) : load_ray(pd.lv[L].O, pd.lv[L].D, slot);
     const float4 h = pd.lv[L].hit[slot];
-    EmitIO io(pd, L, idx, q);
+    EmitIO io(pd, L, idx, q, frame);
     (void)closest_hit(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.lv[L].inst[slot], (uint32_t)L, px + py * pd.width);
     io.finish_shadows(shadow_slots);
     if (emit_next) {
         if (L == 0) {
             for (uint32_t w = 0; w < 2; w++)
                 if (!(io.sec_mask & (1u << w))) store_invalid(pd.lv[1].O, pd.lv[1].D, (size_t)w * pd.cap + idx);
-        } else if (!io.sec_mask) store_invalid(pd.lv[L + 1].O, pd.lv[L + 1].D, idx);
+        } else if (L < MAXD && !io.sec_mask) store_invalid(pd.lv[L < MAXD ? L + 1 : MAXD].O, pd.lv[L < MAXD ? L + 1 : MAXD].D, idx);
     }
+}
+template <bool PRIMARY, bool BATCH>
+__global__ void __launch_bounds__(PBLOCK) k_shade_emit(PipeDev pd, int level, uint32_t shadow_slots, uint32_t emit_next)
+{
+    if (PRIMARY || !BATCH) shade_emit_body<PRIMARY, BATCH, -1>(pd, level, shadow_slots, emit_next);
+    else if (level == 1) shade_emit_body<PRIMARY, BATCH, 1>(pd, level, shadow_slots, emit_next);
+    else if (level == 2) shade_emit_body<PRIMARY, BATCH, 2>(pd, level, shadow_slots, emit_next);
+    else if (level == 3) shade_emit_body<PRIMARY, BATCH, 3>(pd, level, shadow_slots, emit_next);
+    else shade_emit_body<PRIMARY, BATCH, MAXD>(pd, level, shadow_slots, emit_next);
 }
 
 // a ray queue of `batches` batches of *count rays; batch b lives at [b*stride, b*stride + *count).
@@ -661,17 +704,12 @@ __global__ void __launch_bounds__(PBLOCK) k_shade_emit(PipeDev pd, int level, ui
 // expressions of evaluateDirectionalLight / evaluatePointLight (RaytracingCommon.hlsli:126-147; directional_light /
 // point_light above): 16 B written and read per hit instead of 128 B.  The four rays of the ambient-occlusion view have
 // random directions and keep the explicit origin / direction form.
-struct LightRays {
-    uint32_t on;
-    float dir_to_light[3];      // normalize(-directionalLight.forwardDir), computed once per frame on the host with the
-                                //   device's expression (IEEE sqrt and division, left-to-right sums, no contraction)
-    float point_pos[3];         // pointLight.worldPos
-};
 struct QueueSrc {
     const float4 *O, *D;
     const uint32_t *count_ptr;
     uint32_t stride, batches, fl;
     LightRays lights;
+    const LightRays *frame_lights;      // a batch of frames: the lights of frame f (bits 8.. of the hit's word); nullptr: `lights`
     RT_DEV uint32_t n() const { return *count_ptr; }
     RT_DEV uint32_t count() const { return n() * batches; }
     RT_DEV uint32_t flags() const { return fl; }
@@ -689,11 +727,13 @@ struct QueueSrc {
             if (!((bits >> b) & 1u)) return false;
             if ((bits >> (2u + b)) & 1u) { r.tmax = RT_TMAX_SKIPPED; return false; }
             r.tmin = RAY_EPSILON;
+            LightRays lt = lights;
+            if (frame_lights) lt = frame_lights[(bits >> 8) & 0xffu];
             if (b == 0u) {
-                r.d = mk3(lights.dir_to_light[0], lights.dir_to_light[1], lights.dir_to_light[2]);
+                r.d = mk3(lt.dir_to_light[0], lt.dir_to_light[1], lt.dir_to_light[2]);
                 r.tmax = RAY_MAX_T;
             } else {
-                const f3 path = mk3(lights.point_pos[0], lights.point_pos[1], lights.point_pos[2]) - r.o;
+                const f3 path = mk3(lt.point_pos[0], lt.point_pos[1], lt.point_pos[2]) - r.o;
                 const float dist = length(path);
                 r.d = normalize(path);
                 r.tmax = dist - RAY_EPSILON;
@@ -707,11 +747,11 @@ struct QueueSrc {
         return r.tmax > r.tmin;
     }
 };
-static inline LightRays light_rays(const PipeDev &pd)
+static inline LightRays light_rays(uint32_t shadow_compact, const rt_per_frame_constants &pfc)
 {
     LightRays l;
-    l.on = pd.shadow_compact;
-    const rt_float4 f = pd.pfc.directionalLight.forwardDir, w = pd.pfc.pointLight.worldPos;
+    l.on = shadow_compact;
+    const rt_float4 f = pfc.directionalLight.forwardDir, w = pfc.pointLight.worldPos;
     const float x = -f.x, y = -f.y, z = -f.z;              // normalize(): v * (1 / sqrt(dot(v, v))), dot summed left to right
     float d = x * x;
     d += y * y;
@@ -721,6 +761,7 @@ static inline LightRays light_rays(const PipeDev &pd)
     l.point_pos[0] = w.x; l.point_pos[1] = w.y; l.point_pos[2] = w.z;
     return l;
 }
+static inline LightRays light_rays(const PipeDev &pd) { return light_rays(pd.shadow_compact, pd.pfc); }
 static inline LightRays no_light_rays()
 {
     LightRays l;
@@ -828,15 +869,15 @@ __global__ void __launch_bounds__(PBLOCK) k_walk_shadow(SceneDev sc, QueueSrc sr
 }
 
 // the frame's ray / hit counts into the running totals (one thread, once per frame)
-RT_DEV void add_totals(const uint32_t *__restrict__ counters, unsigned long long *__restrict__ totals, uint32_t cap)
+RT_DEV void add_totals(const uint32_t *__restrict__ counters, unsigned long long *__restrict__ totals, uint32_t pixels, uint32_t frames)
 {
-    totals[0] += cap;
+    totals[0] += (unsigned long long)pixels * frames;
     totals[1] += counters[C_SECONDARY];
     totals[2] += counters[C_SHADOW] + counters[C_SHADOW_SKIPPED];
     totals[6] += counters[C_SHADOW_SKIPPED];
     totals[3] += counters[C_NHIT + 0];
     for (int l = 1; l <= MAXD; l++) totals[4] += counters[C_NHIT + l];
-    totals[5] += 1;
+    totals[5] += frames;
 }
 
 // what the frame's last kernel does with the colour of pixel slot q (RayGen's tail, ProgressiveRaytracing.hlsl:36-38 /
@@ -866,45 +907,65 @@ RT_DEV void write_pixel(const PipeDev &pd, uint32_t px, uint32_t py, const Shade
 
 // FLAT = false: one bounce at most, the secondary hits are shaded inline (ResolveIO<0, 1>); FLAT = true: their colours
 // come from k_shade_level (LevelResolveIO)
-template <bool FLAT>
-__global__ void __launch_bounds__(PBLOCK) k_resolve(PipeDev pd)
+template <bool FLAT, bool BATCH>
+__global__ void __launch_bounds__(PBLOCK) k_resolve(PipeDev pd_arg)
 {
-    const uint32_t q = blockIdx.x * PBLOCK + threadIdx.x;
-    if (q == 0) add_totals(pd.counters, pd.totals, pd.n_pixels);      // every counter of the frame is final when this kernel starts
-    if (q >= pd.cap) return;
+    PipeDev pd = pd_arg;
+    const uint32_t ql = blockIdx.x * PBLOCK + threadIdx.x;
+    if (ql == 0) add_totals(pd.counters, pd.totals, pd.n_pixels, pd.n_frames);      // every counter of the frame is final when this kernel starts
+    if (ql >= pd.fcap) return;
     uint32_t px, py;
-    if (!pix_xy(pd, q, px, py)) return;
-    const RayD r = primary_ray(pd, px, py);
-    const float4 h = pd.lv[0].hit[q];
-    Shaded sh;
-    if (h.x == HIT_MISS) {
-        sh.color = sample_environment(pd, r.d);             // PrimaryMiss
-        sh.aov_direct = sh.color;                           // RealtimeRaytracing.hlsl:119-126
-        sh.aov_indirect = mk3(0.0f, 0.0f, 0.0f);
-    } else if (FLAT) {
-        LevelResolveIO io(pd, 0, pd.lv[0].slot_j[q]);
-        sh = closest_hit_aov(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.lv[0].inst[q], 0u, px + py * pd.width);
-    } else {
-        ResolveIO<0, 1> io(pd, pd.lv[0].slot_j[q], px + py * pd.width);
-        sh = closest_hit_aov(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.lv[0].inst[q], 0u, px + py * pd.width);
+    if (!pix_xy(pd, ql, px, py)) return;
+    // a batch: the frames of a pixel one after the other, in frame order, so that the running mean is the one S single
+    // frames would have left (each frame with its own accumCount)
+    for (uint32_t f = 0; f < (BATCH ? pd.n_frames : 1u); f++) {
+        if (BATCH) pd.pfc = pd.pfcs[f];
+        const uint32_t q = f * pd.fcap + ql;
+        const RayD r = primary_ray(pd, px, py);
+        const float4 h = pd.lv[0].hit[q];
+        Shaded sh;
+        if (h.x == HIT_MISS) {
+            sh.color = sample_environment(pd, r.d);             // PrimaryMiss
+            sh.aov_direct = sh.color;                           // RealtimeRaytracing.hlsl:119-126
+            sh.aov_indirect = mk3(0.0f, 0.0f, 0.0f);
+        } else if (FLAT) {
+            LevelResolveIO io(pd, 0, pd.lv[0].slot_j[q]);
+            sh = closest_hit_aov(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.lv[0].inst[q], 0u, px + py * pd.width);
+        } else {
+            ResolveIO<0, 1> io(pd, pd.lv[0].slot_j[q], px + py * pd.width);
+            sh = closest_hit_aov(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.lv[0].inst[q], 0u, px + py * pd.width);
+        }
+        write_pixel(pd, px, py, sh);
     }
-    write_pixel(pd, px, py, sh);
 }
 
 // deep paths: the colour of every hit of level L >= 1 (its shadow rays are traced, the hits of level L + 1 already shaded)
-__global__ void __launch_bounds__(PBLOCK) k_shade_level(PipeDev pd, int L)
+template <bool BATCH, int LC>
+RT_DEV void shade_level_body(const PipeDev &pd_arg, int level)
 {
+    PipeDev pd = pd_arg;
+    const int L = LC >= 0 ? LC : level;
     const uint32_t idx = blockIdx.x * PBLOCK + threadIdx.x;
     if (idx >= pd.counters[C_NHIT + L]) return;
     const uint32_t slot = pd.lv[L].jlist[idx];
     const uint32_t q = pd.lv[L].pix[slot];
-    uint32_t px, py;
-    (void)pix_xy(pd, q, px, py);
+    uint32_t px, py, ql = q;
+    if (BATCH) pd.pfc = pd.pfcs[slot_frame(pd, q, ql)];
+    (void)pix_xy(pd, ql, px, py);
     const RayD r = load_ray(pd.lv[L].O, pd.lv[L].D, slot);
     const float4 h = pd.lv[L].hit[slot];
     LevelResolveIO io(pd, L, idx);
     const f3 c = closest_hit(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.lv[L].inst[slot], (uint32_t)L, px + py * pd.width);
     pd.lv[L].color[slot] = make_float4(c.x, c.y, c.z, 0.0f);
+}
+template <bool BATCH>
+__global__ void __launch_bounds__(PBLOCK) k_shade_level(PipeDev pd, int L)
+{
+    if (!BATCH) shade_level_body<BATCH, -1>(pd, L);
+    else if (L == 1) shade_level_body<BATCH, 1>(pd, L);
+    else if (L == 2) shade_level_body<BATCH, 2>(pd, L);
+    else if (L == 3) shade_level_body<BATCH, 3>(pd, L);
+    else shade_level_body<BATCH, MAXD>(pd, L);
 }
 
 RT_DEV void wave_add64(unsigned long long v, unsigned long long *counter)
@@ -939,9 +1000,9 @@ __global__ void __launch_bounds__(PBLOCK) k_count_primary(PipeDev pd, unsigned l
 {
     const uint32_t q = blockIdx.x * PBLOCK + threadIdx.x;
     unsigned long long rays = 0, nodes = 0, tris = 0;
-    uint32_t px, py;
-    if (q < pd.cap && pix_xy(pd, q, px, py)) {
-        const RayD r = primary_ray(pd, px, py);
+    RayD r;
+    const PrimarySrc src = {pd};
+    if (q < pd.cap && src.load(q, r)) {
         uint32_t cn, ct;
         (void)trace_canonical(pd.sc, r, RT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES, cn, ct);
         rays = 1; nodes = cn; tris = ct;
@@ -1004,6 +1065,8 @@ struct rt_pipeline {
     DevBuf half_out;
     std::vector<hipEvent_t> ring;      // EV_COUNT events per remembered frame
     std::vector<uint8_t> ring_levels;  // radiance levels each remembered frame ran
+    std::vector<uint8_t> ring_nframes; // frames each remembered entry covers (a batch is one entry)
+    DevBuf batch_consts;               // per-frame constants and light rays of a batch (rt_pipeline_render_batch)
     int ring_frames = 0;               // 0 = timing off
     uint64_t ring_pos = 0;             // frames recorded since enable / reset
     DevBuf totals, work;
@@ -1066,27 +1129,33 @@ hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots
     k_primary<STACK, TWO_LEVEL><<<blocks(cap), PBLOCK, 0, st>>>(pd);
     k_compact_level<<<(cap + CTILES * CBLOCK - 1) / (CTILES * CBLOCK), CBLOCK, 0, st>>>(pd, 0);
     if (T) record(ev[1], st);
-    k_shade_emit<true><<<blocks(cap), PBLOCK, 0, st>>>(pd, 0, shadow_slots, levels >= 1 ? 1u : 0u);
+    const bool B = pd.n_frames > 1u;            // a batch of frames: the shading kernels pick the constants of every hit's frame
+    if (B) k_shade_emit<true, true><<<blocks(cap), PBLOCK, 0, st>>>(pd, 0, shadow_slots, levels >= 1 ? 1u : 0u);
+    else k_shade_emit<true, false><<<blocks(cap), PBLOCK, 0, st>>>(pd, 0, shadow_slots, levels >= 1 ? 1u : 0u);
     if (T) record(ev[2], st);
     ShadowSrcN shadows;
     memset(&shadows, 0, sizeof shadows);
     const LightRays lr = light_rays(pd), none = no_light_rays();
-    shadows.q[0] = QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, shadow_slots, any, lr};     // RaytracingCommon.hlsli:94
+    const LightRays *fl = B ? pd.frame_lights : nullptr;
+    shadows.q[0] = QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, shadow_slots, any, lr, fl};     // RaytracingCommon.hlsli:94
     shadows.vis[0] = pd.lv[0].vis;
     shadows.nq = 1;
     size_t shadow_max = (size_t)cap * shadow_slots;
     for (uint32_t l = 1; l <= levels; l++) {
         // level 1: the diffuse and the specular batch of the primary hits; deeper: one ray per hit of level l-1
-        const QueueSrc rays = {pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE, none};   // ProgressiveRaytracing.hlsl:53
+        const QueueSrc rays = {pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE, none, nullptr};   // ProgressiveRaytracing.hlsl:53
         k_trace_secondary<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_secondary<STACK, TWO_LEVEL>, PBLOCK, (size_t)cap * 2), PBLOCK, 0, st>>>(
             pd.sc, rays, pd.lv[l].hit, pd.lv[l].inst, pd.pools + (size_t)l * RT_POOL_GROUPS * RT_POOL_STRIDE, &pd.counters[C_SECONDARY]);
         k_compact_level<<<(2 * cap + CTILES * CBLOCK - 1) / (CTILES * CBLOCK), CBLOCK, 0, st>>>(pd, (int)l);
         if (T) record(ev[3 + 2 * (l - 1)], st);
         const bool casts_shadows = l < pd.max_shadow, spawns = l < levels;
-        if (casts_shadows || spawns) k_shade_emit<false><<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd, (int)l, 2u, spawns ? 1u : 0u);
+        if (casts_shadows || spawns) {
+            if (B) k_shade_emit<false, true><<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd, (int)l, 2u, spawns ? 1u : 0u);
+            else k_shade_emit<false, false><<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd, (int)l, 2u, spawns ? 1u : 0u);
+        }
         if (T) record(ev[4 + 2 * (l - 1)], st);
         if (casts_shadows) {
-            shadows.q[shadows.nq] = QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any, lr};
+            shadows.q[shadows.nq] = QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any, lr, fl};
             shadows.vis[shadows.nq] = pd.lv[l].vis;
             shadows.nq++;
             shadow_max += (size_t)cap * 4;
@@ -1095,12 +1164,19 @@ hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots
     k_trace_shadow<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL>, PBLOCK, shadow_max), PBLOCK, 0, st>>>(
         pd.sc, shadows, pd.pools, &pd.counters[C_SHADOW]);
     if (T) record(ev[EV_SHADOW], st);
-    if (levels <= 1) k_resolve<false><<<blocks(cap), PBLOCK, 0, st>>>(pd);      // (level by level is slower here: 0.143 vs 0.118 ms at 1080p)
-    else {
-        for (uint32_t l = levels; l >= 1; l--) k_shade_level<<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd, (int)l);
-        k_resolve<true><<<blocks(cap), PBLOCK, 0, st>>>(pd);
+    // (resolve: one thread per pixel slot of ONE frame; a batch's frames are accumulated in order inside the thread)
+    if (levels <= 1) {                          // (level by level is slower here: 0.143 vs 0.118 ms at 1080p)
+        if (B) k_resolve<false, true><<<blocks(pd.fcap), PBLOCK, 0, st>>>(pd);
+        else k_resolve<false, false><<<blocks(pd.fcap), PBLOCK, 0, st>>>(pd);
+    } else {
+        for (uint32_t l = levels; l >= 1; l--) {
+            if (B) k_shade_level<true><<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd, (int)l);
+            else k_shade_level<false><<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd, (int)l);
+        }
+        if (B) k_resolve<true, true><<<blocks(pd.fcap), PBLOCK, 0, st>>>(pd);
+        else k_resolve<true, false><<<blocks(pd.fcap), PBLOCK, 0, st>>>(pd);
     }
-    if (T) { record(ev[EV_RESOLVE], st); p->ring_levels[ring_slot] = (uint8_t)levels; p->ring_pos++; }
+    if (T) { record(ev[EV_RESOLVE], st); p->ring_levels[ring_slot] = (uint8_t)levels; p->ring_nframes[ring_slot] = (uint8_t)pd.n_frames; p->ring_pos++; }
     return first_error;
 }
 
@@ -1122,13 +1198,14 @@ static int count_walk_launch(rt_pipeline *p, unsigned long long *w)
     const unsigned gq = rt_persistent_grid(ctx, k_walk_queue<TWO_LEVEL>, PBLOCK, (size_t)cap * 2);
     const unsigned gs = rt_persistent_grid(ctx, k_walk_shadow<TWO_LEVEL>, PBLOCK, (size_t)cap * 2);
     const LightRays lr = light_rays(pd), none = no_light_rays();
-    k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any, lr}, w + 7 * RT_STAGE_SHADOW0);
+    const LightRays *fl = pd.n_frames > 1u ? pd.frame_lights : nullptr;
+    k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any, lr, fl}, w + 7 * RT_STAGE_SHADOW0);
     const uint32_t levels = pd.max_rad < (uint32_t)MAXD ? pd.max_rad : (uint32_t)MAXD;
     for (uint32_t l = 1; l <= levels; l++) {
-        k_walk_queue<TWO_LEVEL><<<gq, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE, none},
+        k_walk_queue<TWO_LEVEL><<<gq, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE, none, nullptr},
                                                        w + 7 * RT_STAGE_SECONDARY);
         if (l < pd.max_shadow)
-            k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any, lr}, w + 7 * RT_STAGE_SHADOW1);
+            k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any, lr, fl}, w + 7 * RT_STAGE_SHADOW1);
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -1158,7 +1235,7 @@ int rt_pipeline_destroy(rt_pipeline *p)
     if (!p) return RT_OK;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    DevBuf *all[] = {&p->d_mats, &p->d_env, &p->accum_own, &p->aov_own, &p->counters, &p->half_out, &p->totals, &p->work};
+    DevBuf *all[] = {&p->d_mats, &p->d_env, &p->accum_own, &p->aov_own, &p->counters, &p->half_out, &p->totals, &p->work, &p->batch_consts};
     for (DevBuf *b : all) b->release();
     for (rt_pipeline::LevelBuf &l : p->lv) {
         DevBuf *lb[] = {&l.O, &l.D, &l.hit, &l.inst, &l.slot_j, &l.jlist, &l.pix, &l.shO, &l.shD, &l.vis, &l.color};
@@ -1326,13 +1403,16 @@ int rt_pipeline_update(rt_pipeline *p, const rt_per_frame_constants *constants)
 
 // one frame over the rectangle [x0,x1) x [y0,y1); band_rows != 0: over the interleaved bands {b : b mod band_world == band_rank}
 // of band_rows rows each (the rectangle then spans the full width and the rank's rows, packed)
+// frames / n_frames: the constants of the frames this set of launches renders (one: the last rt_pipeline_update)
 static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
-                         uint32_t band_rows, uint32_t band_rank, uint32_t band_world)
+                         uint32_t band_rows, uint32_t band_rank, uint32_t band_world, const rt_per_frame_constants *frames = nullptr, uint32_t n_frames = 1)
 {
     RT_REQUIRE(p, "null pipeline");
     if (!p->scene || !p->scene->built) { rt_set_error("render: acceleration structures not built"); return RT_ERR_STATE; }
     if (!p->accum) { rt_set_error("render: no output resource"); return RT_ERR_STATE; }
-    if (!p->have_pfc) { rt_set_error("render: update() has not been called"); return RT_ERR_STATE; }
+    if (!frames && !p->have_pfc) { rt_set_error("render: update() has not been called"); return RT_ERR_STATE; }
+    if (!frames) { frames = &p->pfc; n_frames = 1; }
+    RT_REQUIRE(n_frames >= 1 && n_frames <= RT_MAX_BATCH, "batch size");
     if (p->mats.empty()) { rt_set_error("render: no material"); return RT_ERR_STATE; }
     RT_REQUIRE(width == p->width && height == p->height, "width/height differ from the output resource");
     if (x1 > width) x1 = width;
@@ -1342,8 +1422,8 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     p->rendered = false;
-    // RayGen early-out (ProgressiveRaytracing.hlsl:14-16): nothing is traced or written
-    if (p->kind == RT_PIPELINE_PROGRESSIVE && p->pfc.cameraParams.accumCount >= p->pfc.options.maxIterations) {
+    // RayGen early-out (ProgressiveRaytracing.hlsl:14-16): nothing is traced or written (batches: the caller has dropped such frames)
+    if (p->kind == RT_PIPELINE_PROGRESSIVE && frames[0].cameraParams.accumCount >= frames[0].options.maxIterations) {
         memset(&p->stats, 0, sizeof p->stats);
         return RT_OK;
     }
@@ -1353,8 +1433,11 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
         p->mats_dirty = false;
     }
     const uint32_t tw = x1 - x0, th = y1 - y0;
-    const uint32_t tiles_x = (tw + 7u) / 8u, cap = tiles_x * ((th + 7u) / 8u) * 64u;
-    const uint32_t shadow_slots = (p->kind == RT_PIPELINE_PROGRESSIVE && p->pfc.options.showAmbientOcclusionOnly) ? 4u : 2u;
+    const uint32_t tiles_x = (tw + 7u) / 8u, fcap = tiles_x * ((th + 7u) / 8u) * 64u;
+    RT_REQUIRE((uint64_t)fcap * n_frames < 0x40000000ull, "batch: more than 2^30 pixel slots in one set of launches");
+    const uint32_t cap = fcap * n_frames;
+    const bool ao_view = p->kind == RT_PIPELINE_PROGRESSIVE && frames[0].options.showAmbientOcclusionOnly;
+    const uint32_t shadow_slots = ao_view ? 4u : 2u;
     RT_TRY(ensure_queues(p, cap, shadow_slots, frame_levels(p)));
     if (!p->totals.p) {
         RT_TRY(p->totals.reserve(8 * sizeof(unsigned long long)));
@@ -1363,7 +1446,24 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     PipeDev pd;
     // (threads of the largest launch: the primary stage runs one thread per pixel slot, the persistent stages fewer)
     RT_TRY(rt_scene_dev_for_launch(ctx, p->scene, rt_lds_stack_rows(ctx), cap > ctx->cu_count * 16u * PBLOCK ? cap : ctx->cu_count * 16u * PBLOCK, &pd.sc));
-    pd.pfc = p->pfc;
+    pd.pfc = frames[0];
+    pd.n_frames = n_frames; pd.fcap = fcap;
+    pd.pfcs = nullptr; pd.frame_lights = nullptr;
+    pd.shadow_compact = ao_view ? 0u : 1u;          // the AO view's four rays have random directions
+    if (n_frames > 1) {
+        // the batch's constants and light rays go to device memory: kernels index them by the frame of a slot
+        const size_t cb = sizeof(rt_per_frame_constants) * RT_MAX_BATCH, lb = sizeof(LightRays) * RT_MAX_BATCH;
+        RT_TRY(p->batch_consts.reserve(cb + lb));
+        std::vector<unsigned char> stage(cb + lb, 0);
+        for (uint32_t f = 0; f < n_frames; f++) {
+            memcpy(&stage[sizeof(rt_per_frame_constants) * f], &frames[f], sizeof(rt_per_frame_constants));
+            const LightRays lr = light_rays(pd.shadow_compact, frames[f]);
+            memcpy(&stage[cb + sizeof(LightRays) * f], &lr, sizeof lr);
+        }
+        HIP_TRY(hipMemcpyAsync(p->batch_consts.p, stage.data(), cb + lb, hipMemcpyHostToDevice, st));     // (pageable source: staged before the call returns)
+        pd.pfcs = p->batch_consts.as<rt_per_frame_constants>();
+        pd.frame_lights = (const LightRays *)((const char *)p->batch_consts.p + cb);
+    }
     pd.mats = p->d_mats.as<rt_material_params>();
     pd.nmats = (uint32_t)p->mats.size();
     pd.env = p->d_env.as<float4>();
@@ -1379,11 +1479,10 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
         for (uint32_t b = band_rank; (uint64_t)b * band_rows < height; b += band_world)
             owned_rows += (uint64_t)(b + 1) * band_rows <= height ? band_rows : height - b * band_rows;
     }
-    pd.n_pixels = tw * owned_rows;
+    pd.n_pixels = tw * owned_rows;                  // (per frame)
     pd.max_rad = p->max_rad; pd.max_shadow = p->max_shadow;
     pd.accum_mode = p->accum_mode;
     pd.skip_unlit = p->skip_unlit;
-    pd.shadow_compact = p->pfc.options.showAmbientOcclusionOnly ? 0u : 1u;     // the AO view's four rays have random directions
     pd.kind = p->kind;
     pd.accum = p->accum;
     pd.aov_direct = p->accum;                       // realtime: output 0 = direct lighting, output 1 = indirect specular
@@ -1408,7 +1507,7 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     p->last_shadow_slots = shadow_slots;
     p->last_scene_gen = p->scene->generation;
     p->last_tile[0] = x0; p->last_tile[1] = y0; p->last_tile[2] = x1; p->last_tile[3] = y1;
-    p->last_pixels = pd.n_pixels;
+    p->last_pixels = pd.n_pixels * n_frames;
     p->rendered = true;
     return RT_OK;
 }
@@ -1431,6 +1530,32 @@ int rt_pipeline_render_bands(rt_pipeline *p, uint32_t width, uint32_t height, ui
 int rt_pipeline_render(rt_pipeline *p, uint32_t width, uint32_t height)
 {
     return rt_pipeline_render_tile(p, width, height, 0, 0, width, height);
+}
+
+int rt_pipeline_render_batch(rt_pipeline *p, uint32_t width, uint32_t height, const rt_per_frame_constants *constants, uint32_t n)
+{
+    RT_REQUIRE(p && (constants || n == 0), "null argument");
+    RT_REQUIRE(p->kind == RT_PIPELINE_PROGRESSIVE, "render_batch: only the progressive pipeline accumulates frames");
+    uint32_t batch_max = RT_MAX_BATCH;
+    if (const char *e = getenv("RT_BATCH_MAX")) { const int v = atoi(e); if (v >= 1 && v <= (int)RT_MAX_BATCH) batch_max = (uint32_t)v; }
+    // frames RayGen would leave at once (accumCount >= maxIterations, ProgressiveRaytracing.hlsl:14-16) are dropped here;
+    // frames that disagree on what sizes the queues (the ambient-occlusion view) do not share a set of launches
+    std::vector<rt_per_frame_constants> run;
+    auto flush = [&]() -> int {
+        if (run.empty()) return RT_OK;
+        const int rc = render_region(p, width, height, 0, 0, width, height, 0, 0, 1, run.data(), (uint32_t)run.size());
+        run.clear();
+        return rc;
+    };
+    for (uint32_t i = 0; i < n; i++) {
+        const rt_per_frame_constants &c = constants[i];
+        if (c.cameraParams.accumCount >= c.options.maxIterations) continue;
+        if (!run.empty() && (run.size() >= batch_max || (run[0].options.showAmbientOcclusionOnly != 0) != (c.options.showAmbientOcclusionOnly != 0))) RT_TRY(flush());
+        run.push_back(c);
+    }
+    RT_TRY(flush());
+    if (n) { p->pfc = constants[n - 1]; p->have_pfc = true; }     // as after n x (update, render)
+    return RT_OK;
 }
 
 int rt_pipeline_get_num_outputs(const rt_pipeline *p, int *n)
@@ -1554,6 +1679,7 @@ int rt_pipeline_enable_timing(rt_pipeline *p, int frames)
     for (hipEvent_t e : p->ring) if (e) (void)hipEventDestroy(e);
     p->ring.assign((size_t)frames * EV_COUNT, nullptr);
     p->ring_levels.assign((size_t)frames, 0);
+    p->ring_nframes.assign((size_t)frames, 1);
     for (hipEvent_t &e : p->ring) HIP_TRY(hipEventCreate(&e));
     p->ring_frames = frames;
     p->ring_pos = 0;
@@ -1606,7 +1732,7 @@ int rt_pipeline_get_stats(rt_pipeline *p, rt_stats *out)
     out->rays_secondary = c[C_SECONDARY];
     out->rays_shadow = (uint64_t)c[C_SHADOW] + c[C_SHADOW_SKIPPED];
     out->rays_shadow_skipped = c[C_SHADOW_SKIPPED];
-    out->frames = 1;
+    out->frames = p->last_pd.n_frames;
     if (p->ring_frames > 0 && p->ring_pos > 0) {
         float ms[8];
         RT_TRY(stage_times(p, p->ring_pos - 1, ms));
@@ -1630,12 +1756,14 @@ int rt_pipeline_get_totals(rt_pipeline *p, rt_stats *out)
     out->frames = t[5];
     if (p->ring_frames > 0) {
         const uint64_t have = p->ring_pos < (uint64_t)p->ring_frames ? p->ring_pos : (uint64_t)p->ring_frames;
+        uint64_t covered = 0;
         for (uint64_t f = p->ring_pos - have; f < p->ring_pos; f++) {
             float ms[8];
             RT_TRY(stage_times(p, f, ms));
             add_times(out, ms);
+            covered += p->ring_nframes[(size_t)(f % (uint64_t)p->ring_frames)];
         }
-        if (have < out->frames) out->frames = have;      // times cover only the remembered frames
+        if (covered < out->frames) out->frames = covered;      // times cover only the remembered frames
     }
     return RT_OK;
 }
@@ -1664,16 +1792,17 @@ int rt_pipeline_count_work(rt_pipeline *p, rt_stage_work *out)
     const uint32_t any = RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH | RT_RAY_FLAG_SKIP_CLOSEST_HIT_SHADER;
     k_count_primary<<<blocks(cap), PBLOCK, 0, st>>>(pd, w + 3 * RT_STAGE_PRIMARY);
     const LightRays lr = light_rays(pd), none = no_light_rays();
-    k_count_queue<<<(blocks(cap) + 1) * ss, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any, lr},
+    const LightRays *fl = pd.n_frames > 1u ? pd.frame_lights : nullptr;
+    k_count_queue<<<(blocks(cap) + 1) * ss, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any, lr, fl},
                                                              w + 3 * RT_STAGE_SHADOW0);
     const uint32_t levels = pd.max_rad < (uint32_t)MAXD ? pd.max_rad : (uint32_t)MAXD;
     for (uint32_t l = 1; l <= levels; l++) {        // every secondary level adds into the same two rows
         const uint32_t batches = l == 1 ? 2u : 1u;
         k_count_queue<<<(blocks((size_t)cap * 2) + 1) * batches, PBLOCK, 0, st>>>(
-            pd.sc, QueueSrc{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, batches, RT_RAY_FLAG_NONE, none}, w + 3 * RT_STAGE_SECONDARY);
+            pd.sc, QueueSrc{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, batches, RT_RAY_FLAG_NONE, none, nullptr}, w + 3 * RT_STAGE_SECONDARY);
         if (l < pd.max_shadow)
             k_count_queue<<<(blocks((size_t)cap * 2) + 1) * 2, PBLOCK, 0, st>>>(
-                pd.sc, QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2 * cap, 2, any, lr}, w + 3 * RT_STAGE_SHADOW1);
+                pd.sc, QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2 * cap, 2, any, lr, fl}, w + 3 * RT_STAGE_SHADOW1);
     }
     HIP_TRY(hipGetLastError());
     unsigned long long h[RT_STAGE_COUNT * 3];

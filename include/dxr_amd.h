@@ -96,11 +96,28 @@ int rt_scene_destroy(rt_scene *s);
 int rt_scene_bvh_info(const rt_scene *s, int which, uint32_t *n_prims, uint32_t *n_nodes, uint32_t *max_depth);
 int rt_scene_bvh_read(const rt_scene *s, int which, rt_bvh_node *nodes, uint64_t *sorted_keys, uint32_t *parents);
 int rt_scene_instance_info(const rt_scene *s, uint32_t instance, float world_box[6], float world_to_object[12]);
-/* Inspection of the PRODUCTION traversal layout of the same structures (tests, tools): four-wide quantised nodes of 64 B
- * (float4 origin.xyz + scale.x | lo.x[4] hi.x[4] lo.y[4] hi.y[4] bytes | lo.z[4] hi.z[4] bytes, scale.y, scale.z | four
- * int32 child codes: >= 0 node index, INT32_MIN unused, otherwise ~code with code = instance (TLAS) or
- * first_record << 3 | (count - 1) (BLAS)), plane = fma(byte, scale, origin); BLAS records are 48 B: nine floats p0 p1 p2,
- * the uint32 primitive index, 8 B padding.  root_code: 0 = node 0, negative = the whole structure is one leaf. */
+/* Inspection of the PRODUCTION traversal layout of the same structures (tests, tools).  rt_wide_layout_info tells which
+ * of the two layouts the library was built with.
+ * width 4 (the default), 64-B nodes of 16 words:
+ *   w0..w2 float origin.xyz of the node's box, w3 float scale.x | w4 lo.x bytes of children 0..3 (child k in bits 8k..),
+ *   w5 hi.x, w6 lo.y, w7 hi.y | w8 lo.z, w9 hi.z, w10 float scale.y, w11 float scale.z | w12..w15 int32 child codes;
+ *   children packed at the front, larger surface first; plane = fma(byte, scale, origin); a scale of +inf (bytes 0) marks
+ *   an axis that is not quantised (non-finite extents): its planes bound nothing.
+ * width 8 (build option -DRT_WIDE=8), 128-B records of 32 words:
+ *   w0..w2  float origin.xyz
+ *   w3      ex | ey << 8 | ez << 16 | valid << 24: biased exponents of the three power-of-two scales (scale = 2^(e - 127);
+ *           e = 255: axis not quantised) and the mask of the slots that hold a child
+ *   w4,w5   lo.x bytes of slots 0..3, 4..7 (slot k in bits 8 (k mod 4) ...)    w6,w7   hi.x bytes
+ *   w8..w11 lo.y, hi.y likewise        w12..w15 lo.z, hi.z likewise
+ *   w16..w23 int32 child codes of slots 0..7
+ *   w24     index of the first internal child (the internal children of a node are consecutive, in slot order)
+ *   w25     mask of the slots that hold an internal child      w26 builder's binary node      w27..w31 zero
+ *   Slots: the child nearest the (-,-,-) corner of the node sits in slot 0, nearest (+,+,+) in slot 7 (bit a of the slot =
+ *   axis a positive); the traversal visits hit children in the order of slot XOR (sign bits of the ray direction).
+ * Child codes: >= 0 node index, INT32_MIN unused, otherwise ~code with code = instance (TLAS) or
+ * first_record << 3 | (count - 1) (BLAS).  BLAS records are 48 B: nine floats p0 p1 p2, the uint32 primitive index, 8 B
+ * padding.  root_code: 0 = node 0, negative = the whole structure is one leaf. */
+int rt_wide_layout_info(uint32_t *width, uint32_t *node_bytes);
 int rt_scene_wide_info(const rt_scene *s, int which, uint32_t *n_nodes, int32_t *root_code, uint32_t *n_records);
 int rt_scene_wide_read(const rt_scene *s, int which, void *nodes, void *records);
 /* test / experiment hook: overwrite the node array with a RENUMBERING of itself (same count; node 0 stays the root and the
@@ -176,6 +193,15 @@ int rt_pipeline_clear_output(rt_pipeline *p);
 int rt_pipeline_update(rt_pipeline *p, const rt_per_frame_constants *constants);
 /* render(cmdList, frameIndex, w, h) (.cpp:215-247): one 1-spp progressive frame. */
 int rt_pipeline_render(rt_pipeline *p, uint32_t width, uint32_t height);
+/* n frames = n x { update(&constants[i]); render(w, h) } with the same bits in the output, rendered through SHARED sets of
+ * launches (up to 16 frames each): the sample-batch mode of BASELINE configs[2] (256 spp accumulated).  The reference issues one
+ * DispatchRays per frame (src/ProgressiveRaytracingPipeline.cpp:188-195, :244) and RayGen folds each frame into gOutput
+ * with that frame's accumCount (assets/shaders/ProgressiveRaytracing.hlsl:36-38); here the rays of the frames of a batch
+ * share the ray queues (a slot's frame selects constants, lights and RNG seed), so the persistent traversal launches and
+ * their tails are paid once per batch, and the resolve kernel folds a pixel's frames in frame order -- the running mean is
+ * the one n single frames leave.  Frames with accumCount >= maxIterations are skipped (:14-16).  Progressive pipeline only;
+ * afterwards the pipeline's constants are constants[n - 1].  Queue memory grows with the batch (1080p: ~0.8 GB per frame). */
+int rt_pipeline_render_batch(rt_pipeline *p, uint32_t width, uint32_t height, const rt_per_frame_constants *constants, uint32_t n);
 /* same, restricted to pixel rectangle [x0,x1) x [y0,y1) (tile sharding) */
 int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height,
                             uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);

@@ -1,0 +1,134 @@
+"""rt_pipeline_render_batch: S frames through shared sets of launches == S x (update, render), bit for bit.
+
+The reference renders one DispatchRays per frame and folds it into gOutput with that frame's accumCount
+(src/ProgressiveRaytracingPipeline.cpp:188-195, assets/shaders/ProgressiveRaytracing.hlsl:36-38).  The batch mode (BASELINE
+configs[2]: 256 spp accumulated) puts the rays of up to 8 frames into the same queues; the image and the ray counts must
+not be able to tell.  Covered: partial batches, chunking beyond 8, multi-bounce paths (the level-by-level resolve), the
+debug / AO views (their own queue layouts), instanced two-level scenes, frames past maxIterations, SUM accumulation, and
+config 3 end to end on one device (8 logical shards x 32 frames)."""
+import numpy as np
+import pytest
+
+from dxrexperiments_amd import rtypes as T, scenes
+from test_gpu_pipeline import make_gpu_pipeline, rms
+from util import CORNELL_OBJ, cam_array, random_xforms, triangle_soup
+
+pytestmark = pytest.mark.gpu
+
+
+def frames_of(capi, cam, n, W, H, seed=7, options=None, first=1):
+    host = capi.ProgressiveHost(seed)
+    for k, v in (options or {}).items():
+        host.options[k] = v
+    return [host.update(cam, 0.0, first + f, W, H) for f in range(n)]
+
+
+def both_ways(p, pfcs):
+    p.clear_output()
+    p.reset_totals()
+    for c in pfcs:
+        p.update(c); p.render()
+    one_by_one, t1 = p.read_output(), p.totals()
+    p.clear_output()
+    p.reset_totals()
+    p.render_batch(pfcs)
+    batched, t2 = p.read_output(), p.totals()
+    assert np.array_equal(one_by_one, batched), "%d pixels differ" % int((one_by_one != batched).any(axis=2).sum())
+    for k in ("rays_primary", "rays_secondary", "rays_shadow", "rays_shadow_skipped", "primary_hits", "secondary_hits", "frames"):
+        assert t1[k] == t2[k], (k, t1[k], t2[k])
+    return batched
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 8, 11])
+def test_cornell_batches(gpu, capi, n):
+    W = H = 64
+    m = capi.Model(gpu, path=CORNELL_OBJ)
+    sc = capi.Scene(gpu)
+    sc.add_model(m)
+    p = capi.Pipeline(gpu)
+    p.set_scene(sc)
+    p.add_material(T.default_material())
+    p.set_environment_constant((0.5, 0.5, 0.5))
+    p.create_output(W, H)
+    p.build_acceleration_structures()
+    cam = cam_array(scenes.cornell_camera(), 1.0)
+    img = both_ways(p, frames_of(capi, cam, n, W, H))
+    assert img[..., 3].min() == 1.0 and img[..., 3].max() == 1.0
+
+
+@pytest.mark.parametrize("case", ["default", "four_bounces", "ao", "one_light", "skip_unlit", "sum"])
+def test_atrium_batches(gpu, capi, case):
+    """the bench scene's camera at 192x108 (an odd number of 8x8 tiles per row), 6 frames"""
+    W, H = 192, 108
+    v, i = scenes.sponza_class(seed=42)
+    mat = T.default_material()
+    if case == "four_bounces":
+        mat["type"] = 2; mat["reflectivity"] = 0.6; mat["roughness"] = 0.3
+    p = make_gpu_pipeline(capi, gpu, [(v, i)], [(0, None)], [mat], W, H, env=scenes.sky_cubemap(16))
+    opts = {"ao": {"showAmbientOcclusionOnly": 1}, "one_light": {"debug": 2}}.get(case)
+    if case == "four_bounces":
+        p.set_depth_limits(4, 3)
+    if case == "skip_unlit":
+        p.set_skip_unlit_shadow_rays(True)
+    if case == "sum":
+        p.set_accumulation_mode(T.ACCUM_SUM)
+    cam = cam_array(scenes.sponza_camera(), W / H)
+    both_ways(p, frames_of(capi, cam, 6, W, H, options=opts))
+
+
+def test_instanced_scene_and_changing_constants(gpu, capi):
+    """two-level walks; every frame of the batch with its own lights, options and camera jitter"""
+    W, H = 96, 64
+    blob = scenes.blob_mesh(level=2)
+    soup = triangle_soup(400, seed=4, extent=2.0, size=0.5)
+    xf = random_xforms(24, seed=11, spread=6.0)
+    mats = []
+    for k in range(24):
+        m = T.default_material()
+        m["type"] = k % 3
+        m["albedo"] = (0.2 + 0.03 * k, 0.9 - 0.03 * k, 0.3, 1.0)
+        mats.append(m)
+    p = make_gpu_pipeline(capi, gpu, [blob, soup], [(k % 2, xf[k]) for k in range(24)], mats, W, H, env=scenes.sky_cubemap(16))
+    cam = np.array([0, 2, 16, 0, 0, 0, 0, 1, 0, 0.8, W / H], np.float32)
+    pfcs = frames_of(capi, cam, 7, W, H)
+    for f, c in enumerate(pfcs):                         # every frame its own light set-up and environment strength
+        c["directionalLight"]["forwardDir"] = (0.3 - 0.1 * f, -0.2, -1.0 + 0.05 * f, 0.0)
+        c["pointLight"]["worldPos"] = (0.5 * f, 1.0, 2.0 - f, 1.0)
+        c["options"]["environmentStrength"] = 0.5 + 0.1 * f
+        c["options"]["cosineHemisphereSampling"] = f % 2
+    both_ways(p, pfcs)
+
+
+def test_frames_past_max_iterations_are_skipped(gpu, capi):
+    W = H = 48
+    v, i = triangle_soup(2000, seed=9)
+    p = make_gpu_pipeline(capi, gpu, [(v, i)], [(0, None)], [T.default_material()], W, H)
+    cam = np.array([0, 0, 25, 0, 0, 0, 0, 1, 0, 0.8, 1.0], np.float32)
+    pfcs = frames_of(capi, cam, 9, W, H, options={"maxIterations": 4})      # accumCount 0..8: frames 4.. leave RayGen at once
+    assert [int(c["cameraParams"]["accumCount"]) for c in pfcs][:5] == [0, 1, 2, 3, 4]
+    both_ways(p, pfcs)
+    assert p.totals()["frames"] == 4
+
+
+def test_config3_on_one_device_8_shards_of_32_frames(gpu, capi):
+    """BASELINE configs[2] end to end, one device standing in for eight: rank r renders frames {f : f mod 8 == r} of 256 into
+    a SUM buffer in batches; (sum of the eight sums) / 256 against the 256-frame running mean: <= 1e-5 RMS."""
+    W, H = 192, 108
+    v, i = scenes.sponza_class(seed=42)
+    p = make_gpu_pipeline(capi, gpu, [(v, i)], [(0, None)], [T.default_material()], W, H, env=scenes.sky_cubemap(16))
+    cam = cam_array(scenes.sponza_camera(), W / H)
+    N, R = 256, 8
+    pfcs = frames_of(capi, cam, N, W, H, seed=1234)
+    p.set_accumulation_mode(T.ACCUM_RUNNING_MEAN)
+    p.clear_output()
+    p.render_batch(pfcs)
+    mean = p.read_output()
+    p.set_accumulation_mode(T.ACCUM_SUM)
+    total = np.zeros_like(mean, dtype=np.float64)
+    for r in range(R):
+        p.clear_output()
+        p.render_batch(pfcs[r::R])
+        total += p.read_output()
+    shard_mean = (total / N).astype(np.float32)
+    assert rms(shard_mean, mean) <= 1e-5
+    assert shard_mean[..., 3].min() == 1.0 and np.isfinite(shard_mean).all()

@@ -372,7 +372,7 @@ def test_count_walk_is_the_production_walk(gpu, capi):
     for s in w1.values():
         assert s["instance_entries"] == 0                       # one identity instance: single-level walk
         assert s["nodes_global"] + s["nodes_lds"] >= s["rays"] // 2 and s["tris"] > 0
-        assert 0 < s["lines"] <= s["nodes_global"] + 2 * s["tris"]            # lanes of a wave share node lines
+        assert 0 < s["lines"] <= 2 * s["nodes_global"] + 2 * s["tris"]        # 64-B lines; lanes of a wave share node records (two lines each)
         assert 0 < s["longest_walk"] < 500
     assert w1["primary"]["nodes_lds"] > 0                       # the top of the tree is LDS resident
     assert w1["primary"]["lines"] < w1["primary"]["nodes_global"] + w1["primary"]["tris"] * 3 // 2    # primary rays of a tile share lines

@@ -1,0 +1,102 @@
+"""N-version check of the shading oracle (task 6).
+
+oracle/oracle_shade.h is the one restatement of RayGen -> PrimaryClosestHit -> shade() every GPU parity test leans on.
+tests/golden/nversion_shade.py is a SECOND restatement, written from the HLSL text alone in float32 numpy: brute-force
+intersection instead of a BVH, numpy's own transcendentals instead of the polynomial kernels, no code shared with oracle/
+or the product.  Here both render the Cornell box (32 x 32, two accumulated frames) under option / material sets that
+exercise every branch of shade(); primary hit ids must be identical and the images must agree to RMS <= 1e-5 (north_star's
+tolerance; ulp-level differences of the transcendentals are the only expected source).  The measured values of the
+authoring run are committed in tests/golden/reference_assets.json ("nversion_shading") and checked against as well, so a
+drift of either restatement shows."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, os.path.dirname(HERE))
+
+import nversion_shade as NV                              # noqa: E402
+from dxrexperiments_amd import rtypes as T, scenes       # noqa: E402
+
+W = H = 32
+
+CASES = {
+    "default": ({}, {}),
+    "uniform_hemisphere": ({"cosineHemisphereSampling": 0}, {}),
+    "debug2_one_light": ({"debug": 2}, {}),
+    "ambient_occlusion": ({"showAmbientOcclusionOnly": 1}, {}),
+    "ambient_occlusion_uniform": ({"showAmbientOcclusionOnly": 1, "cosineHemisphereSampling": 0}, {}),
+    "no_indirect_diffuse": ({"noIndirectDiffuse": 1}, {}),
+    "direct_only_view": ({"showDirectLightingOnly": 1}, {}),
+    "indirect_diffuse_view": ({"showIndirectDiffuseOnly": 1}, {}),
+    "indirect_specular_view": ({"showIndirectSpecularOnly": 1}, {}),
+    "fresnel_view": ({"showFresnelTerm": 1}, {}),
+    "albedo_view": ({"showGBufferAlbedoOnly": 1}, {}),
+    "diffuse_material": ({}, {"type": 0}),
+    "glass_rough_emissive": ({"environmentStrength": 0.25}, {"type": 2, "roughness": 0.9, "reflectivity": 0.3, "emissive": (0.2, 0.1, 0.4, 0.5)}),
+}
+
+
+def run_case(options, material):
+    from oracle import pyoracle as O
+    v, tri = O.obj_load(os.path.join(HERE, "golden", "cornell.obj"))
+    c = scenes.cornell_camera()
+    cam = np.array([*c["eye"], *c["at"], *c["up"], c["fov"], W / H], np.float32)
+    sc = O.Scene()
+    sc.add_instance(sc.add_model(v, tri))
+    sc.build()
+    nsc = NV.Scene(v["position"], v["normal"], tri)
+    mat = T.default_material()
+    for k, val in material.items():
+        mat[k] = val
+    host = O.Progressive(1234)
+    ob = np.frombuffer(host.options_buffer(), T.DEBUG_OPTIONS)
+    for k, val in options.items():
+        ob[k] = val
+    acc = np.zeros((H, W, 4), np.float32)
+    acc2 = acc.copy()
+    ids_equal = True
+    for frame in range(2):
+        pfc = host.update(cam, 0.0, frame + 1, W, H)
+        acc, _ = sc.render(mat, pfc, W, H, accum=acc, env_constant=(0.5, 0.5, 0.5))
+        pf = np.frombuffer(pfc.tobytes(), T.PER_FRAME_CONSTANTS)[0]
+        acc2, prim = NV.render_frame(nsc, pf, mat, W, H, acc2)
+        # the oracle's primary hits of the same rays (its BVH walk; ids must equal the brute-force ones)
+        o3, d3 = NV.primary_rays(pf, W, H)
+        o = np.concatenate([o3, np.zeros((W * H, 1), np.float32)], axis=1)
+        d = np.concatenate([d3, np.full((W * H, 1), 1.0e38, np.float32)], axis=1)
+        h = sc.trace(o, d, flags=T.RAY_FLAG_CULL_BACK_FACING_TRIANGLES, mode=0)
+        want = np.where(h["inst"] == T.RT_NO_HIT, -1, h["prim"].astype(np.int64))
+        ids_equal = ids_equal and np.array_equal(want, prim)
+    diff = acc2.astype(np.float64) - acc.astype(np.float64)
+    return {"rms": float(np.sqrt((diff ** 2).mean())), "max_abs": float(np.abs(diff).max()), "hit_ids_equal": bool(ids_equal),
+            "mean": float(acc[..., :3].mean())}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_second_restatement_agrees_with_the_oracle(name):
+    r = run_case(*CASES[name])
+    assert r["hit_ids_equal"], "primary hit ids differ between the oracle's BVH walk and brute force"
+    assert r["rms"] <= 1e-5, r
+    committed = json.load(open(os.path.join(HERE, "golden", "reference_assets.json")))["nversion_shading"][name]
+    assert abs(r["mean"] - committed["mean"]) <= 1e-5 and r["rms"] <= max(10 * committed["rms"], 1e-6), (r, committed)
+
+
+def test_the_cases_are_different_images():
+    """(the option switches really reach both restatements: the views are not all one picture)"""
+    committed = json.load(open(os.path.join(HERE, "golden", "reference_assets.json")))["nversion_shading"]
+    means = sorted(round(c["mean"], 4) for c in committed.values())
+    assert len(set(means)) >= len(means) - 2
+
+
+if __name__ == "__main__":                                  # authoring run: record the measured values
+    path = os.path.join(HERE, "golden", "reference_assets.json")
+    d = json.load(open(path))
+    d["nversion_shading"] = {k: run_case(*CASES[k]) for k in sorted(CASES)}
+    json.dump(d, open(path, "w"), indent=1, sort_keys=True)
+    for k, r in d["nversion_shading"].items():
+        print("%-28s rms %.3g max %.3g ids %s mean %.4f" % (k, r["rms"], r["max_abs"], r["hit_ids_equal"], r["mean"]))

@@ -51,8 +51,9 @@ def measure(name):
 measure("breadth first (as built)")
 nodes, root, _ = scene.wide_read(0)
 n = nodes.shape[0]
-code = nodes[:, 12:16].view(np.int32)
-TOP = 128
+TOP = 128 if capi.wide_layout()[0] == 4 else 80
+CODES = slice(12, 16) if capi.wide_layout()[0] == 4 else slice(16, 24)
+code = nodes[:, CODES].view(np.int32)
 t0 = time.time()
 new = np.full(n, -1, np.int64)
 new[:TOP] = np.arange(min(TOP, n))
@@ -71,18 +72,18 @@ assert nxt == n and (new >= 0).all()
 print("depth-first numbering of %d nodes in %.1f s" % (n, time.time() - t0))
 out = np.empty_like(nodes)
 out[new] = nodes
-oc = out[:, 12:16].view(np.int32)
+oc = out[:, CODES].view(np.int32)
 m = oc >= 0
 oc[m] = new[oc[m]]
 scene.wide_write(out)
-measure("depth first behind the top 128")
+measure("depth first behind the top")
 # control: a random permutation behind the top
 r = np.random.default_rng(1)
 perm = np.arange(n); perm[TOP:] = TOP + r.permutation(n - TOP)
 out2 = np.empty_like(nodes)
 out2[perm] = nodes
-oc2 = out2[:, 12:16].view(np.int32)
+oc2 = out2[:, CODES].view(np.int32)
 m = oc2 >= 0
 oc2[m] = perm[oc2[m]]
 scene.wide_write(out2)
-measure("random order behind the top 128 (control)")
+measure("random order behind the top (control)")

@@ -9,6 +9,13 @@
 //   2  per lane: 2 x dwordx4 (a 32-B node: what a compressed node would cost)
 //   3  per lane: 1 x dwordx4 (16 B)
 //   4  per lane: 4 x dwordx4 from FOUR different slabs (same bytes as 0, four times the cache lines)
+//   5  per lane: 8 x dwordx4 = all 128 B of ONE 128-B-aligned block (an eight-wide node that IS the L2 line / fabric request)
+//   6  per lane: the two 64-B halves of one 128-B block, the second half addressed only after the first has returned
+//      (what a node costs whose second line is a dependent fetch)
+//   7  per lane: 6 x dwordx4 = the first 96 B of one 128-B-aligned block (origin + 48 plane bytes + 8 child codes)
+//   8  per lane: 4 x dwordx4 = one 64-B slab, but at 128-B stride (a 64-B node in a 128-B slot: same lines per lane as 0,
+//      tells whether 5 pays for bytes or for lines)
+// Modes 5-8 index the table in 128-B blocks (half as many blocks in the same bytes).
 // Reported: ns per wave-step per CU and lane-slabs per ns for the whole chip.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -52,6 +59,27 @@ __global__ void __launch_bounds__(256) k(const float4 *table, unsigned n_slabs_m
         } else if (MODE == 3) {
             const unsigned off = idx << 6;
             a = ldg16(table, off); b = a; c = a; d = a;
+        } else if (MODE == 5) {
+            const unsigned off = (idx >> 1) << 7;
+            a = ldg16(table, off); b = ldg16(table, off + 16); c = ldg16(table, off + 32); d = ldg16(table, off + 48);
+            const v4f e = ldg16(table, off + 64), f = ldg16(table, off + 80), g = ldg16(table, off + 96), h = ldg16(table, off + 112);
+            a += e; b += f; c += g; d += h;
+        } else if (MODE == 6) {
+            const unsigned off = (idx >> 1) << 7;
+            a = ldg16(table, off); b = ldg16(table, off + 16); c = ldg16(table, off + 32); d = ldg16(table, off + 48);
+            // the second half's address depends on the first half's data (always +64, but the hardware cannot know)
+            const unsigned dep = (__float_as_uint(a.x) | __float_as_uint(d.w)) >> 31;        // 0 for this table (all values >= 0)
+            const unsigned off2 = off + 64u;
+            const v4f e = ldg16(table, off2 + dep), f = ldg16(table, off2 + 16 + dep), g = ldg16(table, off2 + 32 + dep), h = ldg16(table, off2 + 48 + dep);
+            a += e; b += f; c += g; d += h;
+        } else if (MODE == 7) {
+            const unsigned off = (idx >> 1) << 7;
+            a = ldg16(table, off); b = ldg16(table, off + 16); c = ldg16(table, off + 32); d = ldg16(table, off + 48);
+            const v4f e = ldg16(table, off + 64), f = ldg16(table, off + 80);
+            a += e; b += f;
+        } else if (MODE == 8) {
+            const unsigned off = (idx >> 1) << 7;
+            a = ldg16(table, off); b = ldg16(table, off + 16); c = ldg16(table, off + 32); d = ldg16(table, off + 48);
         } else {
             const unsigned off = idx << 6;
             a = ldg16(table, off); b = ldg16(table, (off + 0x40040u + 16) & ((n_slabs_mask << 6) | 63u));
@@ -99,5 +127,9 @@ int main(int argc, char **argv)
     run<2>("2 per lane 2 x 16 B", table, n_slabs - 1, out, blocks);
     run<3>("3 per lane 1 x 16 B", table, n_slabs - 1, out, blocks);
     run<4>("4 per lane 4 x 16 B (four slabs)", table, n_slabs - 1, out, blocks);
+    run<5>("5 per lane 8 x 16 B (one 128-B block)", table, n_slabs - 1, out, blocks);
+    run<6>("6 per lane 2 x 64 B, 2nd dependent", table, n_slabs - 1, out, blocks);
+    run<7>("7 per lane 6 x 16 B (96 of 128 B)", table, n_slabs - 1, out, blocks);
+    run<8>("8 per lane 4 x 16 B at 128-B stride", table, n_slabs - 1, out, blocks);
     return 0;
 }

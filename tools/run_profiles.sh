@@ -26,4 +26,26 @@ for w in $WL; do
   run tcc --kernel-trace --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
   run ea --kernel-trace --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_sum
   run sq --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
+  # the vector-memory path between the lanes and the L2 (round 3): L1 tag accesses, L1 -> L2 read requests and their summed
+  # latency, cycles the L1 waits for L2 data, address-unit busy cycles and the wave instructions it took
+  run tcp --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum
+  run ta --kernel-trace --pmc TA_TA_BUSY_sum TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum
+  run ta2 --kernel-trace --pmc TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum GRBM_GUI_ACTIVE
 done
+if [ -n "$CALIBRATE" ]; then
+  # the same counters on tools/microbench/slab_fetch (known lines per lane and launch): counter units per 64-B line / 128-B block
+  for n in tcp ta ta2; do
+    case $n in
+      tcp) C="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum";;
+      ta) C="TA_TA_BUSY_sum TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum";;
+      ta2) C="TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum GRBM_GUI_ACTIVE";;
+    esac
+    for sz in 131072 8388608; do
+      timeout 300 rocprofv3 --kernel-trace --pmc $C -d $OUT/slab_${sz}_$n -o p --output-format csv -- $R/tools/microbench/slab_fetch $sz 6 > $OUT/slab_${sz}_$n.log 2>&1
+      python3 $R/tools/profile_summary.py $OUT/slab_${sz}_$n "rocprofv3 --pmc $C -- tools/microbench/slab_fetch $sz 6 (launches: 100 warm-up iterations, then 2000 timed; 1536 workgroups of 256; one block index per lane and iteration)" > $OUT/slab_${sz}_$n.md
+      rm -rf $OUT/slab_${sz}_$n
+    done
+  done
+  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/slab_kt -o p --output-format csv -- $R/tools/microbench/slab_fetch 131072 6 > $OUT/slab_kt.log 2>&1
+  python3 $R/tools/profile_summary.py $OUT/slab_kt "rocprofv3 --kernel-trace --stats -- tools/microbench/slab_fetch 131072 6" > $OUT/slab_kt.md; rm -rf $OUT/slab_kt
+fi
