@@ -28,10 +28,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
-# Rate at which the chip serves uniformly random cache-resident rows to divergent lanes: MI355X_MICROARCH.md, "Indexed rows:
-# gather into LDS", 38 MB table (Infinity Cache): 33.5 GB/s per CU = 8.6 TB/s chip-wide.  tools/microbench/slab_fetch.hip
-# measures 7.5 TB/s for this engine's own access shape (one 64-B line per lane from an 8 MiB table, profiles/r02/slab_fetch.txt).
-GATHER_PEAK_GBS = 8600.0
+# Ceilings of the vector-memory path for this engine's access shape (every lane its own pseudo-random 64-B line), calibrated with
+# the counters of round 3 on tools/microbench/slab_fetch (profiles/r03/slab_131072_tcp.md + slab_kt.md, 8 MiB table):
+#   L1 -> L2 read requests: one per 64-B line a lane gathers (TCP_TCC_READ_REQ / lane-line = 0.996); the chip sustains
+#   120.6 G of them per second (mode 3: 411.26 M requests per 3409 us) = 7.7 TB/s of 64-B lines (round 2 measured 7.5);
+#   L1 tag accesses: one per 16-B load per lane (TCP_TOTAL_CACHE_ACCESSES / lane-load = 1.000), ceiling one per clock per CU.
+L2_REQUEST_PEAK_PER_S = 120.6e9
+GATHER_PEAK_GBS = L2_REQUEST_PEAK_PER_S * 64 / 1e9
+N_CU, N_SIMD, N_XCD = 256, 1024, 8
+VALU_ISSUE_CYCLES = 2.0        # a wave64 VALU instruction occupies a SIMD-32 for 2 cycles (MI355X_MICROARCH.md, "Wave scheduling")
 LINE_BYTES = 64
 RAY_BYTES, NODE_BYTES, TRI_BYTES = 48, 32, 36   # 32 B ray in + 16 B hit out; node; triangle
 # what the production kernels request per unit (DESIGN.md sections 3 / 4): one 64-B node per step that is not served by the
@@ -60,6 +65,11 @@ def parse():
                     "(rank 0, N=1 only); 0 = skip")
     ap.add_argument("--batch", type=int, default=1, help="frames per rt_pipeline_render_batch call (1 = one render() per frame, the headline; "
                     "up to 8 frames share one set of launches: the sample-batch mode of BASELINE configs[2])")
+    ap.add_argument("--obj", default=None, help="render this Wavefront OBJ instead of the procedural atrium (e.g. the real Sponza); "
+                    "config.workload then names the file and its triangle count")
+    ap.add_argument("--camera", type=float, nargs=6, default=None, metavar=("EX", "EY", "EZ", "AX", "AY", "AZ"),
+                    help="eye and look-at point for --obj (default: a view from outside the mesh's bounding box towards its centre)")
+    ap.add_argument("--fov", type=float, default=None, help="vertical field of view in radians for --obj (default pi/4, src/utils/Camera.h:141-144)")
     ap.add_argument("--workload", choices=("c2", "c5"), default="c2", help="c5: ONLY the 10 M-triangle workload (profiling passes)")
     ap.add_argument("--partition", choices=("samples", "tiles"), default="samples",
                     help="samples (default, the headline): frames sharded over the GPUs, one all-reduce.  tiles: BASELINE configs[4], the "
@@ -163,10 +173,15 @@ def committed_profile(workload):
     return {}
 
 
-LIVE_PMC_PASSES = {"ea": ["TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"], "write": ["WRITE_SIZE"]}
+LIVE_PMC_NOTES = []        # why a live pass was not used (the committed profile is the fallback; reported as roofline.traffic_fallback)
+LIVE_PMC_PASSES = {"ea": ["TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"], "write": ["WRITE_SIZE"],
+                   # round 3: what the SIMDs issue and where the waves' cycles go (SQ; GRBM_GUI_ACTIVE has slots of its own), and what
+                   # the lanes ask of the L1 and the L1 of the L2 (TCP)
+                   "sq": ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"],
+                   "tcp": ["TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"]}
 
 
-def live_traffic(workload, width, height, budget_s=90.0):
+def live_traffic(workload, width, height, budget_s=90.0, passes=("ea", "write", "sq", "tcp")):
     """Memory-side bytes per launch of the traversal kernels, measured IN THIS RUN: bench.py re-runs itself for a few frames
     as a child of `rocprofv3 --kernel-trace --pmc ...`, one pass for the L2's read requests by size (32 / 64 / 128 B: the
     calibrated byte count for this access shape, MI355X_MICROARCH.md HBM section) and one for WRITE_SIZE (they do not fit one
@@ -185,17 +200,22 @@ def live_traffic(workload, width, height, budget_s=90.0):
               else ["--workload", "c5", "--hbm-frames", "2"])
     out, t0 = {}, time.perf_counter()
     env = dict(os.environ, TMPDIR="/tmp")
-    for name, counters in LIVE_PMC_PASSES.items():
-        if time.perf_counter() - t0 > budget_s:
-            return {}
+    for name in passes:
+        counters = LIVE_PMC_PASSES[name]
+        left = budget_s - (time.perf_counter() - t0)
+        if left < 10.0:
+            LIVE_PMC_NOTES.append("%s/%s: budget of %.0f s spent before the pass" % (workload, name, budget_s))
+            break
         d = tempfile.mkdtemp(prefix="dxr_pmc_")
         try:
             # (the program itself directly behind `--`: the profiler's preloaded library initialises the GPU first)
             r = subprocess.run([exe, "--kernel-trace", "--pmc"] + counters + ["-d", d, "-o", "p", "--output-format", "csv", "--",
-                                sys.executable, *child], cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                                sys.executable, *child], cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=min(240.0, left))
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
-                return {}
+                LIVE_PMC_NOTES.append("%s/%s: rocprofv3 exit code %d, %d counter files" % (workload, name, r.returncode, len(files)))
+                break
             acc = {}
             for f in files:
                 for row in csv.DictReader(open(f)):
@@ -207,15 +227,27 @@ def live_traffic(workload, width, height, budget_s=90.0):
             for (k, c), (n, v) in acc.items():
                 out.setdefault(k, {})[c] = v / n
                 out[k]["dispatches"] = n
-        except (OSError, subprocess.SubprocessError, KeyError, ValueError):
-            return {}
+            if name == "sq":                 # the same pass's launch durations: with GRBM_GUI_ACTIVE they give the clock under this load
+                dur = {}
+                for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        k = next((k for k in ("k_trace_secondary", "k_trace_shadow", "k_primary") if k in row["Kernel_Name"]), None)
+                        if k:
+                            a = dur.setdefault(k, [0, 0.0])
+                            a[0] += 1
+                            a[1] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                for k, (n, ns) in dur.items():
+                    out.setdefault(k, {})["sq_pass_avg_us"] = ns / n / 1e3
+        except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
+            LIVE_PMC_NOTES.append("%s/%s: %s" % (workload, name, type(e).__name__))
+            break
         finally:
             shutil.rmtree(d, ignore_errors=True)
     for k, e in out.items():
         if all(c in e for c in LIVE_PMC_PASSES["ea"]) and "WRITE_SIZE" in e:
             e["read_bytes_by_request_size"] = int(32 * e["TCC_EA0_RDREQ_32B_sum"] + 64 * e["TCC_EA0_RDREQ_64B_sum"] + 128 * e["TCC_EA0_RDREQ_128B_sum"])
             e["bytes_per_launch"] = int(e["read_bytes_by_request_size"] + e["WRITE_SIZE"] * 1024)      # rocprofv3 reports WRITE_SIZE in KiB
-    return {k: e for k, e in out.items() if "bytes_per_launch" in e}
+    return out         # (a pass that failed leaves its counters out: the committed profile fills in, roofline.traffic_fallback says why)
 
 
 def walk_bytes(stage, w):
@@ -261,7 +293,7 @@ def stage_table(pipe, tot, with_canonical=True, levels=1):
     return stages, n_t
 
 
-def hbm_workload(ctx, capi, T, scenes, frames, warm):
+def hbm_workload(ctx, capi, T, scenes, frames, warm, batch=1):
     """The one configuration whose traversal working set (~0.8 GB of slabs + triangle records) does not fit the 256 MB
     Infinity Cache: BASELINE configs[4], the 10 M-triangle mesh at 3840x2160 with 4 radiance bounces (SURVEY 7 "Roofline
     honesty").  Rendered on the same context after the headline measurement; returns the stage table of `frames` frames."""
@@ -287,16 +319,24 @@ def hbm_workload(ctx, capi, T, scenes, frames, warm):
     host = capi.ProgressiveHost(3)
     host.options["maxIterations"] = 1 << 20
     cam = capi.camera_array((0.0, 6.0, 19.0), (0.0, -4.0, 0.0), (0, 1, 0), 0.8, W / H)
-    for f in range(warm):
-        pipe.update(host.update(cam, 0.0, f + 1, W, H))
-        pipe.render()
+    if batch <= 1:
+        for f in range(warm):
+            pipe.update(host.update(cam, 0.0, f + 1, W, H))
+            pipe.render()
+    else:                   # (the first batch sizes the queues for `batch` frames: not part of the timed region)
+        pipe.render_batch([host.update(cam, 0.0, f + 1, W, H) for f in range(max(warm, batch))])
+        warm = max(warm, batch)
     ctx.synchronize()
     pipe.enable_timing(frames)
     pipe.reset_totals()
     t0 = time.perf_counter()
-    for f in range(warm, warm + frames):
-        pipe.update(host.update(cam, 0.0, f + 1, W, H))
-        pipe.render()
+    if batch <= 1:
+        for f in range(warm, warm + frames):
+            pipe.update(host.update(cam, 0.0, f + 1, W, H))
+            pipe.render()
+    else:
+        for f0 in range(warm, warm + frames, batch):
+            pipe.render_batch([host.update(cam, 0.0, f + 1, W, H) for f in range(f0, min(f0 + batch, warm + frames))])
     ctx.synchronize()
     dt = time.perf_counter() - t0
     tot = pipe.totals()
@@ -307,6 +347,34 @@ def hbm_workload(ctx, capi, T, scenes, frames, warm):
             "frames": frames, "ms_per_frame": dt / frames * 1e3, "Mrays_per_s": rays / dt / 1e6, "rays_per_frame": rays / frames,
             "bvh_build_ms": scene.build_ms(), "generate_s": gen_s, "stages": stages, "launches_timed": n_t}
 
+
+
+def rank_report(torch, dist, ctx, rank, world, local_rank, dev, backend, elapsed, collective_ms):
+    """What makes an N > 1 line self-verifying (task 8): the world size the process group really has, the backend
+    and RCCL version, every rank's device ordinal and PCI bus id (two ranks on one GPU show up as a repeated id), the
+    HIP-event time of the collective per rank, and the spread of the per-rank elapsed times.  Gathered with one SUM
+    all-reduce of a table in which every rank fills its own row (works over RCCL and gloo alike)."""
+    bus = ctx.pci_bus_id()
+    try:
+        dom, b, rest = bus.split(":")
+        d_, fn = rest.split(".")
+        nums = [int(dom, 16), int(b, 16), int(d_, 16), int(fn, 16)]
+    except ValueError:
+        nums = [0, 0, 0, 0]
+    table = torch.zeros((world, 8), dtype=torch.float64, device=dev)
+    table[rank] = torch.tensor([float(local_rank)] + [float(x) for x in nums] + [elapsed, collective_ms, float(os.getpid())], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(table, op=dist.ReduceOp.SUM)
+    rows = table.cpu().tolist()
+    ids = ["%04x:%02x:%02x.%x" % (int(r[1]), int(r[2]), int(r[3]), int(r[4])) for r in rows]
+    try:
+        rccl = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
+    except Exception:                                            # (no RCCL in this torch build)
+        rccl = None
+    return {"ranks_seen": dist.get_world_size() if world > 1 else 1, "backend": (dist.get_backend() if world > 1 else "none"),
+            "rccl_version": rccl, "device_ordinals": [int(r[0]) for r in rows], "pci_bus_ids": ids,
+            "distinct_devices": len(set(ids)), "collective_ms": [r[6] for r in rows],
+            "elapsed_s_min": min(r[5] for r in rows), "elapsed_s_max": max(r[5] for r in rows), "pids": [int(r[7]) for r in rows]}
 
 def tiles_main(args, rank, world, local_rank, dev, capi, D, T, scenes, torch, dist):
     """BASELINE configs[4]: the 10 M-triangle mesh at 3840x2160 with 4 radiance bounces, tile-partitioned:
@@ -349,12 +417,17 @@ def tiles_main(args, rank, world, local_rank, dev, capi, D, T, scenes, torch, di
     t0 = time.perf_counter()
     for i in range(Wu, Wu + K):
         step(i)
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev[0].record()
     if world > 1:
         D.gather_tiles(acc, band)
+    ev[1].record()
     torch.cuda.synchronize()
+    mine_elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    report = rank_report(torch, dist, ctx, rank, world, local_rank, dev, os.environ.get("DXR_BENCH_BACKEND", "nccl"), mine_elapsed, ev[0].elapsed_time(ev[1]))
     tot = pipe.totals()
     red = torch.tensor([elapsed, float(tot["rays_primary"] + tot["rays_secondary"] + tot["rays_shadow"] - tot["rays_shadow_skipped"]),
                         float(tot["rays_primary"])], dtype=torch.float64, device=dev)
@@ -374,7 +447,8 @@ def tiles_main(args, rank, world, local_rank, dev, capi, D, T, scenes, torch, di
                        "parallelism": "tile-partitioned x%d, one all-gather of %d band slots per rank (%.1f MB sent per rank)"
                                       % (world, slots, floats * 4 / 1e6) if world > 1 else "single GPU",
                        "frames": K},
-            "frames_per_s": K / elapsed, "primary_mrays_per_s": float(red[2].item()) / elapsed / 1e6, "bvh_build_ms": scene.build_ms()}))
+            "frames_per_s": K / elapsed, "primary_mrays_per_s": float(red[2].item()) / elapsed / 1e6, "bvh_build_ms": scene.build_ms(),
+            "ranks": report}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -397,9 +471,10 @@ def main():
     # memory-side traffic for the two rooflines, measured by child runs under rocprofv3 BEFORE this process touches the GPU
     live = {}
     if world == 1 and not args.no_roofline and not args.no_live_pmc and args.partition == "samples" and args.workload == "c2":
-        live["c2"] = live_traffic("c2", args.width, args.height)
-        if args.hbm_frames > 0:
-            live["c5"] = live_traffic("c5", args.width, args.height)
+        t_live = time.perf_counter()
+        live["c2"] = live_traffic("c2", args.width, args.height, budget_s=100.0)
+        if args.hbm_frames > 0:           # (the 10 M-triangle child runs take ~30 s each: the two traffic passes only)
+            live["c5"] = live_traffic("c5", args.width, args.height, budget_s=max(20.0, 190.0 - (time.perf_counter() - t_live)), passes=("ea", "write"))
 
     import numpy as np
     import torch
@@ -422,13 +497,18 @@ def main():
     if args.workload == "c5":            # profiling passes: only the HBM-bound workload, one JSON line of its own
         assert world == 1, "--workload c5 is a single-GPU profiling mode"
         ctx = capi.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-        h = hbm_workload(ctx, capi, T, scenes, max(args.hbm_frames, 1), 2)
+        h = hbm_workload(ctx, capi, T, scenes, max(args.hbm_frames, 1), 2, batch=args.batch)
         print(json.dumps({"metric": "Mrays/s, 10 M triangles 4K 4-bounce (roofline workload)", "value": h["Mrays_per_s"], "unit": "Mrays/s",
                           "n_gpus": 1, "roofline_hbm": h}))
         return
 
     W, H, K, Wu = args.width, args.height, args.steps, args.warmup
-    verts, tris = scenes.sponza_class(seed=42)
+    if args.obj:
+        verts, tris = capi.obj_read(args.obj)              # the product's reader (rt_obj.cpp); no device needed
+        workload = "user OBJ %s (%d triangles, %d vertices)" % (os.path.basename(args.obj), tris.shape[0], verts.shape[0])
+    else:
+        verts, tris = scenes.sponza_class(seed=42)
+        workload = "BASELINE configs[1]: Sponza-class procedural atrium (seed 42, %d triangles)" % tris.shape[0]
     env = scenes.sky_cubemap(64)
     mat = T.default_material()
 
@@ -455,6 +535,12 @@ def main():
     total_frames = (Wu + K) * world
     host.options["maxIterations"] = max(1024, total_frames + 1)
     cam = scenes.sponza_camera()
+    if args.obj:
+        lo, hi = verts["position"].min(axis=0), verts["position"].max(axis=0)
+        centre, ext = 0.5 * (lo + hi), float(np.linalg.norm(hi - lo))
+        eye, at = (args.camera[:3], args.camera[3:]) if args.camera else (centre + np.array([0.35, 0.2, 1.0]) * ext, centre)
+        cam = dict(eye=tuple(float(x) for x in eye), at=tuple(float(x) for x in at), up=(0.0, 1.0, 0.0),
+                   fov=args.fov if args.fov else float(np.float32(np.pi / 4)))
     cam11 = capi.camera_array(cam["eye"], cam["at"], cam["up"], cam["fov"], W / H)
     pfcs = [host.update(cam11, 0.0, f + 1, W, H) for f in range(total_frames)]
     mine = D.shard_frames(rank, world, total_frames)
@@ -488,16 +574,21 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     steps(Wu, Wu + K)
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev[0].record()
     if world > 1:
         mean, n_frames = D.reduce_accumulation(acc, Wu + K)
+    ev[1].record()
     torch.cuda.synchronize()
+    mine_elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    report = rank_report(torch, dist, ctx, rank, world, local_rank, dev, backend, mine_elapsed, ev[0].elapsed_time(ev[1]))
 
     tot = pipe.totals()
-    # `value` counts rays that were actually TRAVERSED.  Shadow rays of a light with N.L == 0 are emitted by the reference's
-    # shaders (and counted in rays_shadow) but their visibility is multiplied by zero, so this engine does not walk them.
+    # `value` counts rays that were actually TRAVERSED: every ray the reference's shaders trace.  (rt_pipeline_set_skip_unlit_shadow_rays,
+    # off here as by default, would leave out the shadow rays of lights with N.L == 0 and count them in rays_shadow_skipped.)
     rays_local = tot["rays_primary"] + tot["rays_secondary"] + tot["rays_shadow"] - tot["rays_shadow_skipped"]
     red = torch.tensor([elapsed, float(rays_local), float(tot["rays_primary"]), float(tot["rays_shadow_skipped"])], dtype=torch.float64, device=dev)
     if world > 1:
@@ -515,8 +606,8 @@ def main():
             "n_gpus": world, "steps": K, "warmup": Wu, "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: Sponza-class procedural atrium (seed 42, %d triangles), %dx%d, 1 spp/frame "
-                                   "progressive accumulation, reference default material/lights/options" % (tris.shape[0], W, H),
+            "config": {"workload": "%s, %dx%d, 1 spp/frame progressive accumulation, reference default material/lights/options" % (workload, W, H),
+                       "camera": {"eye": list(cam["eye"]), "at": list(cam["at"]), "vfov": cam["fov"]},
                        "frames_per_gpu": K, "parallelism": "sample-sharded x%d, one RCCL all-reduce of the fp32 accumulation buffer" % world
                        if world > 1 else "single GPU", "accumulation": "sum+allreduce" if world > 1 else "running mean",
                        "frames_per_launch_set": S},
@@ -527,6 +618,7 @@ def main():
             "reference_ray_budget_mrays_per_s": (rays_all + skipped_all) / elapsed / 1e6,
             "shadow_rays_not_traversed_per_frame": skipped_all / (K * world),
             "bvh_build_ms": build_ms, "bvh_rebuild_ms": rebuild_ms,
+            "ranks": report,
         }
         if not args.no_roofline:
             stages, n_t = stage_table(pipe, tot)
@@ -534,37 +626,88 @@ def main():
             d = stages[dom]
             prof = committed_profile("c2").get("kernels", {}).get(d["kernel"], {})
             lv = live.get("c2", {}).get(d["kernel"], {})
-            # The C2 working set (~12 MB of nodes + 12 MB of triangle records) lives in the 4 MiB-per-XCD L2s and the
-            # Infinity Cache, so HBM cannot bound these kernels (memory-side traffic = `traffic`, a few % of what the lanes
-            # request).  What they are is a random gather of 64-B lines from cache-resident tables by divergent lanes, and the
-            # roofline is the rate the chip serves such a gather at: achieved = distinct lines x 64 B per launch / launch time.
-            out["roofline"] = {"bound": "cache-gather", "kernel": d["kernel"], "stage": dom,
-                               "achieved": d["gathered_GBps"], "peak": GATHER_PEAK_GBS, "unit": "GB/s",
-                               "frac": d["gathered_GBps"] / GATHER_PEAK_GBS,
-                               "traffic": lv.get("bytes_per_launch", prof.get("bytes_per_launch")),
-                               "traffic_source": ("this run: %d launches under rocprofv3 --pmc (read requests by size, WRITE_SIZE)" % lv["dispatches"])
-                                                 if lv else "committed profile",
-                               "bytes_per_launch": d["gathered_bytes"], "avg_launch_ms": d["avg_ms"], "launches_timed": n_t,
-                               "definition": "bytes = 64 B x distinct lines the launch gathers (node lines de-duplicated over the lanes of "
-                                             "each wave step + the lines its triangle records span, tallied by a counting instantiation "
-                                             "of the timed kernel on the last frame's queues, rt_pipeline_count_walk) + ray in / result "
-                                             "out; nodes served by the LDS-resident top of the tree are excluded; peak = random-row "
-                                             "gather rate from the Infinity Cache (MI355X_MICROARCH.md: 8.6 TB/s; this access shape "
-                                             "measured at 7.5 TB/s, profiles/r02/slab_fetch.txt); traffic = memory-side bytes "
-                                             "(FETCH_SIZE by request size + WRITE_SIZE) of the committed PMC pass",
-                               "requested_GBps_per_lane": d["requested_GBps"],
-                               "pmc": {k: prof.get(k) for k in ("TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "SQ_INSTS_VALU", "SQ_WAIT_ANY",
-                                                               "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES",
-                                                               "avg_us", "GBps") if k in prof},
-                               "pmc_source": committed_profile("c2").get("source"), "pmc_commit": committed_profile("c2").get("commit"),
-                               # SURVEY 8(d)'s layout-independent contract figure, kept for reference: canonical-LBVH counters x
-                               # (32 B node, 36 B triangle, 48 B ray) against HBM peak.  NOT a physical bound for this cache-resident
-                               # working set (the timed kernel walks a different tree and its bytes never leave the caches).
-                               "contract_8d_hbm": {"algorithmic_bytes_per_launch": d["canonical"]["algorithmic_bytes"],
-                                                   "GBps": d["canonical"]["GBps"], "over_hbm_peak": d["canonical"]["GBps"] / HBM_PEAK_GBS}}
+            # What bounds the dominant kernel (round 3, counters under the round-2 self-count).  The C2 working set (~4 MB of nodes
+            # + 12 MB of triangle records) lives in the L2s and the Infinity Cache, so HBM cannot bound it (`traffic`: a few % of
+            # what the lanes gather).  The vector-memory path is not saturated either: the L1 -> L2 read requests run at about a
+            # quarter of the rate the chip sustains for this access shape and the L1 tag accesses at about a third of one per
+            # clock per CU (`memory_path`).  What the kernel does saturate -- and what moved its time in every experiment of
+            # rounds 2 and 3: instructions per step, lanes per instruction, waves per SIMD -- is vector-instruction issue on a
+            # latency chain: `achieved` = wave64 VALU instructions per second (SQ_INSTS_VALU per launch / this run's HIP-event
+            # duration of the launch), `peak` = SIMDs x clock / 2 cycles per instruction on a SIMD-32, with the clock the chip held
+            # under this load (GRBM_GUI_ACTIVE / 8 XCDs / launch duration of the counter pass).
+            pm = dict(prof)
+            pm.update({k: v for k, v in lv.items() if not isinstance(v, str)})
+            have_sq = all(k in pm for k in ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE")) and (pm.get("sq_pass_avg_us") or pm.get("avg_us"))
+            rl = {"bound": "valu-issue", "kernel": d["kernel"], "stage": dom, "unit": "G wave64 VALU instructions/s",
+                  "traffic": lv.get("bytes_per_launch", prof.get("bytes_per_launch")),
+                  "traffic_source": ("this run: %d launches under rocprofv3 --pmc (read requests by size, WRITE_SIZE)" % lv["dispatches"])
+                                    if "bytes_per_launch" in lv else "committed profile",
+                  "counters_source": ("this run (rocprofv3 --pmc child passes: %s)" % ", ".join(sorted(k for k in ("sq", "tcp") if any(c in lv for c in LIVE_PMC_PASSES[k]))))
+                                     if any(c in lv for c in LIVE_PMC_PASSES["sq"]) else "committed profile %s" % committed_profile("c2").get("source"),
+                  "traffic_fallback": LIVE_PMC_NOTES or None,
+                  "avg_launch_ms": d["avg_ms"], "launches_timed": n_t}
+            if have_sq:
+                clk_hz = pm["GRBM_GUI_ACTIVE"] / N_XCD / ((pm.get("sq_pass_avg_us") or pm["avg_us"]) * 1e-6)
+                rl["achieved"] = pm["SQ_INSTS_VALU"] / (d["avg_ms"] * 1e-3) / 1e9
+                rl["peak"] = N_SIMD * clk_hz / VALU_ISSUE_CYCLES / 1e9
+                rl["frac"] = rl["achieved"] / rl["peak"]
+                rl["clock_GHz_under_load"] = clk_hz / 1e9
+                wc = pm["SQ_WAVE_CYCLES"]
+                rl["wave_cycles"] = {"parked_on_waitcnt": pm.get("SQ_WAIT_ANY", 0.0) / wc, "issue_stalled": pm.get("SQ_WAIT_INST_ANY", 0.0) / wc,
+                                     "issuing": pm.get("SQ_ACTIVE_INST_ANY", 0.0) / wc}
+                if "SQ_ACTIVE_INST_VALU" in pm:
+                    rl["valu_busy_gfx9_formula"] = pm["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * pm["GRBM_GUI_ACTIVE"] / N_XCD)
+            else:
+                rl.update({"achieved": None, "peak": None, "frac": None})
+            mp = {"lines_counted_by_count_walk": d["gathered_bytes"] // LINE_BYTES, "gathered_GBps_count_walk": d["gathered_GBps"],
+                  "hbm_frac": (rl["traffic"] / (d["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if rl["traffic"] else None}
+            if "TCP_TCC_READ_REQ_sum" in pm:
+                req = pm["TCP_TCC_READ_REQ_sum"]
+                mp.update({"l2_read_requests_per_launch": req, "l2_request_rate_frac": req / (d["avg_ms"] * 1e-3) / L2_REQUEST_PEAK_PER_S,
+                           "l2_request_GBps": req * LINE_BYTES / (d["avg_ms"] * 1e-3) / 1e9, "l2_request_peak_GBps": GATHER_PEAK_GBS,
+                           "l1_served_share_of_counted_lines": 1.0 - req / max(d["gathered_bytes"] / LINE_BYTES, 1.0)})
+            if "TCP_TOTAL_CACHE_ACCESSES_sum" in pm and have_sq:
+                mp["l1_tag_accesses_per_launch"] = pm["TCP_TOTAL_CACHE_ACCESSES_sum"]
+                mp["l1_tag_rate_frac"] = pm["TCP_TOTAL_CACHE_ACCESSES_sum"] / (d["avg_ms"] * 1e-3) / (N_CU * clk_hz)
+            rl["memory_path"] = mp
+            rl["definition"] = ("frac = SQ_INSTS_VALU per launch / HIP-event launch duration / (1024 SIMDs x clock / 2 cycles per wave64 VALU "
+                                "instruction on a SIMD-32); clock = GRBM_GUI_ACTIVE / 8 / launch duration in the counter pass.  memory_path: "
+                                "TCP_TCC_READ_REQ (one per 64-B line gathered: calibrated on tools/microbench/slab_fetch, profiles/r03/"
+                                "slab_131072_tcp.md) against the 120.6 G requests/s the chip sustains for this access shape; "
+                                "TCP_TOTAL_CACHE_ACCESSES against one per clock per CU; hbm_frac = traffic / duration / 8 TB/s.  "
+                                "contract_8d_hbm: SURVEY 8(d)'s layout-independent figure, kept as a label")
+            # SURVEY 8(d)'s layout-independent contract figure, kept for reference: canonical-LBVH counters x (32 B node, 36 B
+            # triangle, 48 B ray) against HBM peak.  NOT a physical bound for this cache-resident working set (the timed kernel
+            # walks a different tree and its bytes never leave the caches).
+            rl["contract_8d_hbm"] = {"algorithmic_bytes_per_launch": d["canonical"]["algorithmic_bytes"], "GBps": d["canonical"]["GBps"],
+                                     "over_hbm_peak": d["canonical"]["GBps"] / HBM_PEAK_GBS}
+            rl["pmc"] = {k: pm.get(k) for k in ("TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+                                                "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "TCP_TCC_READ_REQ_sum",
+                                                "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_LATENCY_sum", "TCP_PENDING_STALL_CYCLES_sum") if k in pm}
+            rl["pmc_source"] = committed_profile("c2").get("source")
+            rl["pmc_commit"] = committed_profile("c2").get("commit")
+            out["roofline"] = rl
             tb = sum(stages[s]["gathered_bytes"] for s in TRACE_STAGES)
             out["roofline"]["all_stages_GBps_over_step"] = tb / (out["ms_per_step"] * 1e-3) / 1e9
             out["stages"] = stages
+        if world == 1 and not args.no_roofline and S == 1:
+            # the same K frames again, eight per set of launches (rt_pipeline_render_batch: BASELINE configs[2]'s sample batches):
+            # the persistent traversal stages and their tails are paid once per batch, the image is the same bit for bit
+            SB = 8
+            pipe.clear_output()
+            pipe.render_batch([pfcs[mine[j]] for j in range(0, min(SB, Wu))] or [pfcs[mine[0]]])
+            ctx.synchronize()
+            pipe.reset_totals()
+            tb0 = time.perf_counter()
+            for i in range(Wu, Wu + K, SB):
+                pipe.render_batch([pfcs[mine[j]] for j in range(i, min(i + SB, Wu + K))])
+            ctx.synchronize()
+            tb = time.perf_counter() - tb0
+            totb = pipe.totals()
+            raysb = totb["rays_primary"] + totb["rays_secondary"] + totb["rays_shadow"] - totb["rays_shadow_skipped"]
+            out["sample_batches"] = {"frames_per_launch_set": SB, "frames": K, "ms_per_frame": tb / K * 1e3, "Mrays_per_s": raysb / tb / 1e6,
+                                     "frames_per_s": K / tb, "speedup_over_frame_by_frame": (elapsed / K) / (tb / K),
+                                     "note": "rt_pipeline_render_batch: same frames, same bits, 8 frames per set of launches; `value` above is frame by frame"}
         if world == 1 and args.hbm_frames > 0 and not args.no_roofline:
             del pipe, scene, model
             h = hbm_workload(ctx, capi, T, scenes, args.hbm_frames, 2)
@@ -585,7 +728,7 @@ def main():
                              "frac": traffic / (live_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
                              "traffic": traffic, "avg_launch_ms": live_ms, "launches_timed": h["launches_timed"],
                              "traffic_source": ("this run: %d launches under rocprofv3 --pmc (read requests by size, WRITE_SIZE)" % lv5["dispatches"])
-                                               if lv5 else "committed profile",
+                                               if "bytes_per_launch" in lv5 else "committed profile",
                              "traffic_committed_profile": k5.get("bytes_per_launch"),
                              "profiled_avg_us": prof_us, "profiled_GBps": k5.get("GBps"),
                              "gathered_bytes_per_frame": d["gathered_bytes"], "gathered_GBps": d["gathered_GBps"],

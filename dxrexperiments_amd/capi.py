@@ -158,8 +158,12 @@ SIGNATURES = {
     "rt_dist_get_rank": (_i, [_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rt_dist_all_reduce_sum": (_i, [_p, _p, _sz]),
     "rt_dist_gather_bands": (_i, [_p, _p, _u32, _u32, _u32]),
+    "rt_dist_last_collective_ms": (_i, [_p, C.POINTER(C.c_float)]),
+    "rt_dist_device_pci_bus_id": (_i, [_p, C.c_char_p, _sz]),
     "rt_dds_read_cube": (_i, [C.c_char_p, _p, _sz, C.POINTER(C.c_uint32)]),
     "rt_obj_read": (_i, [C.c_char_p, _p, _u32, _p, _u32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rt_fbx_read": (_i, [C.c_char_p, _p, _u32, _p, _u32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rt_model_create_from_file": (_i, [_p, C.c_char_p, _pp]),
 }
 
 
@@ -228,6 +232,12 @@ class Context:
     def synchronize(self):
         _check(lib().rt_context_synchronize(self.h))
 
+    def pci_bus_id(self):
+        """PCI bus id of the context's device ("0000:c1:00.0"): what tells two ranks on one GPU apart from two GPUs"""
+        buf = C.create_string_buffer(64)
+        _check(lib().rt_dist_device_pci_bus_id(self.h, buf, 64))
+        return buf.value.decode()
+
     @property
     def stream(self):
         s = C.c_void_p()
@@ -293,7 +303,7 @@ class Model:
         self.ctx = ctx
         h = C.c_void_p()
         if path is not None:
-            _check(lib().rt_model_create_from_obj(ctx.h, os.fsencode(path), C.byref(h)))
+            _check(lib().rt_model_create_from_file(ctx.h, os.fsencode(path), C.byref(h)))
         else:
             v = np.ascontiguousarray(verts, dtype=T.VERTEX)
             i = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
@@ -451,7 +461,9 @@ class Pipeline:
         _check(lib().rt_pipeline_set_environment_cube(self.h, _ptr(f), f.shape[1]))
 
     def set_skip_unlit_shadow_rays(self, on=True):
-        """Shadow rays of lights with N.L == 0 (visibility multiplied by zero): counted but not traversed (default) or traversed."""
+        """Shadow rays of lights with N.L == 0 (their visibility is multiplied by zero).  Off (the default, as in dxr_amd.h): every
+        shadow ray the reference traces is traversed.  On: such rays are emitted and counted (rays_shadow_skipped) but not
+        walked; the image is bit-identical either way."""
         _check(lib().rt_pipeline_set_skip_unlit_shadow_rays(self.h, 1 if on else 0))
 
     def set_environment_filter(self, seamless=True):
@@ -649,6 +661,17 @@ def obj_read(path):
     v = np.zeros(nv.value, VERTEX)
     t = np.zeros((nt.value, 3), np.uint32)
     _check(lib().rt_obj_read(os.fsencode(path), _ptr(v), nv.value, _ptr(t), nt.value, C.byref(nv), C.byref(nt)))
+    return v, t
+
+
+def fbx_read(path):
+    """The product's binary-FBX mesh reader, no device needed: (verts[VERTEX], tris[n,3] uint32)."""
+    from .rtypes import VERTEX
+    nv, nt = C.c_uint32(0), C.c_uint32(0)
+    _check(lib().rt_fbx_read(os.fsencode(path), None, 0, None, 0, C.byref(nv), C.byref(nt)))
+    v = np.zeros(nv.value, VERTEX)
+    t = np.zeros((nt.value, 3), np.uint32)
+    _check(lib().rt_fbx_read(os.fsencode(path), _ptr(v), nv.value, _ptr(t), nt.value, C.byref(nv), C.byref(nt)))
     return v, t
 
 

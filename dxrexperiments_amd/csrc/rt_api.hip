@@ -299,6 +299,19 @@ int rt_model_create_from_obj(rt_context *ctx, const char *path, rt_model **out)
     return model_finish(ctx, m, out);
 }
 
+int rt_model_create_from_file(rt_context *ctx, const char *path, rt_model **out)
+{
+    RT_REQUIRE(ctx && path && out, "null argument");
+    const size_t n = strlen(path);
+    const bool fbx = n >= 4 && path[n - 4] == '.' && (path[n - 3] | 0x20) == 'f' && (path[n - 2] | 0x20) == 'b' && (path[n - 1] | 0x20) == 'x';
+    if (!fbx) return rt_model_create_from_obj(ctx, path, out);
+    rt_model *m = new (std::nothrow) rt_model();
+    if (!m) { rt_set_error("out of host memory"); return RT_ERR_OOM; }
+    int rc = rt_fbx_parse(path, m->h_verts, m->h_idx);
+    if (rc != RT_OK) { delete m; return rc; }
+    return model_finish(ctx, m, out);
+}
+
 int rt_model_get_counts(const rt_model *m, uint32_t *n_verts, uint32_t *n_tris)
 {
     RT_REQUIRE(m, "null model");

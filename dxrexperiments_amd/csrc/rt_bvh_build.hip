@@ -235,7 +235,11 @@ __global__ void k_refit(const rt_bvh_node *__restrict__ nodes, const uint32_t *_
         // every store must have been ACKNOWLEDGED before the arrival is counted; inline asm, because the compiler may drop a
         // wait it believes redundant (MI355X_MICROARCH.md, "Compiler hazard")
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t arrived = atomicAdd(&scratch[(size_t)parent * 8 + 7], 1u);
+        // (a relaxed memory-side atomic: the ordering it needs is made by hand -- stores acknowledged above, sc1 loads below --
+        // and the two signal fences keep the COMPILER from moving any of them across it: ADVICE r2)
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        const uint32_t arrived = __hip_atomic_fetch_add(&scratch[(size_t)parent * 8 + 7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
         if (arrived == 0u) return;                       // the sibling's climber will take over from here
         const rt_bvh_node pn = nodes[parent];
         const uint32_t sib = pn.left == cur ? pn.right : pn.left;
@@ -493,6 +497,25 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
     s->h_inst.assign(n, InstanceRec());
     std::vector<Box6> hb(n);
     uint32_t deepest = 0;
+    // the two models most instances use get LDS room for the top of their BLAS in the two-level kernels (rt_trace_wave.h)
+    {
+        std::vector<std::pair<rt_model *, uint32_t>> use;
+        for (uint32_t i = 0; i < n; i++) {
+            rt_model *m = s->inst[i].model;
+            size_t k = 0;
+            while (k < use.size() && use[k].first != m) k++;
+            if (k == use.size()) { if (use.size() < 4096) use.push_back(std::make_pair(m, 0u)); else continue; }
+            use[k].second++;
+        }
+        s->lds_blas[0] = s->lds_blas[1] = nullptr;
+        const char *off = getenv("RT_LDS_BLAS");            // RT_LDS_BLAS=0: BLAS nodes always from global memory (A/B measurements)
+        for (int slot = 0; slot < 2 && !(off && atoi(off) == 0); slot++) {
+            size_t best = use.size();
+            for (size_t k = 0; k < use.size(); k++)
+                if (use[k].first != s->lds_blas[0] && use[k].first->blas.wide_n > 0 && (best == use.size() || use[k].second > use[best].second)) best = k;
+            if (best < use.size()) s->lds_blas[slot] = use[best].first;
+        }
+    }
     for (uint32_t i = 0; i < n; i++) {
         rt_model *m = s->inst[i].model;
         InstanceRec &r = s->h_inst[i];
@@ -522,7 +545,7 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
             }
         }
         r.root_code = m->blas.root_code;
-        r.flags = identity ? RT_INST_IDENTITY : 0u;
+        r.flags = (identity ? RT_INST_IDENTITY : 0u) | (m == s->lds_blas[0] ? 1u << 8 : m == s->lds_blas[1] ? 2u << 8 : 0u);
         r.wide = m->blas.wide.as<WNode>();
         r.tris = m->tris.as<TriRec>();
         r.cnodes = m->blas.nodes.as<rt_bvh_node>();

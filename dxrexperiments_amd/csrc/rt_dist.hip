@@ -14,7 +14,11 @@
 //
 // Launch rule for callers: create the processes BEFORE any of them touches the GPU (examples/progressive_multi.cpp forks
 // first); never re-exec a process that has initialised HIP.
+#include <dirent.h>
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <new>
 
@@ -97,6 +101,76 @@ __global__ void __launch_bounds__(256) k_unpack_bands(float4 *__restrict__ image
     image[i] = gathered[(size_t)(b % world) * chunk_pixels + ((size_t)(b / world) * band_rows + y % band_rows) * width + x];
 }
 
+// Two ranks on ONE device make ncclCommInitRank fail late or hang (RCCL wants one device per rank).  Before the communicator
+// exists the ranks share nothing but the 128-byte id the launcher handed round, so they meet in /dev/shm (one node: the
+// scope of this engine's multi-GPU mode): every rank publishes its device's PCI bus id in a file named after the id and its
+// rank, then reads the others'.  A rank whose file does not appear within the time limit is not on this node (or not yet
+// there): the check is skipped for it, nothing fails.  RT_DIST_CHECK_SECONDS=0 turns the rendezvous off.
+std::string rendezvous_path(const void *id128, int rank)
+{
+    unsigned long long h = 1469598103934665603ull;                       // FNV-1a of the id
+    for (int i = 0; i < 128; i++) { h ^= ((const unsigned char *)id128)[i]; h *= 1099511628211ull; }
+    char name[96];
+    snprintf(name, sizeof name, "/dev/shm/dxr_amd_%016llx_%d", h, rank);
+    return name;
+}
+
+int check_one_device_per_rank(const rt_context *ctx, int rank, int world, const void *id128, std::string *mine)
+{
+    double limit = 20.0;
+    if (const char *e = getenv("RT_DIST_CHECK_SECONDS")) limit = atof(e);
+    if (world < 2 || !(limit > 0.0)) return RT_OK;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, ctx->device) != hipSuccess) return RT_OK;       // nothing to compare
+    {   // entries a failed create left behind (see below) are swept once they are ten minutes old
+        if (DIR *dir = opendir("/dev/shm")) {
+            const time_t now = time(nullptr);
+            while (struct dirent *e = readdir(dir)) {
+                if (strncmp(e->d_name, "dxr_amd_", 8) != 0) continue;
+                const std::string old = std::string("/dev/shm/") + e->d_name;
+                struct stat sb;
+                if (stat(old.c_str(), &sb) == 0 && now - sb.st_mtime > 600) unlink(old.c_str());
+            }
+            closedir(dir);
+        }
+    }
+    const std::string path = rendezvous_path(id128, rank), tmp = path + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "w");
+    if (!f) return RT_OK;                                                                          // no /dev/shm: skip
+    fprintf(f, "%s\n", bus);
+    fclose(f);
+    if (rename(tmp.c_str(), path.c_str()) != 0) { unlink(tmp.c_str()); return RT_OK; }
+    *mine = path;
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int r = 0; r < world; r++) {
+        if (r == rank) continue;
+        const std::string other = rendezvous_path(id128, r);
+        for (;;) {
+            FILE *g = fopen(other.c_str(), "r");
+            if (g) {
+                char theirs[64] = {0};
+                const bool got = fgets(theirs, sizeof theirs, g) != nullptr;
+                fclose(g);
+                if (got) {
+                    theirs[strcspn(theirs, "\n")] = 0;
+                    if (strcmp(theirs, bus) == 0) {
+                        rt_set_error("rt_dist_create: ranks %d and %d are both on the device at PCI %s; RCCL needs one device per rank", rank < r ? rank : r,
+                                     rank < r ? r : rank, bus);
+                        return RT_ERR_INVALID_ARG;
+                    }
+                    break;
+                }
+            }
+            struct timespec t;
+            clock_gettime(CLOCK_MONOTONIC, &t);
+            if ((double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec) > limit) break;       // not on this node (yet): skip
+            usleep(2000);
+        }
+    }
+    return RT_OK;
+}
+
 }  // namespace
 
 struct rt_dist {
@@ -105,6 +179,9 @@ struct rt_dist {
     nccl_comm comm = nullptr;
     int rank = 0, world = 1;
     DevBuf gathered;
+    std::string rendezvous_file;       // this rank's entry of the one-device-per-rank check (removed on destroy)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;                // an event pair brackets the last collective
 };
 
 extern "C" {
@@ -168,14 +245,25 @@ int rt_dist_create(rt_context *ctx, int rank, int world, const void *id128, rt_d
     rt_dist *d = new (std::nothrow) rt_dist();
     if (!d) { rt_set_error("out of host memory"); return RT_ERR_OOM; }
     d->ctx = ctx; d->lib = lib; d->rank = rank; d->world = world;
+    {
+        const int chk = check_one_device_per_rank(ctx, rank, world, id128, &d->rendezvous_file);
+        if (chk != RT_OK) {
+            // (this rank's entry stays: the other rank on the same device has to find it to fail the same way instead of
+            // waiting for RCCL; the next rendezvous on this node sweeps it)
+            delete d;
+            return chk;
+        }
+    }
     nccl_id id;
     memcpy(&id, id128, sizeof id);
     const int rc = lib->comm_init_rank(&d->comm, world, id, rank);
     if (rc != 0) {
         rt_set_error("ncclCommInitRank(rank %d of %d): %s", rank, world, lib->error_string ? lib->error_string(rc) : "RCCL error");
+        if (!d->rendezvous_file.empty()) unlink(d->rendezvous_file.c_str());
         delete d;
         return RT_ERR_HIP;
     }
+    if (hipEventCreate(&d->ev0) != hipSuccess || hipEventCreate(&d->ev1) != hipSuccess) { d->ev0 = nullptr; d->ev1 = nullptr; }
     rt_context_retain(ctx);
     *out = d;
     return RT_OK;
@@ -187,6 +275,9 @@ int rt_dist_destroy(rt_dist *d)
     (void)hipSetDevice(d->ctx->device);
     (void)hipStreamSynchronize(d->ctx->stream);
     if (d->comm) (void)d->lib->comm_destroy(d->comm);
+    if (!d->rendezvous_file.empty()) unlink(d->rendezvous_file.c_str());
+    if (d->ev0) (void)hipEventDestroy(d->ev0);
+    if (d->ev1) (void)hipEventDestroy(d->ev1);
     d->gathered.release();
     rt_context *ctx = d->ctx;
     delete d;
@@ -205,7 +296,28 @@ int rt_dist_all_reduce_sum(rt_dist *d, void *device_f32, size_t count)
 {
     RT_REQUIRE(d && device_f32, "null argument");
     HIP_TRY(hipSetDevice(d->ctx->device));
+    d->timed = false;
+    if (d->ev0) HIP_TRY(hipEventRecord(d->ev0, d->ctx->stream));
     NCCL_TRY(d->lib, d->lib->all_reduce(device_f32, device_f32, count, NCCL_FLOAT, NCCL_SUM, d->comm, d->ctx->stream));
+    if (d->ev1) { HIP_TRY(hipEventRecord(d->ev1, d->ctx->stream)); d->timed = true; }
+    return RT_OK;
+}
+
+int rt_dist_last_collective_ms(rt_dist *d, float *ms)
+{
+    RT_REQUIRE(d && ms, "null argument");
+    *ms = 0.0f;
+    if (!d->timed) { rt_set_error("rt_dist_last_collective_ms: no collective has been issued"); return RT_ERR_STATE; }
+    HIP_TRY(hipSetDevice(d->ctx->device));
+    HIP_TRY(hipEventSynchronize(d->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, d->ev0, d->ev1));
+    return RT_OK;
+}
+
+int rt_dist_device_pci_bus_id(const rt_context *ctx, char *out, size_t capacity)
+{
+    RT_REQUIRE(ctx && out && capacity >= 16, "bad argument");
+    HIP_TRY(hipDeviceGetPCIBusId(out, (int)capacity, ctx->device));
     return RT_OK;
 }
 
@@ -218,6 +330,8 @@ int rt_dist_gather_bands(rt_dist *d, void *device_rgba32f, uint32_t width, uint3
     HIP_TRY(hipSetDevice(d->ctx->device));
     hipStream_t st = d->ctx->stream;
     const size_t chunk_pixels = floats / 4;
+    d->timed = false;
+    if (d->ev0) HIP_TRY(hipEventRecord(d->ev0, st));
     RT_TRY(d->gathered.reserve(floats * 4 * (size_t)d->world));
     float4 *all = d->gathered.as<float4>();
     const unsigned grid = (unsigned)(((size_t)width * height + 255) / 256);
@@ -227,6 +341,7 @@ int rt_dist_gather_bands(rt_dist *d, void *device_rgba32f, uint32_t width, uint3
     NCCL_TRY(d->lib, d->lib->all_gather(all + (size_t)d->rank * chunk_pixels, all, floats, NCCL_FLOAT, d->comm, st));
     k_unpack_bands<<<grid, 256, 0, st>>>((float4 *)device_rgba32f, all, width, height, band_rows, (uint32_t)d->world, chunk_pixels);
     HIP_TRY(hipGetLastError());
+    if (d->ev1) { HIP_TRY(hipEventRecord(d->ev1, st)); d->timed = true; }
     return RT_OK;
 }
 

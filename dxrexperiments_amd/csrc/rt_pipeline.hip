@@ -39,6 +39,9 @@ constexpr int PBLOCK = 256;
 #ifndef RT_SHADOW_UNORDERED
 #define RT_SHADOW_UNORDERED 1
 #endif
+// (only the any-hit instantiation of the walk tallies the queue slots marked "emitted but not traversed": with ordered shadow
+// walks rt_stats.rays_shadow would under-count when rt_pipeline_set_skip_unlit_shadow_rays is on)
+static_assert(RT_SHADOW_UNORDERED != 0, "the shadow stage counts skipped slots in the ANYHIT walk only");
 
 #define RAY_MAX_T 1.0e+38f      // RaytracingCommon.hlsli:8
 #define RAY_EPSILON 0.0001f     // RaytracingCommon.hlsli:9

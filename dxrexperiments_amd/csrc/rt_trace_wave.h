@@ -383,12 +383,24 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
     const TriRec *tris0 = TWO_LEVEL ? nullptr : in0->tris;
     // the LDS-resident top of the tree: smem rows STACK .. STACK + RT_TOP_ROWS - 1 hold nodes 0 .. top_n - 1 (breadth-first
     // numbering) of the structure a ray starts in: the BLAS of a single-level scene, the TLAS of a two-level one
+    // Two-level scenes split the table (round 3): the top of the TLAS (RT_TOP_TLAS nodes) and the tops of the two BLASes
+    // most instances use (RT_TOP_BLAS nodes each; the TLAS build marks those instances, InstanceRec::flags bits 8-9), so that
+    // the first levels of every walk INSIDE such an instance come from LDS as well.
     int *topl = smem + STACK * BLOCK;
     if (sc.top_n != 0) {
         const int *src_top = (const int *)(TWO_LEVEL ? sc.tlas_wide : blas_nodes0);
         for (uint32_t i = threadIdx.x; i < sc.top_n * RT_TOP_WORDS; i += BLOCK) topl[i] = src_top[(i / RT_TOP_WORDS) * (uint32_t)(sizeof(WNode) / 4) + i % RT_TOP_WORDS];
-        __syncthreads();
     }
+    if (TWO_LEVEL) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int *src_top = (const int *)sc.blas_top[k];
+            int *dst = topl + (RT_TOP_TLAS + k * RT_TOP_BLAS) * RT_TOP_WORDS;
+            for (uint32_t i = threadIdx.x; i < sc.blas_top_n[k] * RT_TOP_WORDS; i += BLOCK) dst[i] = src_top[(i / RT_TOP_WORDS) * (uint32_t)(sizeof(WNode) / 4) + i % RT_TOP_WORDS];
+        }
+    }
+    if (sc.top_n != 0 || TWO_LEVEL) __syncthreads();
+    const int *top_cur = topl;                    // LDS table of the structure being walked
     const int root0 = TWO_LEVEL ? sc.tlas_root_code : in0->root_code;
     uint32_t top_lim = sc.top_n;                  // node indices below this are read from LDS (two-level: 0 while inside a BLAS)
 
@@ -459,7 +471,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     cur.o = r.o; cur.d = r.d; cur.ri = wri;
                     node = root0;
                     sp = 0;
-                    if (TWO_LEVEL) { nodes = sc.tlas_wide; in_blas = false; top_lim = sc.top_n; }
+                    if (TWO_LEVEL) { nodes = sc.tlas_wide; in_blas = false; top_lim = sc.top_n; top_cur = topl; }
                     alive = true;
                     n_traced++;
                     if (COUNT) wk_ray0 = wk_glob + wk_top;
@@ -487,7 +499,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 const uint32_t dl = distinct_node_lines(node, !((uint32_t)node < top_lim));
                 if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_read_exec())) wk_lines += (RT_WIDE == 8 ? 2u : 1u) * dl;       // 64-B lines (96 B of a 128-B record: two)
             }
-            wide_step<false, ANYHIT>(nodes, topl, top_lim, cur.ri, r.tmin, ANYHIT ? r.tmax : best.t, st, node, sp);
+            wide_step<false, ANYHIT>(nodes, top_cur, top_lim, cur.ri, r.tmin, ANYHIT ? r.tmax : best.t, st, node, sp);
 #ifdef RT_TRACE_STATS
             st_maxsp = sp > st_maxsp ? sp : st_maxsp;
 #endif
@@ -504,7 +516,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 const uint32_t dl = distinct_node_lines(node, !((uint32_t)node < top_lim));
                 if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_read_exec())) wk_lines += (RT_WIDE == 8 ? 2u : 1u) * dl;       // 64-B lines (96 B of a 128-B record: two)
             }
-            wide_step<true, ANYHIT>(nodes, topl, top_lim, cur.ri, r.tmin, ANYHIT ? r.tmax : best.t, st, node, sp);
+            wide_step<true, ANYHIT>(nodes, top_cur, top_lim, cur.ri, r.tmin, ANYHIT ? r.tmax : best.t, st, node, sp);
 #ifdef RT_TRACE_STATS
             st_maxsp = sp > st_maxsp ? sp : st_maxsp;
 #endif
@@ -528,6 +540,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 in_blas = false;
                 nodes = sc.tlas_wide;
                 top_lim = sc.top_n;
+                top_cur = topl;
                 cur.o = r.o; cur.d = r.d; cur.ri = wri;
             } else if (TWO_LEVEL && !in_blas) {
                 ii = (uint32_t)~node;
@@ -543,7 +556,11 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     nodes = in->wide;
                     tris = in->tris;
                     in_blas = true;
-                    top_lim = 0;
+                    {   // the top of this BLAS is LDS resident if it is one of the two the scene uses most
+                        const uint32_t slot = (in->flags >> 8) & 3u;
+                        top_lim = slot ? sc.blas_top_n[slot - 1u] : 0u;
+                        top_cur = topl + (RT_TOP_TLAS + (slot ? slot - 1u : 0u) * RT_TOP_BLAS) * RT_TOP_WORDS;
+                    }
                     st.write(sp, RT_NODE_SENTINEL);
                     sp++;
                     node = in->root_code;

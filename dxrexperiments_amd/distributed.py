@@ -24,8 +24,21 @@ def shard_frames(rank, world_size, n_frames, first_frame=0):
     return list(range(first_frame + rank, first_frame + n_frames, world_size))
 
 
+def _native_partitions():
+    """The partition functions are host logic of the C ABI (no device needed), but the shared library links the HIP runtime:
+    on a box where it cannot even be loaded, the same two formulas are evaluated here.  Rendering has no such
+    fallback."""
+    try:
+        capi.lib()
+        return True
+    except (ImportError, OSError):
+        return False
+
+
 def frames_per_rank(world_size, n_frames):
     """Frames each rank renders: the C ABI's own partition (rt_shard_frame_count), so C++ and Python callers agree."""
+    if not _native_partitions():
+        return [(n_frames - r + world_size - 1) // world_size if n_frames > r else 0 for r in range(world_size)]
     return [capi.shard_frame_count(r, world_size, n_frames) for r in range(world_size)]
 
 
@@ -47,6 +60,8 @@ def tile_rows(rank, world_size, height, band=16):
     """Partitioning B (image tiles): interleaved bands of `band` rows owned by `rank`, as (y0, y1) pairs -- the C ABI's
     rt_tile_bands.  Pixels are seeded by their GLOBAL index, so the tiled image is bit-identical to the single-GPU one
     and needs no arithmetic exchange."""
+    if not _native_partitions():
+        return [(b * band, min((b + 1) * band, height)) for b in range(rank, (height + band - 1) // band, world_size)]
     return capi.tile_bands(height, band, rank, world_size)
 
 

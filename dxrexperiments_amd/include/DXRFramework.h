@@ -24,6 +24,15 @@
 
 #include "dxr_amd.h"
 
+// D3D12 types the reference's call sites name, kept so that they compile unchanged (src/DXRExperimentsApp.cpp:186-215):
+//   D3D12_GPU_DESCRIPTOR_HANDLE   the reference hands SRV / UAV descriptor-heap handles of its output textures to the
+//                                 denoiser; here the handle's 64-bit `ptr` is the DEVICE ADDRESS of the RGBA32F image
+//   ID3D12GraphicsCommandList     opaque and never defined: work goes to the RtContext's stream, the argument is ignored
+//   D3D12_RESOURCE_STATES         resource barriers have no HIP analogue on one in-order stream: transitionResource is a no-op
+struct D3D12_GPU_DESCRIPTOR_HANDLE { unsigned long long ptr; };
+struct ID3D12GraphicsCommandList;
+enum D3D12_RESOURCE_STATES { D3D12_RESOURCE_STATE_UNORDERED_ACCESS = 0x8, D3D12_RESOURCE_STATE_NON_PIXEL_SHADER_RESOURCE = 0x40 };
+
 namespace DXRFramework
 {
     // what the reference's ThrowIfFailed / HrException do (Helpers/DirectXHelper.h:22-64)
@@ -90,6 +99,8 @@ namespace DXRFramework
         void *getStream() const { void *s = nullptr; ThrowIfFailed(rt_context_get_stream(mHandle, &s)); return s; }
         bool isUsingNativeDxr() const { return false; }
         void waitForGpu() { ThrowIfFailed(rt_context_synchronize(mHandle)); }
+        // RtContext::transitionResource (RtContext.cpp:224-232): kernels of one stream run in order, nothing to do
+        void transitionResource(void *, D3D12_RESOURCE_STATES, D3D12_RESOURCE_STATES) {}
 
         // raytrace(bindings, state, width, height, depth) (RtContext.cpp:192-222); defined below
         inline void raytrace(std::shared_ptr<RtBindings> bindings, std::shared_ptr<RtState> state, uint32_t width, uint32_t height, uint32_t depth);
@@ -108,7 +119,7 @@ namespace DXRFramework
         static SharedPtr create(RtContext::SharedPtr context, const std::string &filePath)
         {
             rt_model *h = nullptr;
-            int rc = rt_model_create_from_obj(context->getHandle(), filePath.c_str(), &h);
+            int rc = rt_model_create_from_file(context->getHandle(), filePath.c_str(), &h);      // .fbx or .obj
             if (rc != RT_OK) {
                 // the reference substitutes one triangle when the import fails (RtModel.cpp:58-68)
                 static const rt_vertex tri[3] = {{{0.0f, 0.25f, 0.0f}, {0, 0, 1}}, {{0.25f, -0.25f, 0.0f}, {0, 0, 1}}, {{-0.25f, -0.25f, 0.0f}, {0, 0, 1}}};

@@ -14,11 +14,12 @@ public:
 
     void userInterface() {}
 
-    struct InputComponents      // SRV handles in the reference: device pointers of RGBA32F images here
+    struct InputComponents      // DenoiseCompositor.h:34-38: SRV handles; a handle's ptr is the device address of an RGBA32F image
     {
-        const void *directLightingSrv;
-        const void *indirectSpecularSrv;
+        D3D12_GPU_DESCRIPTOR_HANDLE directLightingSrv;
+        D3D12_GPU_DESCRIPTOR_HANDLE indirectSpecularSrv;
     };
+    static D3D12_GPU_DESCRIPTOR_HANDLE handleOf(const void *deviceImage) { return D3D12_GPU_DESCRIPTOR_HANDLE{(unsigned long long)(size_t)deviceImage}; }
 
     typedef rt_denoiser_params DenoiserParams;     // DenoiseCompositor.h:41-49
     DenoiserParams &params() { DenoiserParams *p = nullptr; DXRFramework::ThrowIfFailed(rt_denoiser_get_params(mDenoiser, &p)); return *p; }
@@ -26,7 +27,13 @@ public:
     void dispatch(InputComponents inputs, unsigned frameIndex, unsigned width, unsigned height)
     {
         (void)frameIndex;
-        DXRFramework::ThrowIfFailed(rt_denoiser_dispatch(mDenoiser, inputs.directLightingSrv, inputs.indirectSpecularSrv, width, height));
+        DXRFramework::ThrowIfFailed(rt_denoiser_dispatch(mDenoiser, (const void *)(size_t)inputs.directLightingSrv.ptr,
+                                                         (const void *)(size_t)inputs.indirectSpecularSrv.ptr, width, height));
+    }
+    // the reference's signature (DenoiseCompositor.h:20, call site src/DXRExperimentsApp.cpp:206); the command list is ignored
+    void dispatch(ID3D12GraphicsCommandList *, InputComponents inputs, unsigned frameIndex, unsigned width, unsigned height)
+    {
+        dispatch(inputs, frameIndex, width, height);
     }
     void loadResources(unsigned frameCount, bool loadMockResources) { (void)frameCount; (void)loadMockResources; }
     void createOutputResource(unsigned format, unsigned width, unsigned height) { DXRFramework::ThrowIfFailed(rt_denoiser_create_output(mDenoiser, format, width, height)); }

@@ -37,6 +37,7 @@ public:
         DXRFramework::ThrowIfFailed(rt_pipeline_update(mPipeline, &mConstants));
     }
 
+    using RaytracingPipeline::render;       // the (commandList, frameIndex, width, height) form of the reference
     virtual void render(UINT frameIndex, UINT width, UINT height) override
     {
         (void)frameIndex;
@@ -50,6 +51,25 @@ public:
     {
         fillShaderTable();
         DXRFramework::ThrowIfFailed(rt_pipeline_render_bands(mPipeline, width, height, bandRows, rank, world));
+    }
+
+    // n frames = n x { update(...); render(...) } with the same bits in the output, through shared sets of launches
+    // (rt_pipeline_render_batch; the sample-batch mode of long accumulations).  elapsedFrames is the frame count of the FIRST
+    // of them; the host state (jitter RNG, accumulation counter) advances exactly as n update() calls would advance it.
+    void renderBatch(float elapsedTime, UINT firstElapsedFrames, UINT n, UINT width, UINT height)
+    {
+        std::vector<PerFrameConstants> constants(n);
+        float cam[11];
+        mCamera->Pack(cam);
+        rt_debug_options *opt = nullptr;
+        DXRFramework::ThrowIfFailed(rt_progressive_host_options(mHost, &opt));
+        *opt = mShaderDebugOptions;
+        DXRFramework::ThrowIfFailed(rt_progressive_host_set_flags(mHost, mFrameAccumulationEnabled, mAnimationPaused));
+        for (UINT i = 0; i < n; ++i)
+            DXRFramework::ThrowIfFailed(rt_progressive_host_update(mHost, cam, elapsedTime, firstElapsedFrames + i, width, height, &constants[i]));
+        fillShaderTable();
+        DXRFramework::ThrowIfFailed(rt_pipeline_render_batch(mPipeline, width, height, constants.data(), n));
+        if (n) mConstants = constants[n - 1];
     }
 
     // what render() does before DispatchRays (:217-240): per-instance hit records, miss records, apply

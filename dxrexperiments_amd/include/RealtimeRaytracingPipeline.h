@@ -31,6 +31,7 @@ public:
         DXRFramework::ThrowIfFailed(rt_pipeline_update(mPipeline, &mConstants));
     }
 
+    using RaytracingPipeline::render;       // the (commandList, frameIndex, width, height) form of the reference
     virtual void render(UINT frameIndex, UINT width, UINT height) override
     {
         (void)frameIndex;

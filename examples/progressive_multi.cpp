@@ -42,11 +42,13 @@ static int rank_main(int rank, int world, int id_in, int id_out, char **argv)
     const UINT band_rows = 16;
     try {
         int devices = rt_device_count();
-        if (devices < world) {
+        // (test hook: DXR_MULTI_DEVICE=<ordinal> puts every rank on that device -- rt_dist_create must then refuse, not hang)
+        const char *forced = std::getenv("DXR_MULTI_DEVICE");
+        if (!forced && devices < world) {
             std::fprintf(stderr, "rank %d: %d ranks but %d visible GPUs (RCCL wants one device per rank)\n", rank, world, devices);
             return 3;
         }
-        auto context = RtContext::create(rank);
+        auto context = RtContext::create(forced ? std::atoi(forced) : rank);
         // rank 0 creates the communicator id; the launcher relays it to the other ranks
         char id[128];
         if (rank == 0) {
@@ -96,6 +98,13 @@ static int rank_main(int rank, int world, int id_in, int id_out, char **argv)
         else ThrowIfFailed(rt_dist_all_reduce_sum(dist, image_dev, size_t(width) * height * 4));
         ThrowIfFailed(rt_context_synchronize(context->getHandle()));
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        {   // one line per rank: which device it really ran on and what the collective cost there
+            char bus[64] = "?";
+            float coll_ms = 0.0f;
+            (void)rt_dist_device_pci_bus_id(context->getHandle(), bus, sizeof bus);
+            ThrowIfFailed(rt_dist_last_collective_ms(dist, &coll_ms));
+            std::fprintf(stderr, "rank %d of %d: device %d (PCI %s), %.3f s, collective %.3f ms\n", rank, world, context->getDevice(), bus, s, coll_ms);
+        }
         if (!tiles) {
             uint32_t expect = 0;
             ThrowIfFailed(rt_shard_frame_count(rank, world, frames, &expect));
@@ -140,6 +149,7 @@ int main(int argc, char **argv)
         if (pid == 0) {
             for (int k = 0; k < world; k++) { close(to_child[2 * k + 1]); if (k != r) close(to_child[2 * k]); }
             close(from_zero[0]);
+            if (r != 0) close(from_zero[1]);           // only rank 0 writes the id: if it dies first, the launcher must see EOF
             const int rc = rank_main(r, world, to_child[2 * r], from_zero[1], argv);
             std::fflush(stdout);
             _exit(rc);
@@ -151,6 +161,10 @@ int main(int argc, char **argv)
     char id[128];
     bool ok = read_all(from_zero[0], id, sizeof id);
     for (int r = 1; r < world && ok; r++) ok = write_all(to_child[2 * r + 1], id, sizeof id);
+    // whether or not the id went round, the write ends are closed now: a rank still waiting for its id reads EOF and exits
+    // instead of blocking for ever (rank 0 died before it made the id: no GPU, no RCCL, model file missing ...)
+    for (int r = 0; r < world; r++) close(to_child[2 * r + 1]);
+    close(from_zero[0]);
     int worst = ok ? 0 : 7;
     for (pid_t pid : pids) {
         int status = 0;

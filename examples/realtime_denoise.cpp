@@ -59,10 +59,16 @@ int main(int argc, char **argv)
         for (UINT frame = 1; frame <= frames; ++frame) {
             pipeline->update(0.0f, frame, (frame + 2) % 3, frame % 3, width, height);
             pipeline->render(frame % 3, width, height);
-            DenoiseCompositor::InputComponents in{};                    // DXRExperimentsApp.cpp:202-206
-            in.directLightingSrv = pipeline->getOutputResource(0);
-            in.indirectSpecularSrv = pipeline->getOutputResource(1);
-            denoiser->dispatch(in, frame % 3, width, height);
+            // src/DXRExperimentsApp.cpp:198-212, line for line (commandList: unused here)
+            ID3D12GraphicsCommandList *commandList = nullptr;
+            for (int i = 0; i < pipeline->getNumOutputs(); ++i)
+                context->transitionResource(pipeline->getOutputResource(i), D3D12_RESOURCE_STATE_UNORDERED_ACCESS, D3D12_RESOURCE_STATE_NON_PIXEL_SHADER_RESOURCE);
+            DenoiseCompositor::InputComponents inputs = {};
+            inputs.directLightingSrv = pipeline->getOutputSrvHandle(0);
+            inputs.indirectSpecularSrv = pipeline->getOutputSrvHandle(1);
+            denoiser->dispatch(commandList, inputs, frame % 3, width, height);
+            for (int i = 0; i < pipeline->getNumOutputs(); ++i)
+                context->transitionResource(pipeline->getOutputResource(i), D3D12_RESOURCE_STATE_NON_PIXEL_SHADER_RESOURCE, D3D12_RESOURCE_STATE_UNORDERED_ACCESS);
         }
         std::vector<float> image(size_t(width) * height * 4);
         denoiser->readOutput(image.data(), image.size() * sizeof(float));

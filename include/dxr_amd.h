@@ -67,8 +67,11 @@ int rt_device_download(rt_context *ctx, void *host_dst, const void *device_src, 
 
 /* ---- RtModel (libs/DXRFramework/RtModel.h:13, RtModel.cpp:24-118) ---------- */
 
-/* RtModel::create(ctx, filePath) (RtModel.h:13).  Wavefront OBJ only; see
- * DESIGN.md for the vertex/primitive ordering this reader defines. */
+/* RtModel::create(ctx, filePath) (RtModel.h:13; the reference imports through Assimp, RtModel.cpp:26-27).  By extension:
+ * ".fbx" -> the binary-FBX mesh reader (rt_fbx.cpp: Geometry nodes' Vertices / PolygonVertexIndex / LayerElementNormal,
+ * zlib arrays, Lcl transforms of the owning Model; enough for the reference's assets/models/ground.fbx), anything else ->
+ * Wavefront OBJ.  See DESIGN.md for the vertex / primitive ordering these readers define. */
+int rt_model_create_from_file(rt_context *ctx, const char *path, rt_model **out);
 int rt_model_create_from_obj(rt_context *ctx, const char *path, rt_model **out);
 /* The arrays RtModel's constructor builds (RtModel.cpp:33-81). */
 int rt_model_create_from_arrays(rt_context *ctx, const rt_vertex *verts, uint32_t n_verts,
@@ -304,13 +307,21 @@ int rt_tile_bands(uint32_t height, uint32_t band_rows, uint32_t rank, uint32_t w
 int rt_tile_gather_layout(uint32_t width, uint32_t height, uint32_t band_rows, uint32_t world, uint32_t *slots_per_rank, size_t *floats_per_rank);
 typedef struct rt_dist rt_dist;
 int rt_dist_get_unique_id(void *id128);                                   /* ncclGetUniqueId: rank 0 makes it, the launcher hands it round */
-int rt_dist_create(rt_context *ctx, int rank, int world, const void *id128, rt_dist **out);   /* ncclCommInitRank on ctx's device */
+/* ncclCommInitRank on ctx's device.  Before that, the ranks of one node compare the PCI bus ids of their devices through
+ * files in /dev/shm named after the id (RT_DIST_CHECK_SECONDS, default 20, 0 = off): two ranks on one device -- where RCCL
+ * would fail late or hang -- are RT_ERR_INVALID_ARG here.  (The reference runs on one adapter, NodeMask 0:
+ * libs/DXRFramework/RtContext.cpp:37.) */
+int rt_dist_create(rt_context *ctx, int rank, int world, const void *id128, rt_dist **out);
 int rt_dist_destroy(rt_dist *d);
 int rt_dist_get_rank(const rt_dist *d, int *rank, int *world);
 /* partition A: in-place SUM all-reduce of `count` floats (the RT_ACCUM_SUM image of rt_pipeline_get_output_device_ptr) */
 int rt_dist_all_reduce_sum(rt_dist *d, void *device_f32, size_t count);
 /* partition B: every rank holds its own bands of the width x height RGBA32F image; afterwards every rank holds all of it */
 int rt_dist_gather_bands(rt_dist *d, void *device_rgba32f, uint32_t width, uint32_t height, uint32_t band_rows);
+/* HIP-event time of the last collective on the context's stream (all-reduce; gather: pack + all-gather + unpack); synchronises */
+int rt_dist_last_collective_ms(rt_dist *d, float *ms);
+/* "0000:c1:00.0"-style PCI bus id of the context's device: what a launcher prints per rank */
+int rt_dist_device_pci_bus_id(const rt_context *ctx, char *out, size_t capacity);
 
 /* ---- image files for host copies of the outputs (the reference only blits to its window,
  *      src/DXRExperimentsApp.cpp:213-214).  rgba32f = width*height float4, row 0 on top. ---------------- */
@@ -334,6 +345,9 @@ int rt_debug_sample_cube(rt_context *ctx, const float *faces_rgba32f, uint32_t s
 int rt_dds_read_cube(const char *path, float *faces_rgba32f, size_t capacity_floats, uint32_t *size);
 /* The OBJ reader behind rt_model_create_from_obj, without a device: counts first (verts / indices NULL), then data. */
 int rt_obj_read(const char *path, rt_vertex *verts, uint32_t capacity_verts, uint32_t *indices, uint32_t capacity_tris,
+                uint32_t *n_verts, uint32_t *n_tris);
+/* The binary-FBX reader behind rt_model_create_from_file, likewise */
+int rt_fbx_read(const char *path, rt_vertex *verts, uint32_t capacity_verts, uint32_t *indices, uint32_t capacity_tris,
                 uint32_t *n_verts, uint32_t *n_tris);
 
 #ifdef __cplusplus

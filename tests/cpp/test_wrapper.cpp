@@ -62,12 +62,17 @@ int main(int argc, char **argv)
             realtime->buildAccelerationStructures();
             if (realtime->getNumOutputs() != 2 || std::string(realtime->getName()) != "Realtime Ray Tracing Pipeline") return 7;
             realtime->update(0.0f, 5, 0, 0, W, H);
-            realtime->render(0, W, H);
+            realtime->render((ID3D12GraphicsCommandList *)nullptr, 0, W, H);      // the reference's signature
             auto denoiser = DenoiseCompositor::create(context);
             denoiser->loadResources(3, false);
             denoiser->createOutputResource(RT_FORMAT_R32G32B32A32_FLOAT, W, H);
-            DenoiseCompositor::InputComponents inputs = {realtime->getOutputResource(0), realtime->getOutputResource(1)};
-            denoiser->dispatch(inputs, 0, W, H);
+            // the reference's call site (src/DXRExperimentsApp.cpp:202-206): SRV handles from the pipeline, command list first
+            DenoiseCompositor::InputComponents inputs = {};
+            inputs.directLightingSrv = realtime->getOutputSrvHandle(0);
+            inputs.indirectSpecularSrv = realtime->getOutputSrvHandle(1);
+            if (inputs.directLightingSrv.ptr != (unsigned long long)(size_t)realtime->getOutputResource(0) ||
+                realtime->getOutputUavHandle(1).ptr != (unsigned long long)(size_t)realtime->getOutputResource(1)) return 12;
+            denoiser->dispatch((ID3D12GraphicsCommandList *)nullptr, inputs, 0, W, H);
             std::vector<float> three(size_t(W) * H * 4 * 3);
             realtime->readOutput(0, three.data(), image.size() * 4);
             realtime->readOutput(1, three.data() + image.size(), image.size() * 4);

@@ -324,6 +324,31 @@ def test_sponza_1080p_tiles_equal_whole_frame(sponza_pipeline, capi):
     assert np.isfinite(whole).all() and whole[..., 3].min() == 1.0 and whole[..., :3].min() >= 0.0
 
 
+def test_sponza_1080p_frame_digest(sponza_pipeline, capi):
+    """Drift fixture: the sha256 of BASELINE config C2's first two accumulated 1080p frames (host seed 1234, the
+    bench camera) is committed in tests/golden/reference_assets.json.  The oracle comparison of this scene runs at 192x108;
+    at full size the image is only property-checked, so a change of any bit of it between rounds would otherwise go
+    unnoticed.  (The exactness rule makes the image independent of tree, node width and traversal order: the digest of
+    round 3's four-wide and eight-wide builds is the same.)  DXR_RECORD_DIGEST=1 prints the digest instead of checking it."""
+    import hashlib
+    import json
+    import os
+    p, _, W, H = sponza_pipeline
+    host = capi.ProgressiveHost(1234)
+    cam = cam_array(scenes.sponza_camera(), W / H)
+    p.set_accumulation_mode(T.ACCUM_RUNNING_MEAN)
+    p.clear_output()
+    for f in range(2):
+        p.update(host.update(cam, 0.0, f + 1, W, H))
+        p.render()
+    digest = hashlib.sha256(np.ascontiguousarray(p.read_output()).tobytes()).hexdigest()
+    if os.environ.get("DXR_RECORD_DIGEST"):
+        print("\nC2_1080P_2FRAMES_SHA256", digest)
+        return
+    want = json.load(open(GOLDEN + "/reference_assets.json"))["c2_1080p_two_frames_sha256"]
+    assert digest == want, "the 1080p bench frame changed: %s" % digest
+
+
 def test_sponza_1080p_sample_sharding_sum_equals_mean(sponza_pipeline, capi):
     """Multi-GPU partitioning A on one device: R shards render disjoint frame subsets into SUM
     buffers; (sum of sums)/N must match the running mean within fp32 re-association."""

@@ -158,6 +158,13 @@ def test_bench_two_ranks_on_one_gpu():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["frames_per_gpu"] == 4
+    # the N > 1 line says what really ran: both ranks seen, their backend, devices and PCI ids (ONE device here: that is the
+    # point of this test and exactly what the line must expose), a measured collective per rank, the elapsed spread
+    rk = d["ranks"]
+    assert rk["ranks_seen"] == 2 and rk["backend"] == "gloo" and rk["device_ordinals"] == [0, 0]
+    assert len(rk["pci_bus_ids"]) == 2 and rk["pci_bus_ids"][0] == rk["pci_bus_ids"][1] and rk["distinct_devices"] == 1
+    assert len(set(rk["pids"])) == 2 and all(ms > 0.0 for ms in rk["collective_ms"])
+    assert 0.0 < rk["elapsed_s_min"] <= rk["elapsed_s_max"]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--width", "480", "--height", "270",
                           "--cpu-seconds", "0", "--no-live-pmc", "--hbm-frames", "0"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-3000:]

@@ -207,3 +207,16 @@ def test_surface_area_collapse_option(gpu, capi):
     boxes = np.stack([sc3.instance_info(k)[0] for k in range(150)])
     W.check(tn, troot, boxes[:, :3], boxes[:, 3:], 150, blas=False)
     _same_hits(sc3, O, D)
+
+
+def test_three_blases_two_of_them_lds_resident(gpu, capi):
+    """Two-level kernels keep the tops of the TLAS and of the TWO most-instanced BLASes in LDS (round 3); a third model's
+    instances walk their BLAS from global memory.  Same hits as the canonical kernel for all three, in both usage orders."""
+    from util import random_rays
+    models = [scenes.blob_mesh(level=2), triangle_soup(600, seed=21, extent=2.0, size=0.5), triangle_soup(3000, seed=22, extent=2.5, size=0.3)]
+    xf = random_xforms(90, seed=23, spread=9.0)
+    O, D = random_rays(40000, 9, np.full(3, -12.0), np.full(3, 12.0))
+    for order in ((0, 1, 2), (2, 0, 1)):                 # which model is the rare one (10 of 90 instances)
+        inst = [(order[0] if k % 9 else order[2], xf[k]) if k % 2 else (order[1] if k % 9 else order[2], xf[k]) for k in range(90)]
+        sc = build(capi, gpu, models, inst)
+        _same_hits(sc, O, D)

@@ -3,6 +3,7 @@ DDS environment ingestion and the RGBA16F output view."""
 import os
 import struct
 import subprocess
+import time
 
 import numpy as np
 import pytest
@@ -159,3 +160,10 @@ def test_multi_gpu_example_from_the_c_abi(tmp_path, mode):
     # more ranks than GPUs is refused up front, not deadlocked
     r = subprocess.run([multi, CORNELL_OBJ, "32", "32", "1", str(a), "2", mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode != 0 and "visible GPUs" in r.stdout
+    # two ranks forced onto ONE device: rt_dist_create compares the ranks' PCI bus ids before RCCL is asked, and says so
+    # (RCCL itself would fail late or hang); the launcher returns promptly with a non-zero code
+    t0 = time.time()
+    r = subprocess.run([multi, CORNELL_OBJ, "32", "32", "1", str(a), "2", mode], env=dict(os.environ, DXR_MULTI_DEVICE="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode != 0 and "are both on the device at PCI" in r.stdout, r.stdout
+    assert time.time() - t0 < 120

@@ -199,3 +199,74 @@ def test_oracle_denoiser_on_the_reference_mock_inputs(oracle):
     h, final = oracle.denoise(direct, indirect, params)
     assert np.array_equal(h, g["pass_h"]) and np.array_equal(final, g["composite"])
     assert g["direct_rgba8"].std() > 10 and g["indirect_rgba8"].std() > 5      # real image content, not a flat crop
+
+
+# ---- binary FBX (libs/DXRFramework/RtModel.cpp:24-82 imports "Machines.fbx" / ground.fbx through Assimp) -------------------
+
+def _fbx_cases():
+    r = np.random.default_rng(12)
+    # a bumpy 5 x 4 grid of quads + a pentagon and a triangle, per-polygon-vertex normals
+    gx, gz = np.meshgrid(np.arange(5.0), np.arange(4.0), indexing="xy")
+    P = np.stack([gx.ravel(), r.uniform(-0.3, 0.3, 20), gz.ravel()], axis=1)
+    quads = [[y * 5 + x, y * 5 + x + 1, (y + 1) * 5 + x + 1, (y + 1) * 5 + x] for y in range(3) for x in range(4)]
+    polys = quads + [[0, 1, 7, 11, 5], [2, 3, 8]]
+    npv = sum(len(q) for q in polys)
+    Nn = r.normal(size=(npv, 3)); Nn /= np.linalg.norm(Nn, axis=1, keepdims=True)
+    Nv = r.normal(size=(20, 3)); Nv /= np.linalg.norm(Nv, axis=1, keepdims=True)
+    Nn[4:8] = Nn[0:4]                                        # repeated values: vertices of two quads join
+    pool = r.normal(size=(6, 3)); pool /= np.linalg.norm(pool, axis=1, keepdims=True)
+    return {
+        "by_polygon_vertex_zlib_v7500": (dict(positions=P, polygons=polys, normals=Nn), 7500, True),
+        "by_polygon_vertex_raw_v7400": (dict(positions=P, polygons=polys, normals=Nn), 7400, False),
+        "by_vertice": (dict(positions=P, polygons=polys, normals=Nv, mapping="ByVertice"), 7500, True),
+        "index_to_direct": (dict(positions=P, polygons=polys, normals=pool, normals_index=r.integers(0, 6, npv)), 7700, True),
+        "model_transform": (dict(positions=P, polygons=polys, normals=Nn, translation=(1.5, -2.0, 0.25), rotation=(30.0, -45.0, 10.0),
+                                 scaling=(2.0, 0.5, 1.25)), 7500, True),
+    }
+
+
+@pytest.mark.parametrize("case", sorted(_fbx_cases()))
+def test_fbx_reader_on_synthesised_files(capi, tmp_path, case):
+    """rt_fbx_read (the reader behind RtModel::create for .fbx) against tests/fbx_tools.py's independent parser on files
+    written by the tests' own FBX writer: both record widths, raw and zlib arrays, every normal mapping, a Model transform."""
+    import fbx_tools as F
+    mesh, version, compress = _fbx_cases()[case]
+    two = [mesh, dict(mesh, positions=np.asarray(mesh["positions"]) + 10.0)]       # two Geometry nodes: concatenated, indices rebased
+    path = str(tmp_path / (case + ".fbx"))
+    F.write(path, two, version=version, compress=compress)
+    want_v, want_i = F.ingest(path)
+    v, i = capi.fbx_read(path)
+    got = flat(v)
+    assert i.shape == want_i.shape and np.array_equal(i, want_i)
+    if case == "model_transform":               # float64 matrix products in two implementations: last-bit differences allowed
+        assert np.allclose(got, want_v, rtol=0, atol=2e-6)
+    else:
+        assert np.array_equal(got.view(np.uint32), want_v.view(np.uint32))
+    assert i.shape[0] == 2 * (12 * 2 + 3 + 1) and i.max() == v.shape[0] - 1
+
+
+def test_fbx_reader_refuses_what_it_does_not_understand(capi, tmp_path):
+    from dxrexperiments_amd.capi import RtError
+    bad = tmp_path / "ascii.fbx"
+    bad.write_text("; FBX 7.5.0 project file\nFBXHeaderExtension:  {\n}\n")
+    with pytest.raises(RtError, match="not a binary FBX"):
+        capi.fbx_read(str(bad))
+    cut = tmp_path / "cut.fbx"
+    import fbx_tools as F
+    F.write(str(cut), [_fbx_cases()["by_vertice"][0]])
+    data = cut.read_bytes()
+    cut.write_bytes(data[:len(data) // 2])
+    with pytest.raises(RtError):
+        capi.fbx_read(str(cut))
+
+
+@have_ref
+def test_product_fbx_reader_on_the_reference_model(capi, pins):
+    p = pins["ground.fbx"]
+    v, i = capi.fbx_read(REF + "/models/ground.fbx")
+    assert v.shape[0] == p["vertices"] and i.shape[0] == p["triangles"]
+    assert sha(flat(v)) == p["verts_sha256"] and sha(i) == p["indices_sha256"]
+    assert np.array_equal(np.concatenate([v["position"].min(axis=0), v["position"].max(axis=0)]), np.array(p["bounds"], np.float32))
+    import fbx_tools as F
+    iv, ii = F.ingest(REF + "/models/ground.fbx")           # the independent parser again, live
+    assert sha(iv) == p["verts_sha256"] and sha(ii) == p["indices_sha256"]

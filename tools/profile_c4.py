@@ -41,6 +41,13 @@ for f in range(frames):
 st = pipe.stats()
 rays = st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]
 w = pipe.count_walk()
-print("C4: 4096 instances of 2 BLASes, 4K realtime frame %.2f ms = %.0f Mrays/s, denoise %.3f ms, TLAS+BLAS build %.2f ms; stages %s"
-      % (st["ms_total"], rays / st["ms_total"] / 1e3, dn.last_ms(), scene.build_ms(),
-         {k: (v["rays"], round((v["nodes_global"] + v["nodes_lds"]) / max(v["rays"], 1), 1), round(v["instance_entries"] / max(v["rays"], 1), 2)) for k, v in w.items()}))
+print("C4: 4096 instances of 2 BLASes, 4K realtime frame %.2f ms = %.0f Mrays/s, denoise %.3f ms, TLAS+BLAS build %.2f ms"
+      % (st["ms_total"], rays / st["ms_total"] / 1e3, dn.last_ms(), scene.build_ms()))
+print("   stage ms: primary %.3f shade0 %.3f secondary %.3f shade1 %.3f shadow %.3f resolve %.3f"
+      % (st["ms_primary"], st["ms_shade0"], st["ms_trace_secondary"], st["ms_shade1"], st["ms_trace_shadow0"] + st["ms_trace_shadow1"], st["ms_resolve"]))
+# what the production walk fetched (rt_pipeline_count_walk): per ray node steps from global memory / from the LDS tops, triangle
+# tests, instance entries, distinct 64-B lines gathered -- the figures the single-level workloads report in bench.py
+for k, v in w.items():
+    n = max(v["rays"], 1)
+    print("   %-9s rays %9d  nodes global %.2f  lds %.2f  tris %.2f  instance entries %.2f  lines %.2f  longest walk %d"
+          % (k, v["rays"], v["nodes_global"] / n, v["nodes_lds"] / n, v["tris"] / n, v["instance_entries"] / n, v["lines"] / n, v["longest_walk"]))

@@ -2,7 +2,7 @@
 """profiles/<round>/{c2,c5}_{kt,fetch,write,tcc,sq}.md -> profiles/<round>/traffic.json: per workload and traversal kernel
 the memory-side bytes per launch (`roofline.traffic` in bench.py), the rocprofv3 average duration and the SQ / TCC counters.
 
-usage: tools/traffic_from_pmc.py profiles/r02
+usage: tools/traffic_from_pmc.py profiles/r03
 gfx950 (MI355X_MICROARCH.md, HBM section): FETCH_SIZE = TCC_EA0_RDREQ x 64 B whatever the request size, exact only for 64-B
 requests and half the bytes of wide streaming reads; other access shapes are "uncalibrated", so the read bytes are taken from
 the requests BY SIZE (TCC_EA0_RDREQ_32B / _64B / _128B, a pass of their own): bytes_per_launch = 32 n32 + 64 n64 + 128 n128 +
@@ -44,6 +44,7 @@ def main():
     for w in ("c2", "c5", "c4"):
         kt, fe, wr = rows("%s/%s_kt.md" % (d, w)), rows("%s/%s_fetch.md" % (d, w)), rows("%s/%s_write.md" % (d, w))
         tcc, sq, ea = rows("%s/%s_tcc.md" % (d, w)), rows("%s/%s_sq.md" % (d, w)), rows("%s/%s_ea.md" % (d, w))
+        tcp, ta2 = rows("%s/%s_tcp.md" % (d, w)), rows("%s/%s_ta2.md" % (d, w))
         if not fe:
             continue
         ks = {}
@@ -64,10 +65,16 @@ def main():
             if (k, "avg_us") in kt:
                 e["avg_us"] = kt[(k, "avg_us")]
                 e["GBps"] = e["bytes_per_launch"] / (e["avg_us"] * 1e-6) / 1e9
-            for src in (tcc, sq, ea):
+            for src in (tcc, sq, ea, tcp, ta2):
                 for (kk, c), v in src.items():
                     if kk == k and not c.endswith(":n"):
                         e[c] = v
+            # round 3: how busy the SIMDs' vector ALUs were (the gfx9 VALUBusy formula: active VALU quad-cycles x 4 over SIMDs x
+            # shader-engine-active cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs) and the L1 -> L2 read-request rate
+            if "SQ_ACTIVE_INST_VALU" in e and e.get("GRBM_GUI_ACTIVE"):
+                e["valu_busy"] = e["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * e["GRBM_GUI_ACTIVE"] / 8.0)
+            if "TCP_TCC_READ_REQ_sum" in e and "avg_us" in e:
+                e["l2_read_requests_per_s"] = e["TCP_TCC_READ_REQ_sum"] / (e["avg_us"] * 1e-6)
             ks[k] = e
         out["workloads"][w] = {"kernels": ks}
     with open(d + "/traffic.json", "w") as fp:
