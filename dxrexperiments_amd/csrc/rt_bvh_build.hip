@@ -508,8 +508,13 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
             use[k].second++;
         }
         s->lds_blas[0] = s->lds_blas[1] = nullptr;
-        const char *off = getenv("RT_LDS_BLAS");            // RT_LDS_BLAS=0: BLAS nodes always from global memory (A/B measurements)
-        for (int slot = 0; slot < 2 && !(off && atoi(off) == 0); slot++) {
+        // (only a library built with -DRT_LDS_BLAS_TOPS uses this: round 3's experiment, rt_trace_wave.h)
+#ifdef RT_LDS_BLAS_TOPS
+        const bool on = true;
+#else
+        const bool on = false;
+#endif
+        for (int slot = 0; slot < 2 && on; slot++) {
             size_t best = use.size();
             for (size_t k = 0; k < use.size(); k++)
                 if (use[k].first != s->lds_blas[0] && use[k].first->blas.wide_n > 0 && (best == use.size() || use[k].second > use[best].second)) best = k;

@@ -566,22 +566,28 @@ RT_DEV void wave_add(uint32_t v, uint32_t *counter)
 // ---- kernels -------------------------------------------------------------------------
 
 // primary stage: raygen is the ray source, the level-0 hit records the sink (indexed by pixel slot)
-struct PrimarySrc {
+// BATCH = false: one frame, the code of round 2; true: the slot's frame picks the camera (also right for one frame)
+template <bool BATCH>
+struct PrimarySrcT {
     const PipeDev &pd;
     RT_DEV uint32_t count() const { return pd.cap; }
     RT_DEV uint32_t flags() const { return RT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES; }      // ProgressiveRaytracing.hlsl:34
     RT_DEV bool load(uint32_t q, RayD &r) const
     {
-        uint32_t px, py, ql;
-        // (64 consecutive slots = one tile = one chunk of a wave: the frame is the same for every lane that loads here)
-        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_frame(pd, q, ql));
-        const bool valid = pix_xy(pd, ql, px, py);
-        rt_camera_params cp = pd.pfc.cameraParams;
-        if (pd.n_frames > 1u) cp = pd.pfcs[f].cameraParams;
-        r = primary_ray(pd, cp, px, py);
+        uint32_t px, py;
+        if (BATCH && pd.n_frames > 1u) {         // (a kernel argument: the branch is uniform)
+            // 64 consecutive slots = one tile = one chunk of a wave: the frame is the same for every lane that loads here
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)(q / pd.fcap));
+            const bool valid = pix_xy(pd, q - f * pd.fcap, px, py);
+            r = primary_ray(pd, pd.pfcs[f].cameraParams, px, py);
+            return valid;
+        }
+        const bool valid = pix_xy(pd, q, px, py);
+        r = primary_ray(pd, px, py);
         return valid;
     }
 };
+typedef PrimarySrcT<true> PrimarySrc;        // (the counting kernels)
 struct PrimarySink {
     const PipeDev &pd;
     RT_DEV void store(uint32_t q, const HitD &h, bool) const
@@ -592,7 +598,7 @@ struct PrimarySink {
     }
 };
 
-template <int STACK, bool TWO_LEVEL>
+template <int STACK, bool TWO_LEVEL, bool BATCH>
 __global__ void __launch_bounds__(PBLOCK) k_primary(PipeDev pd)
 {
     __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
@@ -600,7 +606,7 @@ __global__ void __launch_bounds__(PBLOCK) k_primary(PipeDev pd)
     // kernel of the frame does) instead of a 20-KB fill launch of its own
     if (blockIdx.x == 0)
         for (uint32_t i = threadIdx.x; i < (uint32_t)(POOL_OFFSET_WORDS + POOL_BYTES / 4); i += PBLOCK) pd.counters[i] = 0u;
-    PrimarySrc src = {pd};
+    PrimarySrcT<BATCH> src = {pd};
     PrimarySink sink = {pd};
     trace_wave<STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, nullptr, smem, nullptr);   // one 8x8 tile per wave, dealt by the hardware dispatcher
 }
@@ -712,12 +718,15 @@ struct QueueSrc {
     const uint32_t *count_ptr;
     uint32_t stride, batches, fl;
     LightRays lights;
-    const LightRays *frame_lights;      // a batch of frames: the lights of frame f (bits 8.. of the hit's word); nullptr: `lights`
     RT_DEV uint32_t n() const { return *count_ptr; }
     RT_DEV uint32_t count() const { return n() * batches; }
     RT_DEV uint32_t flags() const { return fl; }
     RT_DEV size_t slot(uint32_t i) const { const uint32_t c = n(); return (size_t)(i / c) * stride + i % c; }
-    RT_DEV bool load(uint32_t i, RayD &r) const
+    RT_DEV bool load(uint32_t i, RayD &r) const { return load_lit(i, r, nullptr); }
+    // per_frame: a batch of frames -- the lights of frame f (bits 8.. of the hit's word).  The single-frame kernels call this
+    // with a literal nullptr: the branch folds away and their code is what it was before batches existed (with the branch
+    // compiled in, the five inlined copies of this loader cost the any-hit kernel 30 VGPRs and 128 B of scratch).
+    RT_DEV bool load_lit(uint32_t i, RayD &r, const LightRays *per_frame) const
     {
         if (lights.on) {
             const uint32_t c = n(), b = i / c;
@@ -730,13 +739,23 @@ struct QueueSrc {
             if (!((bits >> b) & 1u)) return false;
             if ((bits >> (2u + b)) & 1u) { r.tmax = RT_TMAX_SKIPPED; return false; }
             r.tmin = RAY_EPSILON;
-            LightRays lt = lights;
-            if (frame_lights) lt = frame_lights[(bits >> 8) & 0xffu];
+            if (per_frame) {                                 // (three floats by hand: a struct copy ends up in scratch memory)
+                const float *fl = b == 0u ? per_frame[(bits >> 8) & 0xffu].dir_to_light : per_frame[(bits >> 8) & 0xffu].point_pos;
+                const f3 l = mk3(fl[0], fl[1], fl[2]);
+                if (b == 0u) { r.d = l; r.tmax = RAY_MAX_T; }
+                else {
+                    const f3 path = l - r.o;
+                    const float dist = length(path);
+                    r.d = normalize(path);
+                    r.tmax = dist - RAY_EPSILON;
+                }
+                return r.tmax > r.tmin;
+            }
             if (b == 0u) {
-                r.d = mk3(lt.dir_to_light[0], lt.dir_to_light[1], lt.dir_to_light[2]);
+                r.d = mk3(lights.dir_to_light[0], lights.dir_to_light[1], lights.dir_to_light[2]);
                 r.tmax = RAY_MAX_T;
             } else {
-                const f3 path = mk3(lt.point_pos[0], lt.point_pos[1], lt.point_pos[2]) - r.o;
+                const f3 path = mk3(lights.point_pos[0], lights.point_pos[1], lights.point_pos[2]) - r.o;
                 const float dist = length(path);
                 r.d = normalize(path);
                 r.tmax = dist - RAY_EPSILON;
@@ -772,6 +791,16 @@ static inline LightRays no_light_rays()
     return l;
 }
 
+// a queue read with the batch's per-frame lights (nullptr: a single frame); the counting kernels are not register critical
+struct LitQueueSrc {
+    QueueSrc q;
+    const LightRays *per_frame;
+    RT_DEV uint32_t n() const { return q.n(); }
+    RT_DEV uint32_t count() const { return q.count(); }
+    RT_DEV uint32_t flags() const { return q.flags(); }
+    RT_DEV bool load(uint32_t i, RayD &r) const { return q.load_lit(i, r, per_frame); }
+};
+
 struct SecondarySink {
     QueueSrc q;
     float4 *hit1;
@@ -786,10 +815,15 @@ struct SecondarySink {
 };
 
 // every shadow ray of the frame in ONE launch: the shadow queues of all shaded levels, back to back
-struct ShadowSrcN {
+// BATCH: the launch covers several frames, a ray takes the light rays of its hit's frame
+struct ShadowQueues {
     QueueSrc q[MAXD + 1];
     uint32_t *vis[MAXD + 1];
     int nq;
+    const LightRays *frame_lights;      // device array [n_frames] (batches)
+};
+template <bool BATCH>
+struct ShadowSrcN : ShadowQueues {
     // (the loops are fully unrolled so that q[k] is always a compile-time member of the kernel argument)
     RT_DEV uint32_t count() const
     {
@@ -805,7 +839,7 @@ struct ShadowSrcN {
         for (int k = 0; k <= MAXD; k++) {
             if (k < nq) {
                 const uint32_t c = q[k].count();
-                if (i < c) return q[k].load(i, r);
+                if (i < c) return q[k].load_lit(i, r, BATCH ? frame_lights : nullptr);
                 i -= c;
             }
         }
@@ -814,7 +848,7 @@ struct ShadowSrcN {
     }
 };
 struct ShadowSinkN {      // ShadowMiss sets visibility 1 (ProgressiveRaytracing.hlsl:178-182)
-    ShadowSrcN s;
+    ShadowQueues s;
     RT_DEV void store(uint32_t i, const HitD &h, bool) const
     {
 #pragma unroll
@@ -828,11 +862,13 @@ struct ShadowSinkN {      // ShadowMiss sets visibility 1 (ProgressiveRaytracing
     }
 };
 
-template <int STACK, bool TWO_LEVEL>
-__global__ void __launch_bounds__(PBLOCK) k_trace_shadow(SceneDev sc, ShadowSrcN src, uint32_t *pool, uint32_t *stat)
+template <int STACK, bool TWO_LEVEL, bool BATCH>
+__global__ void __launch_bounds__(PBLOCK) k_trace_shadow(SceneDev sc, ShadowQueues queues, uint32_t *pool, uint32_t *stat)
 {
     __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
-    ShadowSinkN sink = {src};
+    ShadowSrcN<BATCH> src;
+    static_cast<ShadowQueues &>(src) = queues;
+    ShadowSinkN sink = {queues};
     trace_wave<STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK, RT_SHADOW_UNORDERED != 0>(sc, src, sink, pool, smem, stat);
 }
 
@@ -864,7 +900,7 @@ __global__ void __launch_bounds__(PBLOCK) k_walk_queue(SceneDev sc, QueueSrc src
     trace_wave<RT_LDS_STACK_ROWS, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK, false, true>(sc, src, sink, nullptr, smem, nullptr, walk);
 }
 template <bool TWO_LEVEL>
-__global__ void __launch_bounds__(PBLOCK) k_walk_shadow(SceneDev sc, QueueSrc src, unsigned long long *walk)
+__global__ void __launch_bounds__(PBLOCK) k_walk_shadow(SceneDev sc, LitQueueSrc src, unsigned long long *walk)
 {
     __shared__ int smem[(RT_LDS_STACK_ROWS + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     NullSink sink;
@@ -979,18 +1015,18 @@ RT_DEV void wave_add64(unsigned long long v, unsigned long long *counter)
 
 // canonical-order re-trace of a queue: sums rays / nodes / triangles into out[0..2]
 __global__ void __launch_bounds__(PBLOCK)
-k_count_queue(SceneDev sc, QueueSrc src, unsigned long long *__restrict__ out)
+k_count_queue(SceneDev sc, LitQueueSrc src, unsigned long long *__restrict__ out)
 {
     const uint32_t n = src.n();
     const uint32_t idx = blockIdx.x * PBLOCK + threadIdx.x;
     const uint32_t per = (n + PBLOCK - 1) / PBLOCK * PBLOCK;
-    const uint32_t b = per ? idx / per : src.batches, k = per ? idx % per : 0;
+    const uint32_t b = per ? idx / per : src.q.batches, k = per ? idx % per : 0;
     unsigned long long rays = 0, nodes = 0, tris = 0;
-    if (b < src.batches && k < n) {
+    if (b < src.q.batches && k < n) {
         RayD r;
         if (src.load(b * n + k, r)) {
             uint32_t cn, ct;
-            (void)trace_canonical(sc, r, src.fl, cn, ct);
+            (void)trace_canonical(sc, r, src.q.fl, cn, ct);
             rays = 1; nodes = cn; tris = ct;
         }
     }
@@ -1129,24 +1165,26 @@ hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots
     const uint32_t any = RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH | RT_RAY_FLAG_SKIP_CLOSEST_HIT_SHADER;
     if (T) record(ev[0], st);
     // primary rays are coherent: one 8x8 tile per wave, scheduled by the hardware dispatcher
-    k_primary<STACK, TWO_LEVEL><<<blocks(cap), PBLOCK, 0, st>>>(pd);
+    if (pd.n_frames > 1u) k_primary<STACK, TWO_LEVEL, true><<<blocks(cap), PBLOCK, 0, st>>>(pd);
+    else k_primary<STACK, TWO_LEVEL, false><<<blocks(cap), PBLOCK, 0, st>>>(pd);
     k_compact_level<<<(cap + CTILES * CBLOCK - 1) / (CTILES * CBLOCK), CBLOCK, 0, st>>>(pd, 0);
     if (T) record(ev[1], st);
     const bool B = pd.n_frames > 1u;            // a batch of frames: the shading kernels pick the constants of every hit's frame
     if (B) k_shade_emit<true, true><<<blocks(cap), PBLOCK, 0, st>>>(pd, 0, shadow_slots, levels >= 1 ? 1u : 0u);
     else k_shade_emit<true, false><<<blocks(cap), PBLOCK, 0, st>>>(pd, 0, shadow_slots, levels >= 1 ? 1u : 0u);
     if (T) record(ev[2], st);
-    ShadowSrcN shadows;
+    ShadowQueues shadows;
     memset(&shadows, 0, sizeof shadows);
     const LightRays lr = light_rays(pd), none = no_light_rays();
     const LightRays *fl = B ? pd.frame_lights : nullptr;
-    shadows.q[0] = QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, shadow_slots, any, lr, fl};     // RaytracingCommon.hlsli:94
+    shadows.frame_lights = fl;
+    shadows.q[0] = QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, shadow_slots, any, lr};     // RaytracingCommon.hlsli:94
     shadows.vis[0] = pd.lv[0].vis;
     shadows.nq = 1;
     size_t shadow_max = (size_t)cap * shadow_slots;
     for (uint32_t l = 1; l <= levels; l++) {
         // level 1: the diffuse and the specular batch of the primary hits; deeper: one ray per hit of level l-1
-        const QueueSrc rays = {pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE, none, nullptr};   // ProgressiveRaytracing.hlsl:53
+        const QueueSrc rays = {pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE, none};   // ProgressiveRaytracing.hlsl:53
         k_trace_secondary<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_secondary<STACK, TWO_LEVEL>, PBLOCK, (size_t)cap * 2), PBLOCK, 0, st>>>(
             pd.sc, rays, pd.lv[l].hit, pd.lv[l].inst, pd.pools + (size_t)l * RT_POOL_GROUPS * RT_POOL_STRIDE, &pd.counters[C_SECONDARY]);
         k_compact_level<<<(2 * cap + CTILES * CBLOCK - 1) / (CTILES * CBLOCK), CBLOCK, 0, st>>>(pd, (int)l);
@@ -1158,13 +1196,15 @@ hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots
         }
         if (T) record(ev[4 + 2 * (l - 1)], st);
         if (casts_shadows) {
-            shadows.q[shadows.nq] = QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any, lr, fl};
+            shadows.q[shadows.nq] = QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any, lr};
             shadows.vis[shadows.nq] = pd.lv[l].vis;
             shadows.nq++;
             shadow_max += (size_t)cap * 4;
         }
     }
-    k_trace_shadow<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL>, PBLOCK, shadow_max), PBLOCK, 0, st>>>(
+    if (B) k_trace_shadow<STACK, TWO_LEVEL, true><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL, true>, PBLOCK, shadow_max), PBLOCK, 0, st>>>(
+        pd.sc, shadows, pd.pools, &pd.counters[C_SHADOW]);
+    else k_trace_shadow<STACK, TWO_LEVEL, false><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL, false>, PBLOCK, shadow_max), PBLOCK, 0, st>>>(
         pd.sc, shadows, pd.pools, &pd.counters[C_SHADOW]);
     if (T) record(ev[EV_SHADOW], st);
     // (resolve: one thread per pixel slot of ONE frame; a batch's frames are accumulated in order inside the thread)
@@ -1202,13 +1242,13 @@ static int count_walk_launch(rt_pipeline *p, unsigned long long *w)
     const unsigned gs = rt_persistent_grid(ctx, k_walk_shadow<TWO_LEVEL>, PBLOCK, (size_t)cap * 2);
     const LightRays lr = light_rays(pd), none = no_light_rays();
     const LightRays *fl = pd.n_frames > 1u ? pd.frame_lights : nullptr;
-    k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any, lr, fl}, w + 7 * RT_STAGE_SHADOW0);
+    k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any, lr}, fl}, w + 7 * RT_STAGE_SHADOW0);
     const uint32_t levels = pd.max_rad < (uint32_t)MAXD ? pd.max_rad : (uint32_t)MAXD;
     for (uint32_t l = 1; l <= levels; l++) {
-        k_walk_queue<TWO_LEVEL><<<gq, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE, none, nullptr},
+        k_walk_queue<TWO_LEVEL><<<gq, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE, none},
                                                        w + 7 * RT_STAGE_SECONDARY);
         if (l < pd.max_shadow)
-            k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any, lr, fl}, w + 7 * RT_STAGE_SHADOW1);
+            k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any, lr}, fl}, w + 7 * RT_STAGE_SHADOW1);
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -1796,16 +1836,16 @@ int rt_pipeline_count_work(rt_pipeline *p, rt_stage_work *out)
     k_count_primary<<<blocks(cap), PBLOCK, 0, st>>>(pd, w + 3 * RT_STAGE_PRIMARY);
     const LightRays lr = light_rays(pd), none = no_light_rays();
     const LightRays *fl = pd.n_frames > 1u ? pd.frame_lights : nullptr;
-    k_count_queue<<<(blocks(cap) + 1) * ss, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any, lr, fl},
+    k_count_queue<<<(blocks(cap) + 1) * ss, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any, lr}, fl},
                                                              w + 3 * RT_STAGE_SHADOW0);
     const uint32_t levels = pd.max_rad < (uint32_t)MAXD ? pd.max_rad : (uint32_t)MAXD;
     for (uint32_t l = 1; l <= levels; l++) {        // every secondary level adds into the same two rows
         const uint32_t batches = l == 1 ? 2u : 1u;
         k_count_queue<<<(blocks((size_t)cap * 2) + 1) * batches, PBLOCK, 0, st>>>(
-            pd.sc, QueueSrc{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, batches, RT_RAY_FLAG_NONE, none, nullptr}, w + 3 * RT_STAGE_SECONDARY);
+            pd.sc, LitQueueSrc{QueueSrc{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, batches, RT_RAY_FLAG_NONE, none}, nullptr}, w + 3 * RT_STAGE_SECONDARY);
         if (l < pd.max_shadow)
             k_count_queue<<<(blocks((size_t)cap * 2) + 1) * 2, PBLOCK, 0, st>>>(
-                pd.sc, QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2 * cap, 2, any, lr, fl}, w + 3 * RT_STAGE_SHADOW1);
+                pd.sc, LitQueueSrc{QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2 * cap, 2, any, lr}, fl}, w + 3 * RT_STAGE_SHADOW1);
     }
     HIP_TRY(hipGetLastError());
     unsigned long long h[RT_STAGE_COUNT * 3];

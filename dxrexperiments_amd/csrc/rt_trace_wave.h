@@ -383,14 +383,17 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
     const TriRec *tris0 = TWO_LEVEL ? nullptr : in0->tris;
     // the LDS-resident top of the tree: smem rows STACK .. STACK + RT_TOP_ROWS - 1 hold nodes 0 .. top_n - 1 (breadth-first
     // numbering) of the structure a ray starts in: the BLAS of a single-level scene, the TLAS of a two-level one
-    // Two-level scenes split the table (round 3): the top of the TLAS (RT_TOP_TLAS nodes) and the tops of the two BLASes
-    // most instances use (RT_TOP_BLAS nodes each; the TLAS build marks those instances, InstanceRec::flags bits 8-9), so that
-    // the first levels of every walk INSIDE such an instance come from LDS as well.
+    // -DRT_LDS_BLAS_TOPS (round 3's experiment; measured: 41 % fewer L2 node fetches on the 4096-instance frame, no faster --
+    // the stages are issue-bound -- and five registers that cost the two-level primary kernel its fifth wave): the table is
+    // split into the top of the TLAS (RT_TOP_TLAS nodes) and the tops of the two BLASes most instances use (RT_TOP_BLAS
+    // nodes each; the TLAS build marks those instances, InstanceRec::flags bits 8-9), so that the first levels of a walk
+    // INSIDE such an instance come from LDS as well.  Default build: the TLAS has the whole table.
     int *topl = smem + STACK * BLOCK;
     if (sc.top_n != 0) {
         const int *src_top = (const int *)(TWO_LEVEL ? sc.tlas_wide : blas_nodes0);
         for (uint32_t i = threadIdx.x; i < sc.top_n * RT_TOP_WORDS; i += BLOCK) topl[i] = src_top[(i / RT_TOP_WORDS) * (uint32_t)(sizeof(WNode) / 4) + i % RT_TOP_WORDS];
     }
+#ifdef RT_LDS_BLAS_TOPS
     if (TWO_LEVEL) {
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -401,6 +404,10 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
     }
     if (sc.top_n != 0 || TWO_LEVEL) __syncthreads();
     const int *top_cur = topl;                    // LDS table of the structure being walked
+#else
+    if (sc.top_n != 0) __syncthreads();
+    const int *const top_cur = topl;
+#endif
     const int root0 = TWO_LEVEL ? sc.tlas_root_code : in0->root_code;
     uint32_t top_lim = sc.top_n;                  // node indices below this are read from LDS (two-level: 0 while inside a BLAS)
 
@@ -471,7 +478,12 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     cur.o = r.o; cur.d = r.d; cur.ri = wri;
                     node = root0;
                     sp = 0;
-                    if (TWO_LEVEL) { nodes = sc.tlas_wide; in_blas = false; top_lim = sc.top_n; top_cur = topl; }
+                    if (TWO_LEVEL) {
+                        nodes = sc.tlas_wide; in_blas = false; top_lim = sc.top_n;
+#ifdef RT_LDS_BLAS_TOPS
+                        top_cur = topl;
+#endif
+                    }
                     alive = true;
                     n_traced++;
                     if (COUNT) wk_ray0 = wk_glob + wk_top;
@@ -540,7 +552,9 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 in_blas = false;
                 nodes = sc.tlas_wide;
                 top_lim = sc.top_n;
+#ifdef RT_LDS_BLAS_TOPS
                 top_cur = topl;
+#endif
                 cur.o = r.o; cur.d = r.d; cur.ri = wri;
             } else if (TWO_LEVEL && !in_blas) {
                 ii = (uint32_t)~node;
@@ -556,11 +570,15 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     nodes = in->wide;
                     tris = in->tris;
                     in_blas = true;
+#ifdef RT_LDS_BLAS_TOPS
                     {   // the top of this BLAS is LDS resident if it is one of the two the scene uses most
                         const uint32_t slot = (in->flags >> 8) & 3u;
                         top_lim = slot ? sc.blas_top_n[slot - 1u] : 0u;
                         top_cur = topl + (RT_TOP_TLAS + (slot ? slot - 1u : 0u) * RT_TOP_BLAS) * RT_TOP_WORDS;
                     }
+#else
+                    top_lim = 0;
+#endif
                     st.write(sp, RT_NODE_SENTINEL);
                     sp++;
                     node = in->root_code;

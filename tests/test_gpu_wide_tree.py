@@ -210,13 +210,21 @@ def test_surface_area_collapse_option(gpu, capi):
 
 
 def test_three_blases_two_of_them_lds_resident(gpu, capi):
-    """Two-level kernels keep the tops of the TLAS and of the TWO most-instanced BLASes in LDS (round 3); a third model's
-    instances walk their BLAS from global memory.  Same hits as the canonical kernel for all three, in both usage orders."""
-    from util import random_rays
+    """RT_LDS_BLAS=1 (round 3; off by default: measured no faster): two-level kernels keep the tops of the TLAS and of the TWO
+    most-instanced BLASes in LDS; a third model's instances walk their BLAS from global memory.  Same hits as the canonical
+    kernel for all three, in both usage orders, and the same hits as with the option off."""
+    import os
+    from util import assert_hits_equal, random_rays
     models = [scenes.blob_mesh(level=2), triangle_soup(600, seed=21, extent=2.0, size=0.5), triangle_soup(3000, seed=22, extent=2.5, size=0.3)]
     xf = random_xforms(90, seed=23, spread=9.0)
     O, D = random_rays(40000, 9, np.full(3, -12.0), np.full(3, 12.0))
     for order in ((0, 1, 2), (2, 0, 1)):                 # which model is the rare one (10 of 90 instances)
         inst = [(order[0] if k % 9 else order[2], xf[k]) if k % 2 else (order[1] if k % 9 else order[2], xf[k]) for k in range(90)]
-        sc = build(capi, gpu, models, inst)
+        plain = build(capi, gpu, models, inst).trace(O, D)
+        os.environ["RT_LDS_BLAS"] = "1"                  # (read when the TLAS is built)
+        try:
+            sc = build(capi, gpu, models, inst)
+        finally:
+            del os.environ["RT_LDS_BLAS"]
         _same_hits(sc, O, D)
+        assert_hits_equal(sc.trace(O, D), plain, "BLAS tops in LDS vs not")
