@@ -50,7 +50,7 @@ TRACE_STAGES = {"primary": (("ms_primary",), "k_primary", ("primary",)),
                 "shadow": (("ms_trace_shadow0", "ms_trace_shadow1"), "k_trace_shadow", ("shadow0", "shadow1"))}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--partition", choices=("samples", "tiles"), default="samples",
                     help="samples (default, the headline): frames sharded over the GPUs, one all-reduce.  tiles: BASELINE configs[4], the "
                          "10 M-triangle 4K 4-bounce frame split into interleaved 16-row bands over the GPUs, one all-gather of the bands")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def relaunch_distributed(args):
@@ -349,6 +349,24 @@ def hbm_workload(ctx, capi, T, scenes, frames, warm, batch=1):
 
 
 
+def headline_workload(args, capi, scenes, np):
+    """(verts, tris, description, camera dict) of the headline run: the procedural Sponza-class atrium, or the mesh of --obj
+    (the product's own OBJ reader, no device needed) seen from --camera or from outside its bounding box."""
+    if args.obj:
+        verts, tris = capi.obj_read(args.obj)
+        workload = "user OBJ %s (%d triangles, %d vertices)" % (os.path.basename(args.obj), tris.shape[0], verts.shape[0])
+        lo, hi = verts["position"].min(axis=0), verts["position"].max(axis=0)
+        centre, ext = 0.5 * (lo + hi), float(np.linalg.norm(hi - lo))
+        eye, at = (args.camera[:3], args.camera[3:]) if args.camera else (centre + np.array([0.35, 0.2, 1.0]) * ext, centre)
+        cam = dict(eye=tuple(float(x) for x in eye), at=tuple(float(x) for x in at), up=(0.0, 1.0, 0.0),
+                   fov=args.fov if args.fov else float(np.float32(np.pi / 4)))
+    else:
+        verts, tris = scenes.sponza_class(seed=42)
+        workload = "BASELINE configs[1]: Sponza-class procedural atrium (seed 42, %d triangles)" % tris.shape[0]
+        cam = scenes.sponza_camera()
+    return verts, tris, workload, cam
+
+
 def rank_report(torch, dist, ctx, rank, world, local_rank, dev, backend, elapsed, collective_ms):
     """What makes an N > 1 line self-verifying (task 8): the world size the process group really has, the backend
     and RCCL version, every rank's device ordinal and PCI bus id (two ranks on one GPU show up as a repeated id), the
@@ -503,12 +521,7 @@ def main():
         return
 
     W, H, K, Wu = args.width, args.height, args.steps, args.warmup
-    if args.obj:
-        verts, tris = capi.obj_read(args.obj)              # the product's reader (rt_obj.cpp); no device needed
-        workload = "user OBJ %s (%d triangles, %d vertices)" % (os.path.basename(args.obj), tris.shape[0], verts.shape[0])
-    else:
-        verts, tris = scenes.sponza_class(seed=42)
-        workload = "BASELINE configs[1]: Sponza-class procedural atrium (seed 42, %d triangles)" % tris.shape[0]
+    verts, tris, workload, cam = headline_workload(args, capi, scenes, np)
     env = scenes.sky_cubemap(64)
     mat = T.default_material()
 
@@ -534,13 +547,6 @@ def main():
     host = capi.ProgressiveHost(1234)
     total_frames = (Wu + K) * world
     host.options["maxIterations"] = max(1024, total_frames + 1)
-    cam = scenes.sponza_camera()
-    if args.obj:
-        lo, hi = verts["position"].min(axis=0), verts["position"].max(axis=0)
-        centre, ext = 0.5 * (lo + hi), float(np.linalg.norm(hi - lo))
-        eye, at = (args.camera[:3], args.camera[3:]) if args.camera else (centre + np.array([0.35, 0.2, 1.0]) * ext, centre)
-        cam = dict(eye=tuple(float(x) for x in eye), at=tuple(float(x) for x in at), up=(0.0, 1.0, 0.0),
-                   fov=args.fov if args.fov else float(np.float32(np.pi / 4)))
     cam11 = capi.camera_array(cam["eye"], cam["at"], cam["up"], cam["fov"], W / H)
     pfcs = [host.update(cam11, 0.0, f + 1, W, H) for f in range(total_frames)]
     mine = D.shard_frames(rank, world, total_frames)

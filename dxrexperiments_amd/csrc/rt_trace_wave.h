@@ -81,6 +81,20 @@ __device__ unsigned long long g_trace_sp_hist[64];      // rays by the deepest s
 #define RT_STAT_LANE(k) ((void)0)
 #endif
 
+// -DRT_PREFETCH_POP (round 3's experiment for the HBM-bound scene, VERDICT r2 task 4): more misses in flight per lane.  After
+// a step the node that will be POPPED next (the top of the stack) is known many steps before it is needed; its line is
+// touched so that the pop finds it in the L2 instead of HBM.  Vector loads return in issue order (s_waitcnt vmcnt counts
+// them in order), so a touch issued BEFORE the next step's node loads would have to land before that node could be used;
+// it is therefore issued right BEHIND them (the step waits with vmcnt(1), the touch stays in flight during the step's
+// arithmetic and has a whole step to land) and its value is "consumed" by an empty asm one step later, which keeps the
+// destination register reserved until then.
+struct PopPrefetch {
+#ifdef RT_PREFETCH_POP
+    int code;           // node to touch behind the next node loads (RT_NODE_EMPTY: none)
+    float val;          // destination of the touch in flight
+#endif
+};
+
 // The traversal stack: STACK rows per lane in LDS (stk[row * BLOCK], one dword per lane per row, bank =
 // lane mod 32: conflict free), rows beyond that in global memory (deep[(row - STACK) * threads + thread]).
 // The LDS rows are sized for occupancy, not for the deepest possible walk: Sponza-class rays never hold
@@ -126,7 +140,7 @@ struct LaneStack {
 // A is +-inf, t(0) = fma(0, inf, B) is NaN, and max / min ignore a NaN operand -- that axis does not cull.)
 template <bool DEEP, bool ANYHIT, int STACK, int BLOCK>
 RT_DEV void wide_step(const WNode *nodes, const int *top, uint32_t top_lim, const RayInv &ri, float tmin, float tbest,
-                      const LaneStack<STACK, BLOCK> &st, int &node, int &sp)
+                      const LaneStack<STACK, BLOCK> &st, int &node, int &sp, PopPrefetch &)
 {
     v4f q0, q1, q2, q3, q4, q5;
     if ((uint32_t)node < top_lim) {
@@ -235,7 +249,7 @@ RT_DEV void wide_step(const WNode *nodes, const int *top, uint32_t top_lim, cons
 // take the exact path inside the step.)
 template <bool DEEP, bool ANYHIT, int STACK, int BLOCK>
 RT_DEV void wide_step(const WNode *nodes, const int *top, uint32_t top_lim, const RayInv &ri, float tmin, float tbest,
-                      const LaneStack<STACK, BLOCK> &st, int &node, int &sp)
+                      const LaneStack<STACK, BLOCK> &st, int &node, int &sp, PopPrefetch &pf)
 {
     v4f q0, q1, q2, q3;
     if ((uint32_t)node < top_lim) {
@@ -247,6 +261,17 @@ RT_DEV void wide_step(const WNode *nodes, const int *top, uint32_t top_lim, cons
         const char *nd = (const char *)nodes + ((uint32_t)node << 6);
         q0 = ldg16(nd, 0); q1 = ldg16(nd, 16); q2 = ldg16(nd, 32); q3 = ldg16(nd, 48);
     }
+#ifdef RT_PREFETCH_POP
+    {
+        __builtin_amdgcn_sched_barrier(0);                   // the touch goes BEHIND this node's loads
+        asm volatile("" :: "v"(pf.val));                     // the touch of the step before: landed by now (waited for here if not)
+        // (issued by every lane, a lane without a target touches node 0 -- always cached: a load inside a branch would give
+        // the paths different numbers of loads in flight and the compiler would have to wait for all of them, vmcnt(0))
+        const bool want = (uint32_t)pf.code >= top_lim && pf.code >= 0 && pf.code < RT_NODE_EMPTY;
+        pf.val = *(const __attribute__((address_space(1))) float *)((const char *)nodes + (want ? (uint32_t)pf.code << 6 : 0u));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     const uint32_t lx = __float_as_uint(q1.x), hx = __float_as_uint(q1.y), ly = __float_as_uint(q1.z), hy = __float_as_uint(q1.w);
     const uint32_t lz = __float_as_uint(q2.x), hz = __float_as_uint(q2.y);
     int c[4] = {__float_as_int(q3.x), __float_as_int(q3.y), __float_as_int(q3.z), __float_as_int(q3.w)};
@@ -314,6 +339,10 @@ RT_DEV void wide_step(const WNode *nodes, const int *top, uint32_t top_lim, cons
     if (p3) { if (DEEP) st.write(sp, c[3]); else st.lds[sp * BLOCK] = c[3]; sp++; }
     if (p2) { if (DEEP) st.write(sp, c[2]); else st.lds[sp * BLOCK] = c[2]; sp++; }
     if (p1) { if (DEEP) st.write(sp, c[1]); else st.lds[sp * BLOCK] = c[1]; sp++; }
+#ifdef RT_PREFETCH_POP
+    // the new top of the stack, if this step pushed one (else: what was touched before, or unknown after a pop)
+    pf.code = p1 ? c[1] : (p2 ? c[2] : (p3 ? c[3] : RT_NODE_EMPTY));
+#endif
     if (any) node = c[0];
     else { node = sp > 0 ? under : RT_NODE_EMPTY; sp = below; }
 }
@@ -424,6 +453,10 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
     HitD best;
     int node = RT_NODE_EMPTY;
     int sp = 0;
+    PopPrefetch pf;
+#ifdef RT_PREFETCH_POP
+    pf.code = RT_NODE_EMPTY; pf.val = 0.0f;
+#endif
     // two-level state
     ObjRay cur;                       // ray in the space of the structure being walked
     const WNode *nodes = TWO_LEVEL ? sc.tlas_wide : blas_nodes0;
@@ -478,6 +511,9 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     cur.o = r.o; cur.d = r.d; cur.ri = wri;
                     node = root0;
                     sp = 0;
+#ifdef RT_PREFETCH_POP
+                    pf.code = RT_NODE_EMPTY;
+#endif
                     if (TWO_LEVEL) {
                         nodes = sc.tlas_wide; in_blas = false; top_lim = sc.top_n;
 #ifdef RT_LDS_BLAS_TOPS
@@ -511,7 +547,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 const uint32_t dl = distinct_node_lines(node, !((uint32_t)node < top_lim));
                 if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_read_exec())) wk_lines += (RT_WIDE == 8 ? 2u : 1u) * dl;       // 64-B lines (96 B of a 128-B record: two)
             }
-            wide_step<false, ANYHIT>(nodes, top_cur, top_lim, cur.ri, r.tmin, ANYHIT ? r.tmax : best.t, st, node, sp);
+            wide_step<false, ANYHIT>(nodes, top_cur, top_lim, cur.ri, r.tmin, ANYHIT ? r.tmax : best.t, st, node, sp, pf);
 #ifdef RT_TRACE_STATS
             st_maxsp = sp > st_maxsp ? sp : st_maxsp;
 #endif
@@ -528,7 +564,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 const uint32_t dl = distinct_node_lines(node, !((uint32_t)node < top_lim));
                 if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_read_exec())) wk_lines += (RT_WIDE == 8 ? 2u : 1u) * dl;       // 64-B lines (96 B of a 128-B record: two)
             }
-            wide_step<true, ANYHIT>(nodes, top_cur, top_lim, cur.ri, r.tmin, ANYHIT ? r.tmax : best.t, st, node, sp);
+            wide_step<true, ANYHIT>(nodes, top_cur, top_lim, cur.ri, r.tmin, ANYHIT ? r.tmax : best.t, st, node, sp, pf);
 #ifdef RT_TRACE_STATS
             st_maxsp = sp > st_maxsp ? sp : st_maxsp;
 #endif
@@ -551,6 +587,9 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
             } else if (TWO_LEVEL && node == RT_NODE_SENTINEL) {
                 in_blas = false;
                 nodes = sc.tlas_wide;
+#ifdef RT_PREFETCH_POP
+                pf.code = RT_NODE_EMPTY;                     // (codes of the structure just left)
+#endif
                 top_lim = sc.top_n;
 #ifdef RT_LDS_BLAS_TOPS
                 top_cur = topl;
@@ -568,6 +607,9 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 if (enter) {
                     cur = to_object(*in, r);
                     nodes = in->wide;
+#ifdef RT_PREFETCH_POP
+                    pf.code = RT_NODE_EMPTY;
+#endif
                     tris = in->tris;
                     in_blas = true;
 #ifdef RT_LDS_BLAS_TOPS

@@ -260,3 +260,29 @@ def test_shard_helpers(capi):
         capi.tile_bands(1080, 0, 0, 1)
     with pytest.raises(capi.RtError):
         capi.shard_frame_count(3, 2, 10)
+
+
+def test_bench_obj_workload(capi):
+    """bench.py --obj PATH [--camera ...]: the headline line from a user mesh (north_star says "Sponza OBJ"; whoever holds the
+    real file gets the same JSON line from it).  Without a GPU: the argument parsing, the product's own OBJ reader on the
+    committed susanne.obj, the workload description the line will carry, and the default / explicit camera."""
+    import importlib.util
+    import os
+    from dxrexperiments_amd import scenes
+    from util import GOLDEN
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    obj = os.path.join(GOLDEN, "susanne.obj")
+    args = bench.parse(["--obj", obj])
+    v, t, workload, cam = bench.headline_workload(args, capi, scenes, np)
+    assert t.shape == (968, 3) and "susanne.obj" in workload and "968 triangles" in workload
+    lo, hi = v["position"].min(axis=0), v["position"].max(axis=0)
+    assert np.allclose(cam["at"], 0.5 * (lo + hi)) and np.linalg.norm(np.array(cam["eye"]) - np.array(cam["at"])) > 0.5 * np.linalg.norm(hi - lo)
+    args = bench.parse(["--obj", obj, "--camera", "1", "2", "3", "0", "0.5", "0", "--fov", "0.9", "--batch", "4"])
+    _, _, _, cam = bench.headline_workload(args, capi, scenes, np)
+    assert cam["eye"] == (1.0, 2.0, 3.0) and cam["at"] == (0.0, 0.5, 0.0) and cam["fov"] == 0.9 and args.batch == 4
+    args = bench.parse([])
+    v, t, workload, cam = bench.headline_workload(args, capi, scenes, np)
+    assert "BASELINE configs[1]" in workload and t.shape[0] == 261936 and cam == scenes.sponza_camera()
