@@ -23,536 +23,21 @@
 // per instruction; hits are compacted with __ballot + popcount prefix sums and one
 // atomic per 1024-thread block; diffuse and specular secondaries sit in separate
 // batches so waves stay as coherent as the sampling allows.
+//
+// This file: the stage kernels, the launch sequence of a frame (or of a batch of frames), the render calls and the work
+// counters.  rt_shade.h: the shaders as device functions.  rt_pipeline_dev.h: PipeDev and the host object.
+// rt_pipeline_host.hip: creation, setters, outputs, checkpoints, timing and statistics.
 #include <hip/hip_fp16.h>
 
 #include <new>
 
-#include "rt_trace_wave.h"
+#include "rt_shade.h"
 
 int rt_dds_load_cube(const char *path, std::vector<float> &faces, uint32_t &size);
 
 using namespace rtd;
 
 namespace {
-
-constexpr int PBLOCK = 256;
-#ifndef RT_SHADOW_UNORDERED
-#define RT_SHADOW_UNORDERED 1
-#endif
-// (only the any-hit instantiation of the walk tallies the queue slots marked "emitted but not traversed": with ordered shadow
-// walks rt_stats.rays_shadow would under-count when rt_pipeline_set_skip_unlit_shadow_rays is on)
-static_assert(RT_SHADOW_UNORDERED != 0, "the shadow stage counts skipped slots in the ANYHIT walk only");
-
-#define RAY_MAX_T 1.0e+38f      // RaytracingCommon.hlsli:8
-#define RAY_EPSILON 0.0001f     // RaytracingCommon.hlsli:9
-#define HLSL_PI 3.1415927f      // RaytracingUtils.hlsli:22
-
-#define HIT_MISS -1.0f
-#define HIT_UNTRACED -2.0f
-
-// Radiance rays are traced level by level: level 0 = primary rays, level L = rays spawned by the hits of
-// level L-1.  MAX_RADIANCE_RAY_DEPTH (RaytracingCommon.hlsli:11) is 1 in the reference; the DAG below is
-// generic up to MAXD so that BASELINE config 5 ("4-bounce") runs.  Because indirect DIFFUSE is only sampled
-// at depth 0 (ProgressiveRaytracing.hlsl:107), every pixel owns at most two chains of specular bounces.
-constexpr int MAXD = 4;
-enum { C_NHIT = 0,                       // [0..MAXD] compacted hits per level
-       C_SECONDARY = MAXD + 1, C_SHADOW = MAXD + 2,
-       C_SHADOW_SKIPPED = MAXD + 3,      // shadow rays whose result cannot matter (N.L == 0): emitted, counted (by the shadow
-                                         //   launch: traced_counter[1], rt_trace_wave.h), not traversed
-       C_COUNT = MAXD + 4 };
-
-// Level L: the rays at radiance depth L (L >= 1; primary rays are generated, not stored), their hit
-// records, the compaction of the hits, and the shadow-ray queue of those hits.
-//   slots of level 1: w*cap + k  (w = 0 diffuse / 1 specular batch, k = compact index of the primary hit)
-//   slots of level L >= 2: j     (compact index of the level L-1 hit that spawned the ray)
-//   shadow queue of level L: s*hcap(L) + idx, idx = compact hit index, hcap(0) = cap, hcap(L>=1) = 2 cap
-struct LevelDev {
-    float4 *O, *D;              // ray queue (unused at level 0)
-    float4 *hit; uint32_t *inst;   // hit records, indexed by slot (level 0: by pixel slot q)
-    uint32_t *slot_j, *jlist;   // slot -> compact hit index (RT_NO_HIT if none), compact index -> slot
-    uint32_t *pix;              // slot -> pixel slot q (unused at level 0)
-    float4 *shO, *shD; uint32_t *vis;
-    float4 *color;              // deep paths (more than one radiance level): the shaded colour of every hit of this level, by slot
-};
-
-// the frame's two light rays as the shadow-queue loader rebuilds them (QueueSrc::load)
-struct LightRays {
-    uint32_t on;
-    float dir_to_light[3];      // normalize(-directionalLight.forwardDir), computed once per frame on the host with the
-                                //   device's expression (IEEE sqrt and division, left-to-right sums, no contraction)
-    float point_pos[3];         // pointLight.worldPos
-};
-
-#define RT_MAX_BATCH 16u                // frames one set of launches renders (rt_pipeline_render_batch)
-
-struct PipeDev {
-    SceneDev sc;
-    rt_per_frame_constants pfc;         // the frame's constants (a batch: of its first frame; kernels take pfcs[frame])
-    // a BATCH of frames in one set of launches (config 3, rt_pipeline_render_batch): frame f owns the pixel slots
-    // [f * fcap, (f + 1) * fcap), every queue is n_frames times as long, a slot's frame selects constants and lights
-    uint32_t n_frames, fcap;            // single frame: 1, cap
-    const rt_per_frame_constants *pfcs; // device array [n_frames] (batches only)
-    const LightRays *frame_lights;      // device array [n_frames] (batches only)
-    const rt_material_params *mats;
-    uint32_t nmats;
-    const float4 *env;
-    uint32_t env_size;
-    uint32_t env_filter;                // RT_CUBE_SEAMLESS / RT_CUBE_FACE_CLAMP
-    float env_const[3];
-    uint32_t width, height;
-    uint32_t x0, y0, tw, th, cap;       // tile rectangle; cap = n_frames * tiles_x * tiles_y * 64 pixel slots
-    uint32_t tiles_x;
-    uint32_t band_rows, band_rank, band_world;      // band_rows != 0: the rectangle's rows are interleaved bands of the image
-    uint32_t n_pixels;                  // pixels of the image this launch covers
-    uint32_t max_rad, max_shadow;
-    uint32_t accum_mode;
-    uint32_t skip_unlit;                // do not traverse shadow rays of lights with N.L == 0 (their visibility is multiplied by 0)
-    uint32_t shadow_compact;            // shadow queues hold ONE float4 per shaded hit (QueueSrc, "light rays")
-    uint32_t kind;                      // RT_PIPELINE_PROGRESSIVE / RT_PIPELINE_REALTIME
-    float4 *accum;
-    float4 *aov_direct, *aov_indirect;  // realtime pipeline outputs (RealtimeRaytracing.hlsl:3-4)
-    uint32_t *counters;
-    unsigned long long *totals;         // running sums over frames (rt_pipeline_get_totals); updated by the frame's last kernel
-    uint32_t *pools;            // chunk counters of the persistent launches: [1 + MAXD][RT_POOL_GROUPS], 128 B apart
-    LevelDev lv[MAXD + 1];
-};
-
-constexpr size_t POOL_BYTES = (size_t)(1 + MAXD) * RT_POOL_GROUPS * RT_POOL_STRIDE * 4;      // shadow launch, levels 1..MAXD
-constexpr size_t POOL_OFFSET_WORDS = 64;      // the pools start on a 256-B boundary after the scalar counters
-
-RT_DEV uint32_t hcap(const PipeDev &pd, int L) { return L == 0 ? pd.cap : 2u * pd.cap; }
-
-// ---- environment: TextureCube.SampleLevel(linear, dir, 0), RaytracingCommon.hlsli:149-159
-// The sampler is MIN_MAG_LINEAR (ProgressiveRaytracingPipeline.cpp:48-55).  On D3D10+ hardware cube maps are
-// always filtered seamlessly: a bilinear tap that falls off the selected face comes from the face across that
-// edge.  RT_CUBE_SEAMLESS (default) models that with the cube's face-adjacency table; a tap off a CORNER has no
-// texel (three faces meet there) and takes the mean of the footprint's other three, the D3D11 functional
-// spec's suggestion.  RT_CUBE_FACE_CLAMP clamps taps to the selected face (round 1's behaviour).
-//
-// Face f = +X -X +Y -Y +Z -Z, edge e = x<0, x>=N, y<0, y>=N -> the face across the edge and where the texel at
-// position k along the edge lands there: bit 0 set: x' is the fixed coordinate (else y'), bit 1: fixed = N-1
-// (else 0), bit 2: the running coordinate is N-1-k (else k).  Derived from the D3D face parameterisation above.
-__constant__ const unsigned char kCubeEdge[24] = {
-    (4 << 3) | 3, (5 << 3) | 1, (2 << 3) | 7, (3 << 3) | 3,      // +X
-    (5 << 3) | 3, (4 << 3) | 1, (2 << 3) | 1, (3 << 3) | 5,      // -X
-    (1 << 3) | 0, (0 << 3) | 4, (5 << 3) | 4, (4 << 3) | 0,      // +Y
-    (1 << 3) | 6, (0 << 3) | 2, (4 << 3) | 2, (5 << 3) | 6,      // -Y
-    (1 << 3) | 3, (0 << 3) | 1, (2 << 3) | 2, (3 << 3) | 0,      // +Z
-    (0 << 3) | 3, (1 << 3) | 1, (2 << 3) | 4, (3 << 3) | 6};     // -Z
-
-// texel (x, y) of `face`, x and y in [-1, N]; false: the tap hangs over a cube corner
-RT_DEV bool cube_tap(const PipeDev &pd, int face, int x, int y, float4 &out)
-{
-    const int m = (int)pd.env_size - 1;
-    const bool ox = x < 0 || x > m, oy = y < 0 || y > m;
-    if (pd.env_filter == RT_CUBE_FACE_CLAMP) {
-        x = min(max(x, 0), m); y = min(max(y, 0), m);
-    } else if (ox && oy) {
-        return false;
-    } else if (ox || oy) {
-        const int e = ox ? (x < 0 ? 0 : 1) : (y < 0 ? 2 : 3);
-        const int k = ox ? y : x;
-        const unsigned code = kCubeEdge[face * 4 + e];
-        const int fixed = (code & 2u) ? m : 0, run = (code & 4u) ? m - k : k;
-        face = (int)(code >> 3);
-        x = (code & 1u) ? fixed : run;
-        y = (code & 1u) ? run : fixed;
-    }
-    out = pd.env[((size_t)face * pd.env_size + (size_t)y) * pd.env_size + (size_t)x];
-    return true;
-}
-
-RT_DEV f3 sample_cube(const PipeDev &pd, f3 d)
-{
-    if (pd.env_size == 0) return mk3(pd.env_const[0], pd.env_const[1], pd.env_const[2]);
-    const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
-    int face; float ma, sc, tc;
-    if (ax >= ay && ax >= az) { face = d.x > 0.0f ? 0 : 1; ma = ax; sc = d.x > 0.0f ? -d.z : d.z; tc = -d.y; }
-    else if (ay >= az) { face = d.y > 0.0f ? 2 : 3; ma = ay; sc = d.x; tc = d.y > 0.0f ? d.z : -d.z; }
-    else { face = d.z > 0.0f ? 4 : 5; ma = az; sc = d.z > 0.0f ? d.x : -d.x; tc = -d.y; }
-    if (!(ma > 0.0f) || !(ma < __uint_as_float(0x7f800000u))) return mk3(0.0f, 0.0f, 0.0f);
-    const float u = (sc / ma + 1.0f) * 0.5f;
-    const float v = (tc / ma + 1.0f) * 0.5f;
-    const float n = (float)pd.env_size;
-    const float fx = u * n - 0.5f, fy = v * n - 0.5f;
-    const float x0f = __builtin_floorf(fx), y0f = __builtin_floorf(fy);
-    const float wx = fx - x0f, wy = fy - y0f;
-    const int x0 = (int)x0f, y0 = (int)y0f;
-    float4 c[4];
-    bool have[4];
-    have[0] = cube_tap(pd, face, x0, y0, c[0]);
-    have[1] = cube_tap(pd, face, x0 + 1, y0, c[1]);
-    have[2] = cube_tap(pd, face, x0, y0 + 1, c[2]);
-    have[3] = cube_tap(pd, face, x0 + 1, y0 + 1, c[3]);
-    for (int k = 0; k < 4; k++) {
-        if (have[k]) continue;                    // at most one tap of a footprint hangs over a corner
-        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-        for (int j = 0; j < 4; j++)
-            if (j != k) { sx = sx + c[j].x; sy = sy + c[j].y; sz = sz + c[j].z; }
-        c[k] = make_float4(sx / 3.0f, sy / 3.0f, sz / 3.0f, 1.0f);
-    }
-    const float4 c00 = c[0], c10 = c[1], c01 = c[2], c11 = c[3];
-    const float tx = c00.x + (c10.x - c00.x) * wx, bx = c01.x + (c11.x - c01.x) * wx;
-    const float ty = c00.y + (c10.y - c00.y) * wx, by = c01.y + (c11.y - c01.y) * wx;
-    const float tz = c00.z + (c10.z - c00.z) * wx, bz = c01.z + (c11.z - c01.z) * wx;
-    return mk3(tx + (bx - tx) * wy, ty + (by - ty) * wy, tz + (bz - tz) * wy);
-}
-
-RT_DEV f3 sample_environment(const PipeDev &pd, f3 dir)
-{
-    return sample_cube(pd, dir) * pd.pfc.options.environmentStrength;
-}
-
-// Pixel slot q -> pixel.  Slots are laid out as 8x8 pixel tiles (64 consecutive slots = one
-// wave = one 8x8 screen tile), so a wave's primary rays -- and, through the order-preserving
-// compaction, the secondary and shadow rays spawned from them -- share BVH nodes.  Slots of
-// partial tiles that fall outside the rectangle are invalid.
-RT_DEV bool pix_xy(const PipeDev &pd, uint32_t q, uint32_t &px, uint32_t &py)
-{
-    const uint32_t t = q >> 6, w = q & 63u;
-    const uint32_t lx = (t % pd.tiles_x) * 8u + (w & 7u), ly = (t / pd.tiles_x) * 8u + (w >> 3);
-    px = pd.x0 + lx;
-    if (pd.band_rows) {         // rows of the rectangle = this rank's interleaved bands, packed (rt_pipeline_render_bands)
-        py = ((ly / pd.band_rows) * pd.band_world + pd.band_rank) * pd.band_rows + ly % pd.band_rows;
-        return lx < pd.tw && ly < pd.th && py < pd.height;
-    }
-    py = pd.y0 + ly;
-    return lx < pd.tw && ly < pd.th;
-}
-
-// ---- RayGen (ProgressiveRaytracing.hlsl:18-32)
-RT_DEV RayD primary_ray(const PipeDev &pd, const rt_camera_params &cp, uint32_t px, uint32_t py)
-{
-    const float dx = ((float)px + 0.5f) / (float)pd.width * 2.0f - 1.0f;
-    const float dy = ((float)py + 0.5f) / (float)pd.height * 2.0f - 1.0f;
-    const float js = pd.kind == RT_PIPELINE_REALTIME ? 10.0f : 30.0f;   // ProgressiveRaytracing.hlsl:26 / RealtimeRaytracing.hlsl:33
-    const float jx = cp.jitters.x * js, jy = cp.jitters.y * js;
-    RayD r;
-    r.o = mk3(cp.worldEyePos.x + jx, cp.worldEyePos.y + jy, cp.worldEyePos.z + 0.0f);
-    f3 dir = mk3(cp.U.x, cp.U.y, cp.U.z) * dx;
-    dir = dir + mk3(cp.V.x, cp.V.y, cp.V.z) * (-dy);
-    dir = dir + mk3(cp.W.x, cp.W.y, cp.W.z);
-    r.d = normalize(dir);
-    r.tmin = 0.0f;
-    r.tmax = RAY_MAX_T;
-    return r;
-}
-RT_DEV RayD primary_ray(const PipeDev &pd, uint32_t px, uint32_t py) { return primary_ray(pd, pd.pfc.cameraParams, px, py); }
-
-// The frame a pixel slot belongs to, and the slot inside that frame (single frames: 0 and q itself)
-RT_DEV uint32_t slot_frame(const PipeDev &pd, uint32_t q, uint32_t &q_in_frame)
-{
-    if (pd.n_frames <= 1u) { q_in_frame = q; return 0u; }
-    const uint32_t f = q / pd.fcap;
-    q_in_frame = q - f * pd.fcap;
-    return f;
-}
-
-// ---- interpolateVertexAttributes (RaytracingCommon.hlsli:53-82), normal only
-RT_DEV f3 hit_normal(const InstanceRec &in, uint32_t prim, float bu, float bv)
-{
-    const float b0 = 1.0f - bu - bv;
-    // verts[indices[3 prim + k]].normal, gathered per primitive at build time (InstanceRec::normals): one 48-B record
-    const TriRec nr = in.normals[prim];
-    f3 n = mk3(nr.a.x, nr.a.y, nr.a.z) * b0;
-    n = n + mk3(nr.a.w, nr.b.x, nr.b.y) * bu;
-    n = n + mk3(nr.b.z, nr.b.w, nr.c.x) * bv;
-    return n;
-}
-
-// ---- lights (RaytracingCommon.hlsli:126-147), AO (:98-124)
-template <class IO>
-RT_DEV f3 directional_light(const PipeDev &pd, IO &io, f3 P, f3 N, uint32_t depth)
-{
-    const rt_directional_light_params &dl = pd.pfc.directionalLight;
-    const f3 L = normalize(mk3(-dl.forwardDir.x, -dl.forwardDir.y, -dl.forwardDir.z));
-    const float NoL = saturate(dot(N, L));
-    // the reference traces this ray even when NoL == 0 (RaytracingCommon.hlsli:132-133); its visibility is then multiplied
-    // by 0, so the ray is emitted and counted but need not be traversed (io.shadow's last argument)
-    const float vis = io.shadow(0, P, L, RAY_EPSILON, RAY_MAX_T, depth, NoL > 0.0f);
-    return mk3(dl.color.x, dl.color.y, dl.color.z) * dl.color.w * NoL * vis;
-}
-
-template <class IO>
-RT_DEV f3 point_light(const PipeDev &pd, IO &io, f3 P, f3 N, uint32_t depth)
-{
-    const rt_point_light_params &pl = pd.pfc.pointLight;
-    const f3 path = mk3(pl.worldPos.x, pl.worldPos.y, pl.worldPos.z) - P;
-    const float dist = length(path);
-    const f3 L = normalize(path);
-    const float NoL = saturate(dot(N, L));
-    const float vis = io.shadow(1, P, L, RAY_EPSILON, dist - RAY_EPSILON, depth, NoL > 0.0f);
-    const float falloff = 1.0f / (2.0f * HLSL_PI * dist * dist);
-    return mk3(pl.color.x, pl.color.y, pl.color.z) * pl.color.w * NoL * vis * falloff;
-}
-
-template <class IO>
-RT_DEV f3 ambient_occlusion(const PipeDev &pd, IO &io, f3 P, f3 N, uint32_t pix)
-{
-    float visibility = 0.0f;
-    uint32_t seed = init_rand(pix, pd.pfc.cameraParams.frameCount);
-    for (int i = 0; i < 4; ++i) {
-        f3 dir; float NoL, pdf;
-        if (pd.pfc.options.cosineHemisphereSampling) {
-            dir = cos_hemisphere(seed, N);
-            NoL = saturate(dot(N, dir));
-            pdf = NoL / HLSL_PI;
-        } else {
-            dir = uniform_hemisphere(seed, N);
-            NoL = saturate(dot(N, dir));
-            pdf = 1.0f / (2.0f * HLSL_PI);
-        }
-        visibility += io.shadow(i, P, dir, RAY_EPSILON, 10.0f, 1u, true) * NoL / pdf;
-    }
-    const float r = visibility / 4.0f;
-    return mk3(r, r, r);
-}
-
-// ---- shade (ProgressiveRaytracing.hlsl:80-148) + evaluateIndirectDiffuse (:57-78)
-template <class IO>
-RT_DEV f3 shade(const PipeDev &pd, IO &io, const rt_material_params &mp, f3 P, f3 N, f3 D, uint32_t depth, uint32_t pix)
-{
-    const rt_debug_options &opt = pd.pfc.options;
-    if (opt.showAmbientOcclusionOnly) return ambient_occlusion(pd, io, P, N, pix);
-
-    uint32_t seed = init_rand(pix, pd.pfc.cameraParams.frameCount);
-
-    f3 direct = mk3(0.0f, 0.0f, 0.0f);
-    if (opt.debug == 2) {
-        if (next_rand(seed) < 0.5f) direct = direct + directional_light(pd, io, P, N, depth) * 2.0f;
-        else direct = direct + point_light(pd, io, P, N, depth) * 2.0f;
-    } else {
-        direct = direct + directional_light(pd, io, P, N, depth);
-        direct = direct + point_light(pd, io, P, N, depth);
-    }
-
-    f3 indirect = mk3(0.0f, 0.0f, 0.0f);
-    if (depth < 1 && !opt.noIndirectDiffuse) {
-        f3 color = mk3(0.0f, 0.0f, 0.0f);
-        if (opt.cosineHemisphereSampling) {
-            const f3 dir = cos_hemisphere(seed, N);
-            color = color + io.secondary(0, P, dir, RAY_EPSILON, depth) * HLSL_PI;
-        } else {
-            const f3 dir = uniform_hemisphere(seed, N);
-            const float NoL = saturate(dot(N, dir));
-            const float pdf = 1.0f / (2.0f * HLSL_PI);
-            color = color + io.secondary(0, P, dir, RAY_EPSILON, depth) * NoL / pdf;
-        }
-        indirect = indirect + color / 1.0f;
-    }
-
-    const f3 diffuse = (direct + indirect) / HLSL_PI;
-
-    f3 fresnel = mk3(0.0f, 0.0f, 0.0f);
-    f3 specular = mk3(0.0f, 0.0f, 0.0f);
-    if (mp.type == 1u || mp.type == 2u) {
-        if (mp.reflectivity > 0.001f) {
-            const float exponent = exp_det((1.0f - mp.roughness) * 12.0f);
-            float pdf, brdf;
-            const f3 mirror = reflect(D, N);
-            const f3 dir = phong_lobe(seed, mirror, exponent, pdf, brdf);
-            const f3 refl = io.secondary(1, P, dir, RAY_EPSILON, depth);
-            specular = specular + refl * brdf / pdf;
-            fresnel = fresnel_schlick(D, N, mk3(mp.specular.x, mp.specular.y, mp.specular.z));
-        }
-    }
-
-    const f3 albedo = mk3(mp.albedo.x, mp.albedo.y, mp.albedo.z);
-    if (depth == 0) {
-        if (opt.showIndirectDiffuseOnly) return albedo * indirect / HLSL_PI;
-        else if (opt.showIndirectSpecularOnly) return specular * mp.reflectivity * fresnel;
-        else if (opt.showFresnelTerm) return fresnel;
-        else if (opt.showGBufferAlbedoOnly) return albedo;
-        else if (opt.showDirectLightingOnly) return albedo * direct / HLSL_PI;
-    }
-    f3 r = mk3(mp.emissive.x, mp.emissive.y, mp.emissive.z) * mp.emissive.w;
-    r = r + albedo * diffuse;
-    r = r + specular * mp.reflectivity * fresnel;
-    return r;
-}
-
-// shadeAOV of the realtime pipeline (RealtimeRaytracing.hlsl:65-103): direct light + one Phong-lobe
-// bounce, split into the two AOVs the denoiser consumes (written at depth 0 only)
-template <class IO>
-RT_DEV f3 shade_aov(const PipeDev &pd, IO &io, const rt_material_params &mp, f3 P, f3 N, f3 D, uint32_t depth, uint32_t pix,
-                    f3 &aov_direct, f3 &aov_indirect)
-{
-    uint32_t seed = init_rand(pix, pd.pfc.cameraParams.frameCount);
-    f3 direct = mk3(0.0f, 0.0f, 0.0f);
-    direct = direct + directional_light(pd, io, P, N, depth);
-    direct = direct + point_light(pd, io, P, N, depth);
-    f3 fresnel = mk3(0.0f, 0.0f, 0.0f);
-    f3 specular = mk3(0.0f, 0.0f, 0.0f);
-    if (mp.type == 1u || mp.type == 2u) {
-        if (mp.reflectivity > 0.001f) {
-            const float exponent = exp_det((1.0f - mp.roughness) * 12.0f);
-            float pdf, brdf;
-            const f3 mirror = reflect(D, N);
-            const f3 dir = phong_lobe(seed, mirror, exponent, pdf, brdf);
-            const f3 refl = io.secondary(1, P, dir, RAY_EPSILON, depth);
-            specular = specular + refl * brdf / pdf;
-            fresnel = fresnel_schlick(D, N, mk3(mp.specular.x, mp.specular.y, mp.specular.z));
-        }
-    }
-    const f3 albedo = mk3(mp.albedo.x, mp.albedo.y, mp.albedo.z);
-    const f3 dl = albedo * direct / HLSL_PI;
-    const f3 is = specular * mp.reflectivity * fresnel;
-    if (depth == 0) { aov_direct = dl; aov_indirect = is; }
-    return dl + is;
-}
-
-struct Shaded { f3 color, aov_direct, aov_indirect; };
-
-// PrimaryClosestHit (ProgressiveRaytracing.hlsl:150-158, RealtimeRaytracing.hlsl:105-117) for a stored hit
-template <class IO>
-RT_DEV Shaded closest_hit_aov(const PipeDev &pd, IO &io, const RayD &r, float t, float u, float v, uint32_t prim, uint32_t inst,
-                              uint32_t depth, uint32_t pix)
-{
-    const InstanceRec &in = pd.sc.inst[inst];
-    const f3 N = normalize(hit_normal(in, prim, u, v));
-    const f3 P = r.o + r.d * t;
-    const rt_material_params mp = pd.mats[min(inst, pd.nmats - 1u)];
-    Shaded s;
-    s.aov_direct = mk3(0.0f, 0.0f, 0.0f);
-    s.aov_indirect = mk3(0.0f, 0.0f, 0.0f);
-    if (pd.kind == RT_PIPELINE_REALTIME) s.color = shade_aov(pd, io, mp, P, N, r.d, depth, pix, s.aov_direct, s.aov_indirect);
-    else s.color = shade(pd, io, mp, P, N, r.d, depth, pix);
-    return s;
-}
-
-template <class IO>
-RT_DEV f3 closest_hit(const PipeDev &pd, IO &io, const RayD &r, float t, float u, float v, uint32_t prim, uint32_t inst,
-                      uint32_t depth, uint32_t pix)
-{
-    return closest_hit_aov(pd, io, r, t, u, v, prim, inst, depth, pix).color;
-}
-
-RT_DEV void store_ray(float4 *O, float4 *D, size_t slot, f3 o, float tmin, f3 d, float tmax)
-{
-    O[slot] = make_float4(o.x, o.y, o.z, tmin);
-    D[slot] = make_float4(d.x, d.y, d.z, tmax);
-}
-RT_DEV void store_invalid(float4 *O, float4 *D, size_t slot)
-{
-    O[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    D[slot] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);      // tmax < tmin: never traced
-}
-RT_DEV RayD load_ray(const float4 *O, const float4 *D, size_t slot)
-{
-    const float4 a = O[slot], b = D[slot];
-    RayD r;
-    r.o = mk3(a.x, a.y, a.z); r.tmin = a.w;
-    r.d = mk3(b.x, b.y, b.z); r.tmax = b.w;
-    return r;
-}
-
-// ---- the "TraceRay" providers of the two passes ---------------------------------
-
-// emit pass at radiance depth L: shadow ray s -> shadow queue of level L, secondary ray -> ray queue of level L+1
-struct EmitIO {
-    const PipeDev &pd;
-    int L;
-    uint32_t idx, q;            // compact hit index at level L, pixel slot
-    uint32_t frame;             // frame of the batch the hit belongs to (single frames: 0)
-    uint32_t shadow_mask, skip_mask, sec_mask;
-    f3 shadow_origin;           // compact shadow queues: the hit point both light rays start from
-    RT_DEV EmitIO(const PipeDev &p, int level, uint32_t i, uint32_t qq, uint32_t f) : pd(p), L(level), idx(i), q(qq), frame(f), shadow_mask(0), skip_mask(0), sec_mask(0)
-    {
-        shadow_origin = mk3(0.0f, 0.0f, 0.0f);
-    }
-    // matters = false: whatever this ray finds is multiplied by zero by the caller
-    RT_DEV float shadow(int s, f3 o, f3 d, float tmin, float tmax, uint32_t depth, bool matters)
-    {
-        if (depth >= pd.max_shadow) return 1.0f;
-        const bool skipped = !matters && pd.skip_unlit;     // "emitted but not worth traversing"; the trace kernel counts these
-        shadow_mask |= 1u << s;
-        if (skipped) skip_mask |= 1u << s;
-        if (pd.shadow_compact) {                            // the ray is rebuilt from the hit point by QueueSrc::load
-            shadow_origin = o;
-            return 1.0f;
-        }
-        if (skipped) store_ray(pd.lv[L].shO, pd.lv[L].shD, (size_t)s * hcap(pd, L) + idx, mk3(0.0f, 0.0f, 0.0f), 0.0f, mk3(0.0f, 0.0f, 0.0f), RT_TMAX_SKIPPED);
-        else store_ray(pd.lv[L].shO, pd.lv[L].shD, (size_t)s * hcap(pd, L) + idx, o, tmin, d, tmax);
-        return 1.0f;
-    }
-    // the shadow slots of this hit that no ray went to are marked "not traced"
-    RT_DEV void finish_shadows(uint32_t shadow_slots) const
-    {
-        if (pd.shadow_compact) {
-            pd.lv[L].shO[idx] = make_float4(shadow_origin.x, shadow_origin.y, shadow_origin.z, __uint_as_float(shadow_mask | (skip_mask << 2) | (frame << 8)));
-            return;
-        }
-        for (uint32_t s = 0; s < shadow_slots; s++)
-            if (!(shadow_mask & (1u << s))) store_invalid(pd.lv[L].shO, pd.lv[L].shD, (size_t)s * hcap(pd, L) + idx);
-    }
-    RT_DEV f3 secondary(int w, f3 o, f3 d, float tmin, uint32_t depth)
-    {
-        if (depth >= pd.max_rad || L >= MAXD) return mk3(0.0f, 0.0f, 0.0f);
-        const size_t slot = L == 0 ? (size_t)w * pd.cap + idx : idx;
-        store_ray(pd.lv[L + 1].O, pd.lv[L + 1].D, slot, o, tmin, d, RAY_MAX_T);
-        pd.lv[L + 1].pix[slot] = q;
-        sec_mask |= 1u << w;
-        return mk3(0.0f, 0.0f, 0.0f);
-    }
-};
-
-// resolve pass at radiance depth L: every TraceRay is replaced by its stored result; a secondary hit
-// recurses into the next level (compile-time recursion, MAXD deep)
-template <int L, int MAXL>
-struct ResolveIO {
-    const PipeDev &pd;
-    uint32_t idx, pix;
-    RT_DEV ResolveIO(const PipeDev &p, uint32_t i, uint32_t px) : pd(p), idx(i), pix(px) {}
-    RT_DEV float shadow(int s, f3, f3, float, float, uint32_t depth, bool matters)
-    {
-        if (depth >= pd.max_shadow) return 1.0f;
-        if (!matters && pd.skip_unlit) return 1.0f;                       // never traced; the caller multiplies by zero
-        return pd.lv[L].vis[(size_t)s * hcap(pd, L) + idx] ? 1.0f : 0.0f;
-    }
-    RT_DEV f3 secondary(int w, f3 o, f3 d, float tmin, uint32_t depth)
-    {
-        if constexpr (L >= MAXL) {
-            return mk3(0.0f, 0.0f, 0.0f);
-        } else {
-            if (depth >= pd.max_rad) return mk3(0.0f, 0.0f, 0.0f);
-            const size_t slot = L == 0 ? (size_t)w * pd.cap + idx : idx;
-            const float4 h = pd.lv[L + 1].hit[slot];
-            if (h.x == HIT_MISS) return sample_environment(pd, d);             // PrimaryMiss, :160-164
-            if (h.x == HIT_UNTRACED) return mk3(0.0f, 0.0f, 0.0f);
-            RayD r;
-            r.o = o; r.tmin = tmin; r.d = d; r.tmax = RAY_MAX_T;
-            ResolveIO<L + 1, MAXL> io(pd, pd.lv[L + 1].slot_j[slot], pix);
-            return closest_hit(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.lv[L + 1].inst[slot], depth + 1u, pix);
-        }
-    }
-};
-
-// The same pass for paths of more than one bounce, level by level from the deepest up (k_shade_level, then k_resolve_flat):
-// the colour of a secondary hit is not recomputed by compile-time recursion -- five nested shade() bodies cost 142 VGPRs,
-// three waves per SIMD -- but read from the colour buffer the pass of the level below has just written.  It is the value
-// the recursion would have produced (same function, same inputs), so the image does not change by a bit.
-struct LevelResolveIO {
-    const PipeDev &pd;
-    int L;
-    uint32_t idx;
-    RT_DEV LevelResolveIO(const PipeDev &p, int level, uint32_t i) : pd(p), L(level), idx(i) {}
-    RT_DEV float shadow(int s, f3, f3, float, float, uint32_t depth, bool matters)
-    {
-        if (depth >= pd.max_shadow) return 1.0f;
-        if (!matters && pd.skip_unlit) return 1.0f;
-        return pd.lv[L].vis[(size_t)s * hcap(pd, L) + idx] ? 1.0f : 0.0f;
-    }
-    RT_DEV f3 secondary(int w, f3, f3 d, float, uint32_t depth)
-    {
-        if (depth >= pd.max_rad || L >= MAXD) return mk3(0.0f, 0.0f, 0.0f);
-        const size_t slot = L == 0 ? (size_t)w * pd.cap + idx : idx;
-        const float4 h = pd.lv[L + 1].hit[slot];
-        if (h.x == HIT_MISS) return sample_environment(pd, d);             // PrimaryMiss, :160-164
-        if (h.x == HIT_UNTRACED) return mk3(0.0f, 0.0f, 0.0f);
-        const float4 c = pd.lv[L + 1].color[slot];
-        return mk3(c.x, c.y, c.z);
-    }
-};
 
 // ---- compaction ----------------------------------------------------------------------
 constexpr int CBLOCK = 1024;
@@ -1051,19 +536,6 @@ __global__ void __launch_bounds__(PBLOCK) k_count_primary(PipeDev pd, unsigned l
     wave_add64(tris, &out[2]);
 }
 
-__global__ void k_f32_to_f16(const float4 *__restrict__ in, ushort4 *__restrict__ out, size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 v = in[i];
-    ushort4 o;
-    o.x = __half_as_ushort(__float2half_rn(v.x));
-    o.y = __half_as_ushort(__float2half_rn(v.y));
-    o.z = __half_as_ushort(__float2half_rn(v.z));
-    o.w = __half_as_ushort(__float2half_rn(v.w));
-    out[i] = o;
-}
-
 __global__ void k_debug_cube(PipeDev pd, const float *__restrict__ dirs, float *__restrict__ out, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1072,57 +544,10 @@ __global__ void k_debug_cube(PipeDev pd, const float *__restrict__ dirs, float *
     out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
 }
 
-inline unsigned blocks(size_t n) { return (unsigned)((n + PBLOCK - 1) / PBLOCK); }
 
 }  // namespace
 
-// ---- host object ------------------------------------------------------------------------
-
-struct rt_pipeline {
-    rt_context *ctx = nullptr;
-    uint32_t kind = RT_PIPELINE_PROGRESSIVE;
-    DevBuf aov_own;                    // realtime: second output (indirect specular); the first lives in accum_own
-    rt_scene *scene = nullptr;
-    std::vector<rt_material_params> mats;
-    DevBuf d_mats;
-    bool mats_dirty = true;
-    DevBuf d_env;
-    uint32_t env_size = 0;
-    uint32_t env_filter = RT_CUBE_SEAMLESS;
-    float env_const[3] = {0.5f, 0.5f, 0.5f};
-    uint32_t width = 0, height = 0, format = RT_FORMAT_R32G32B32A32_FLOAT;
-    DevBuf accum_own;
-    float4 *accum = nullptr;
-    rt_per_frame_constants pfc;
-    bool have_pfc = false;
-    uint32_t max_rad = 1, max_shadow = 2, accum_mode = RT_ACCUM_RUNNING_MEAN;
-    uint32_t skip_unlit = 0;           // off by default: every shadow ray the reference traces is traversed (rt_pipeline_set_skip_unlit_shadow_rays)
-    // queues (sized for `cap` pixels)
-    uint32_t cap = 0, sh0_batches = 0, levels = 0;
-    struct LevelBuf { DevBuf O, D, hit, inst, slot_j, jlist, pix, shO, shD, vis, color; } lv[MAXD + 1];
-    DevBuf counters;
-    DevBuf half_out;
-    std::vector<hipEvent_t> ring;      // EV_COUNT events per remembered frame
-    std::vector<uint8_t> ring_levels;  // radiance levels each remembered frame ran
-    std::vector<uint8_t> ring_nframes; // frames each remembered entry covers (a batch is one entry)
-    DevBuf batch_consts;               // per-frame constants and light rays of a batch (rt_pipeline_render_batch)
-    int ring_frames = 0;               // 0 = timing off
-    uint64_t ring_pos = 0;             // frames recorded since enable / reset
-    DevBuf totals, work;
-    PipeDev last_pd;
-    uint32_t last_shadow_slots = 2;
-    rt_stats stats;
-    uint32_t last_tile[4] = {0, 0, 0, 0};
-    uint32_t last_pixels = 0;
-    bool rendered = false;
-    uint32_t last_scene_gen = 0;       // generation of the scene last_pd was filled from
-};
-
 namespace {
-
-// events of one frame: start | primary | shade 0 | (trace l, shade l) for l = 1..MAXD | shadow | resolve
-constexpr int EV_COUNT = 5 + 2 * MAXD;
-constexpr int EV_SHADOW = 3 + 2 * MAXD, EV_RESOLVE = 4 + 2 * MAXD;
 
 int ensure_queues(rt_pipeline *p, uint32_t cap, uint32_t sh0_batches, uint32_t levels)
 {
@@ -1257,192 +682,6 @@ static int count_walk_launch(rt_pipeline *p, unsigned long long *w)
 }  // namespace
 
 extern "C" {
-
-int rt_pipeline_create(rt_context *ctx, uint32_t kind, rt_pipeline **out)
-{
-    RT_REQUIRE(ctx && out, "null argument");
-    RT_REQUIRE(kind == RT_PIPELINE_PROGRESSIVE || kind == RT_PIPELINE_REALTIME, "unknown pipeline kind");
-    rt_pipeline *p = new (std::nothrow) rt_pipeline();
-    if (!p) { rt_set_error("out of host memory"); return RT_ERR_OOM; }
-    p->ctx = ctx;
-    p->kind = kind;
-    rt_context_retain(ctx);
-    memset(&p->pfc, 0, sizeof p->pfc);
-    memset(&p->stats, 0, sizeof p->stats);
-    *out = p;
-    return RT_OK;
-}
-
-int rt_pipeline_destroy(rt_pipeline *p)
-{
-    if (!p) return RT_OK;
-    (void)hipSetDevice(p->ctx->device);
-    (void)hipStreamSynchronize(p->ctx->stream);
-    DevBuf *all[] = {&p->d_mats, &p->d_env, &p->accum_own, &p->aov_own, &p->counters, &p->half_out, &p->totals, &p->work, &p->batch_consts};
-    for (DevBuf *b : all) b->release();
-    for (rt_pipeline::LevelBuf &l : p->lv) {
-        DevBuf *lb[] = {&l.O, &l.D, &l.hit, &l.inst, &l.slot_j, &l.jlist, &l.pix, &l.shO, &l.shD, &l.vis, &l.color};
-        for (DevBuf *b : lb) b->release();
-    }
-    for (hipEvent_t e : p->ring) if (e) (void)hipEventDestroy(e);
-    if (p->scene) rt_scene_destroy(p->scene);
-    rt_context *ctx = p->ctx;
-    delete p;
-    rt_context_release(ctx);
-    return RT_OK;
-}
-
-const char *rt_pipeline_get_name(const rt_pipeline *p)
-{
-    // include/ProgressiveRaytracingPipeline.h:40, include/RealtimeRaytracingPipeline.h:40
-    return p && p->kind == RT_PIPELINE_REALTIME ? "Realtime Ray Tracing Pipeline" : "Progressive Ray Tracing Pipeline";
-}
-
-int rt_pipeline_set_scene(rt_pipeline *p, rt_scene *s)
-{
-    RT_REQUIRE(p && s, "null argument");
-    RT_REQUIRE(s->ctx == p->ctx, "scene belongs to a different context");
-    rt_scene_retain(s);
-    if (p->scene) rt_scene_destroy(p->scene);
-    p->scene = s;
-    p->rendered = false;        // last_pd holds device pointers of the previous scene
-    return RT_OK;
-}
-
-int rt_pipeline_add_material(rt_pipeline *p, const rt_material_params *m)
-{
-    RT_REQUIRE(p && m, "null argument");
-    p->mats.push_back(*m);
-    p->mats_dirty = true;
-    p->rendered = false;        // d_mats may be reallocated by the next render
-    return RT_OK;
-}
-
-int rt_pipeline_set_material(rt_pipeline *p, uint32_t index, const rt_material_params *m)
-{
-    RT_REQUIRE(p && m, "null argument");
-    RT_REQUIRE(index < p->mats.size(), "material index out of range");
-    p->mats[index] = *m;
-    p->mats_dirty = true;
-    p->rendered = false;
-    return RT_OK;
-}
-
-int rt_pipeline_set_environment_cube(rt_pipeline *p, const float *faces, uint32_t size)
-{
-    RT_REQUIRE(p && faces && size > 0, "bad argument");
-    HIP_TRY(hipSetDevice(p->ctx->device));
-    const size_t bytes = (size_t)6 * size * size * 16;
-    RT_TRY(p->d_env.reserve(bytes));
-    HIP_TRY(hipMemcpyAsync(p->d_env.p, faces, bytes, hipMemcpyHostToDevice, p->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-    p->env_size = size;
-    return RT_OK;
-}
-
-int rt_pipeline_set_environment_constant(rt_pipeline *p, const float rgb[3])
-{
-    RT_REQUIRE(p && rgb, "null argument");
-    p->env_size = 0;
-    for (int k = 0; k < 3; k++) p->env_const[k] = rgb[k];
-    return RT_OK;
-}
-
-int rt_pipeline_set_environment_filter(rt_pipeline *p, uint32_t filter)
-{
-    RT_REQUIRE(p, "null pipeline");
-    RT_REQUIRE(filter == RT_CUBE_SEAMLESS || filter == RT_CUBE_FACE_CLAMP, "unknown cube-map filter");
-    p->env_filter = filter;
-    return RT_OK;
-}
-
-int rt_pipeline_load_environment_dds(rt_pipeline *p, const char *path)
-{
-    RT_REQUIRE(p && path, "null argument");
-    std::vector<float> faces;
-    uint32_t size = 0;
-    RT_TRY(rt_dds_load_cube(path, faces, size));
-    return rt_pipeline_set_environment_cube(p, faces.data(), size);
-}
-
-int rt_pipeline_create_output(rt_pipeline *p, uint32_t format, uint32_t width, uint32_t height)
-{
-    RT_REQUIRE(p, "null pipeline");
-    RT_REQUIRE(width > 0 && height > 0, "empty output");
-    RT_REQUIRE(format == RT_FORMAT_R32G32B32A32_FLOAT || format == RT_FORMAT_R16G16B16A16_FLOAT, "unsupported output format");
-    HIP_TRY(hipSetDevice(p->ctx->device));
-    RT_TRY(p->accum_own.reserve((size_t)width * height * 16));
-    if (p->kind == RT_PIPELINE_REALTIME) RT_TRY(p->aov_own.reserve((size_t)width * height * 16));     // kNumOutputResources = 2
-    p->accum = p->accum_own.as<float4>();
-    p->width = width; p->height = height; p->format = format;
-    p->rendered = false;
-    return rt_pipeline_clear_output(p);
-}
-
-int rt_pipeline_bind_output(rt_pipeline *p, void *device_rgba32f, uint32_t width, uint32_t height)
-{
-    RT_REQUIRE(p && device_rgba32f, "null argument");
-    RT_REQUIRE(width > 0 && height > 0, "empty output");
-    RT_REQUIRE(p->kind == RT_PIPELINE_PROGRESSIVE, "bind_output: only the progressive pipeline renders into caller memory");
-    p->accum = (float4 *)device_rgba32f;
-    p->width = width; p->height = height; p->format = RT_FORMAT_R32G32B32A32_FLOAT;
-    p->rendered = false;
-    return RT_OK;
-}
-
-int rt_pipeline_build_acceleration_structures(rt_pipeline *p)
-{
-    RT_REQUIRE(p, "null pipeline");
-    if (!p->scene) { rt_set_error("buildAccelerationStructures: no scene set"); return RT_ERR_STATE; }
-    if (p->scene->built) return RT_OK;       // built once, shared between pipelines
-    p->rendered = false;                     // a rebuild reallocates what last_pd points at
-    return rt_scene_build(p->scene, 2);
-}
-
-int rt_pipeline_set_depth_limits(rt_pipeline *p, uint32_t max_radiance_depth, uint32_t max_shadow_depth)
-{
-    RT_REQUIRE(p, "null pipeline");
-    if (max_radiance_depth > (uint32_t)MAXD) {
-        rt_set_error("max radiance depth %u: the wavefront DAG holds at most %d radiance levels", max_radiance_depth, MAXD);
-        return RT_ERR_UNSUPPORTED;
-    }
-    p->max_rad = max_radiance_depth;
-    p->max_shadow = max_shadow_depth;
-    return RT_OK;
-}
-
-int rt_pipeline_set_skip_unlit_shadow_rays(rt_pipeline *p, int on)
-{
-    RT_REQUIRE(p, "null pipeline");
-    p->skip_unlit = on ? 1u : 0u;
-    return RT_OK;
-}
-
-int rt_pipeline_set_accumulation_mode(rt_pipeline *p, uint32_t mode)
-{
-    RT_REQUIRE(p, "null pipeline");
-    RT_REQUIRE(mode == RT_ACCUM_RUNNING_MEAN || mode == RT_ACCUM_SUM, "unknown accumulation mode");
-    p->accum_mode = mode;
-    return RT_OK;
-}
-
-int rt_pipeline_clear_output(rt_pipeline *p)
-{
-    RT_REQUIRE(p, "null pipeline");
-    if (!p->accum) { rt_set_error("no output resource"); return RT_ERR_STATE; }
-    HIP_TRY(hipSetDevice(p->ctx->device));
-    HIP_TRY(hipMemsetAsync(p->accum, 0, (size_t)p->width * p->height * 16, p->ctx->stream));
-    if (p->aov_own.p) HIP_TRY(hipMemsetAsync(p->aov_own.p, 0, (size_t)p->width * p->height * 16, p->ctx->stream));
-    return RT_OK;
-}
-
-int rt_pipeline_update(rt_pipeline *p, const rt_per_frame_constants *constants)
-{
-    RT_REQUIRE(p && constants, "null argument");
-    p->pfc = *constants;
-    p->have_pfc = true;
-    return RT_OK;
-}
 
 // one frame over the rectangle [x0,x1) x [y0,y1); band_rows != 0: over the interleaved bands {b : b mod band_world == band_rank}
 // of band_rows rows each (the rectangle then spans the full width and the rank's rows, packed)
@@ -1598,226 +837,6 @@ int rt_pipeline_render_batch(rt_pipeline *p, uint32_t width, uint32_t height, co
     }
     RT_TRY(flush());
     if (n) { p->pfc = constants[n - 1]; p->have_pfc = true; }     // as after n x (update, render)
-    return RT_OK;
-}
-
-int rt_pipeline_get_num_outputs(const rt_pipeline *p, int *n)
-{
-    RT_REQUIRE(p && n, "null argument");
-    *n = p->kind == RT_PIPELINE_REALTIME ? 2 : 1;
-    return RT_OK;
-}
-
-int rt_pipeline_get_output_device_ptr(rt_pipeline *p, uint32_t id, void **ptr)
-{
-    RT_REQUIRE(p && ptr, "null argument");
-    RT_REQUIRE(id < (p->kind == RT_PIPELINE_REALTIME ? 2u : 1u), "output index out of range");
-    *ptr = id == 0 ? (void *)p->accum : p->aov_own.p;
-    return RT_OK;
-}
-
-int rt_pipeline_read_output_n(rt_pipeline *p, uint32_t id, void *host, size_t bytes)
-{
-    RT_REQUIRE(p && host, "null argument");
-    RT_REQUIRE(id < (p->kind == RT_PIPELINE_REALTIME ? 2u : 1u), "output index out of range");
-    const float4 *src = id == 0 ? p->accum : p->aov_own.as<float4>();
-    if (!src) { rt_set_error("no output resource"); return RT_ERR_STATE; }
-    HIP_TRY(hipSetDevice(p->ctx->device));
-    const size_t npix = (size_t)p->width * p->height;
-    hipStream_t st = p->ctx->stream;
-    if (p->format == RT_FORMAT_R16G16B16A16_FLOAT) {
-        RT_REQUIRE(bytes == npix * 8, "host buffer must be width*height*8 bytes for RGBA16F");
-        RT_TRY(p->half_out.reserve(npix * 8));
-        k_f32_to_f16<<<blocks(npix), PBLOCK, 0, st>>>(src, p->half_out.as<ushort4>(), npix);
-        HIP_TRY(hipMemcpyAsync(host, p->half_out.p, bytes, hipMemcpyDeviceToHost, st));
-    } else {
-        RT_REQUIRE(bytes == npix * 16, "host buffer must be width*height*16 bytes for RGBA32F");
-        HIP_TRY(hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, st));
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    return RT_OK;
-}
-
-int rt_pipeline_read_output(rt_pipeline *p, void *host, size_t bytes) { return rt_pipeline_read_output_n(p, 0, host, bytes); }
-
-int rt_pipeline_write_output(rt_pipeline *p, const void *host_rgba32f, size_t bytes)
-{
-    RT_REQUIRE(p && host_rgba32f, "null argument");
-    if (!p->accum) { rt_set_error("no output resource"); return RT_ERR_STATE; }
-    RT_REQUIRE(bytes == (size_t)p->width * p->height * 16, "host buffer must be width*height*16 bytes (RGBA32F)");
-    HIP_TRY(hipSetDevice(p->ctx->device));
-    HIP_TRY(hipMemcpyAsync(p->accum, host_rgba32f, bytes, hipMemcpyHostToDevice, p->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-    return RT_OK;
-}
-
-// checkpoint file: "DXRACCUM1\n", u32 width, u32 height, u64 state bytes, host state, width*height float4
-static const char kCheckpointMagic[10] = {'D', 'X', 'R', 'A', 'C', 'C', 'U', 'M', '1', '\n'};
-
-int rt_pipeline_save_checkpoint(rt_pipeline *p, const rt_progressive_host *h, const char *path)
-{
-    RT_REQUIRE(p && path, "null argument");
-    if (!p->accum) { rt_set_error("no output resource"); return RT_ERR_STATE; }
-    RT_REQUIRE(p->kind == RT_PIPELINE_PROGRESSIVE, "checkpoint: only the progressive pipeline accumulates");
-    HIP_TRY(hipSetDevice(p->ctx->device));
-    const size_t bytes = (size_t)p->width * p->height * 16;
-    std::vector<char> img(bytes), state;
-    HIP_TRY(hipMemcpyAsync(img.data(), p->accum, bytes, hipMemcpyDeviceToHost, p->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-    size_t sb = 0;
-    if (h) {
-        RT_TRY(rt_progressive_host_save_state(h, nullptr, 0, &sb));
-        state.resize(sb);
-        RT_TRY(rt_progressive_host_save_state(h, state.data(), sb, &sb));
-    }
-    FILE *f = fopen(path, "wb");
-    if (!f) { rt_set_error("checkpoint: cannot create %s", path); return RT_ERR_IO; }
-    const uint32_t wh[2] = {p->width, p->height};
-    const uint64_t sb64 = sb;
-    bool ok = fwrite(kCheckpointMagic, 1, sizeof kCheckpointMagic, f) == sizeof kCheckpointMagic && fwrite(wh, 4, 2, f) == 2 &&
-              fwrite(&sb64, 8, 1, f) == 1 && (sb == 0 || fwrite(state.data(), 1, sb, f) == sb) && fwrite(img.data(), 1, bytes, f) == bytes;
-    ok = (fclose(f) == 0) && ok;
-    if (!ok) { rt_set_error("checkpoint: short write to %s", path); return RT_ERR_IO; }
-    return RT_OK;
-}
-
-int rt_pipeline_load_checkpoint(rt_pipeline *p, rt_progressive_host *h, const char *path)
-{
-    RT_REQUIRE(p && path, "null argument");
-    if (!p->accum) { rt_set_error("no output resource"); return RT_ERR_STATE; }
-    FILE *f = fopen(path, "rb");
-    if (!f) { rt_set_error("checkpoint: cannot open %s", path); return RT_ERR_IO; }
-    char magic[sizeof kCheckpointMagic];
-    uint32_t wh[2] = {0, 0};
-    uint64_t sb = 0;
-    int rc = RT_OK;
-    std::vector<char> state, img;
-    do {
-        if (fread(magic, 1, sizeof magic, f) != sizeof magic || memcmp(magic, kCheckpointMagic, sizeof magic) != 0 || fread(wh, 4, 2, f) != 2 ||
-            fread(&sb, 8, 1, f) != 1 || sb > (1u << 20)) { rt_set_error("checkpoint: %s is not an accumulation checkpoint", path); rc = RT_ERR_IO; break; }
-        if (wh[0] != p->width || wh[1] != p->height) {
-            rt_set_error("checkpoint: %s holds a %ux%u image, the output is %ux%u", path, wh[0], wh[1], p->width, p->height);
-            rc = RT_ERR_INVALID_ARG;
-            break;
-        }
-        state.resize((size_t)sb);
-        img.resize((size_t)wh[0] * wh[1] * 16);
-        if ((sb && fread(state.data(), 1, (size_t)sb, f) != sb) || fread(img.data(), 1, img.size(), f) != img.size()) {
-            rt_set_error("checkpoint: %s is truncated", path);
-            rc = RT_ERR_IO;
-        }
-    } while (0);
-    fclose(f);
-    if (rc != RT_OK) return rc;
-    if (h && sb) RT_TRY(rt_progressive_host_load_state(h, state.data(), (size_t)sb));
-    return rt_pipeline_write_output(p, img.data(), img.size());
-}
-
-int rt_pipeline_enable_timing(rt_pipeline *p, int frames)
-{
-    RT_REQUIRE(p, "null pipeline");
-    RT_REQUIRE(frames >= 0 && frames <= 4096, "timing ring holds 0..4096 frames");
-    HIP_TRY(hipSetDevice(p->ctx->device));
-    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-    for (hipEvent_t e : p->ring) if (e) (void)hipEventDestroy(e);
-    p->ring.assign((size_t)frames * EV_COUNT, nullptr);
-    p->ring_levels.assign((size_t)frames, 0);
-    p->ring_nframes.assign((size_t)frames, 1);
-    for (hipEvent_t &e : p->ring) HIP_TRY(hipEventCreate(&e));
-    p->ring_frames = frames;
-    p->ring_pos = 0;
-    return RT_OK;
-}
-
-// ms: primary | shade 0 | secondary traces (all levels) | 0 | secondary shades (all levels) | shadow | resolve | total
-static int stage_times(rt_pipeline *p, uint64_t frame, float ms[8])
-{
-    const size_t slot = (size_t)(frame % (uint64_t)p->ring_frames);
-    hipEvent_t *ev = &p->ring[slot * EV_COUNT];
-    const int levels = p->ring_levels[slot];
-    for (int k = 0; k < 8; k++) ms[k] = 0.0f;
-    HIP_TRY(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
-    HIP_TRY(hipEventElapsedTime(&ms[1], ev[1], ev[2]));
-    int last = 2;
-    for (int l = 1; l <= levels; l++) {
-        float t = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&t, ev[last], ev[3 + 2 * (l - 1)]));
-        ms[2] += t;
-        HIP_TRY(hipEventElapsedTime(&t, ev[3 + 2 * (l - 1)], ev[4 + 2 * (l - 1)]));
-        ms[4] += t;
-        last = 4 + 2 * (l - 1);
-    }
-    HIP_TRY(hipEventElapsedTime(&ms[5], ev[last], ev[EV_SHADOW]));
-    HIP_TRY(hipEventElapsedTime(&ms[6], ev[EV_SHADOW], ev[EV_RESOLVE]));
-    HIP_TRY(hipEventElapsedTime(&ms[7], ev[0], ev[EV_RESOLVE]));
-    return RT_OK;
-}
-
-static void add_times(rt_stats *out, const float ms[8])
-{
-    out->ms_primary += ms[0]; out->ms_shade0 += ms[1]; out->ms_trace_secondary += ms[2]; out->ms_trace_shadow0 += ms[3];
-    out->ms_shade1 += ms[4]; out->ms_trace_shadow1 += ms[5]; out->ms_resolve += ms[6]; out->ms_total += ms[7];
-}
-
-int rt_pipeline_get_stats(rt_pipeline *p, rt_stats *out)
-{
-    RT_REQUIRE(p && out, "null argument");
-    HIP_TRY(hipSetDevice(p->ctx->device));
-    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-    memset(out, 0, sizeof *out);
-    if (!p->rendered) return RT_OK;
-    uint32_t c[C_COUNT];
-    HIP_TRY(hipMemcpy(c, p->counters.p, sizeof c, hipMemcpyDeviceToHost));
-    out->rays_primary = p->last_pixels;
-    out->primary_hits = c[C_NHIT];
-    out->secondary_hits = 0;
-    for (int l = 1; l <= MAXD; l++) out->secondary_hits += c[C_NHIT + l];
-    out->rays_secondary = c[C_SECONDARY];
-    out->rays_shadow = (uint64_t)c[C_SHADOW] + c[C_SHADOW_SKIPPED];
-    out->rays_shadow_skipped = c[C_SHADOW_SKIPPED];
-    out->frames = p->last_pd.n_frames;
-    if (p->ring_frames > 0 && p->ring_pos > 0) {
-        float ms[8];
-        RT_TRY(stage_times(p, p->ring_pos - 1, ms));
-        add_times(out, ms);
-    }
-    p->stats = *out;
-    return RT_OK;
-}
-
-int rt_pipeline_get_totals(rt_pipeline *p, rt_stats *out)
-{
-    RT_REQUIRE(p && out, "null argument");
-    HIP_TRY(hipSetDevice(p->ctx->device));
-    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-    memset(out, 0, sizeof *out);
-    if (!p->totals.p) return RT_OK;
-    unsigned long long t[8];
-    HIP_TRY(hipMemcpy(t, p->totals.p, sizeof t, hipMemcpyDeviceToHost));
-    out->rays_primary = t[0]; out->rays_secondary = t[1]; out->rays_shadow = t[2]; out->rays_shadow_skipped = t[6];
-    out->primary_hits = t[3]; out->secondary_hits = t[4];
-    out->frames = t[5];
-    if (p->ring_frames > 0) {
-        const uint64_t have = p->ring_pos < (uint64_t)p->ring_frames ? p->ring_pos : (uint64_t)p->ring_frames;
-        uint64_t covered = 0;
-        for (uint64_t f = p->ring_pos - have; f < p->ring_pos; f++) {
-            float ms[8];
-            RT_TRY(stage_times(p, f, ms));
-            add_times(out, ms);
-            covered += p->ring_nframes[(size_t)(f % (uint64_t)p->ring_frames)];
-        }
-        if (covered < out->frames) out->frames = covered;      // times cover only the remembered frames
-    }
-    return RT_OK;
-}
-
-int rt_pipeline_reset_totals(rt_pipeline *p)
-{
-    RT_REQUIRE(p, "null pipeline");
-    HIP_TRY(hipSetDevice(p->ctx->device));
-    if (p->totals.p) HIP_TRY(hipMemsetAsync(p->totals.p, 0, 8 * sizeof(unsigned long long), p->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-    p->ring_pos = 0;
     return RT_OK;
 }
 

@@ -1,0 +1,156 @@
+// rt_pipeline_dev.h -- what the translation units of the pipeline share: the stage constants, the device-visible view of a
+// frame (PipeDev: what every kernel of the wavefront DAG takes as its argument), and the host object behind rt_pipeline.
+// Kernels and launches: rt_pipeline.hip.  Device shading functions: rt_shade.h.  Outputs, checkpoints, statistics:
+// rt_pipeline_host.hip.
+#pragma once
+
+#include "rt_trace_wave.h"
+
+namespace rtp {
+
+using namespace rtd;
+
+
+constexpr int PBLOCK = 256;
+#ifndef RT_SHADOW_UNORDERED
+#define RT_SHADOW_UNORDERED 1
+#endif
+// (only the any-hit instantiation of the walk tallies the queue slots marked "emitted but not traversed": with ordered shadow
+// walks rt_stats.rays_shadow would under-count when rt_pipeline_set_skip_unlit_shadow_rays is on)
+static_assert(RT_SHADOW_UNORDERED != 0, "the shadow stage counts skipped slots in the ANYHIT walk only");
+
+#define RAY_MAX_T 1.0e+38f      // RaytracingCommon.hlsli:8
+#define RAY_EPSILON 0.0001f     // RaytracingCommon.hlsli:9
+#define HLSL_PI 3.1415927f      // RaytracingUtils.hlsli:22
+
+#define HIT_MISS -1.0f
+#define HIT_UNTRACED -2.0f
+
+// Radiance rays are traced level by level: level 0 = primary rays, level L = rays spawned by the hits of
+// level L-1.  MAX_RADIANCE_RAY_DEPTH (RaytracingCommon.hlsli:11) is 1 in the reference; the DAG below is
+// generic up to MAXD so that BASELINE config 5 ("4-bounce") runs.  Because indirect DIFFUSE is only sampled
+// at depth 0 (ProgressiveRaytracing.hlsl:107), every pixel owns at most two chains of specular bounces.
+constexpr int MAXD = 4;
+enum { C_NHIT = 0,                       // [0..MAXD] compacted hits per level
+       C_SECONDARY = MAXD + 1, C_SHADOW = MAXD + 2,
+       C_SHADOW_SKIPPED = MAXD + 3,      // shadow rays whose result cannot matter (N.L == 0): emitted, counted (by the shadow
+                                         //   launch: traced_counter[1], rt_trace_wave.h), not traversed
+       C_COUNT = MAXD + 4 };
+
+// Level L: the rays at radiance depth L (L >= 1; primary rays are generated, not stored), their hit
+// records, the compaction of the hits, and the shadow-ray queue of those hits.
+//   slots of level 1: w*cap + k  (w = 0 diffuse / 1 specular batch, k = compact index of the primary hit)
+//   slots of level L >= 2: j     (compact index of the level L-1 hit that spawned the ray)
+//   shadow queue of level L: s*hcap(L) + idx, idx = compact hit index, hcap(0) = cap, hcap(L>=1) = 2 cap
+struct LevelDev {
+    float4 *O, *D;              // ray queue (unused at level 0)
+    float4 *hit; uint32_t *inst;   // hit records, indexed by slot (level 0: by pixel slot q)
+    uint32_t *slot_j, *jlist;   // slot -> compact hit index (RT_NO_HIT if none), compact index -> slot
+    uint32_t *pix;              // slot -> pixel slot q (unused at level 0)
+    float4 *shO, *shD; uint32_t *vis;
+    float4 *color;              // deep paths (more than one radiance level): the shaded colour of every hit of this level, by slot
+};
+
+// the frame's two light rays as the shadow-queue loader rebuilds them (QueueSrc::load)
+struct LightRays {
+    uint32_t on;
+    float dir_to_light[3];      // normalize(-directionalLight.forwardDir), computed once per frame on the host with the
+                                //   device's expression (IEEE sqrt and division, left-to-right sums, no contraction)
+    float point_pos[3];         // pointLight.worldPos
+};
+
+#define RT_MAX_BATCH 16u                // frames one set of launches renders (rt_pipeline_render_batch)
+
+struct PipeDev {
+    SceneDev sc;
+    rt_per_frame_constants pfc;         // the frame's constants (a batch: of its first frame; kernels take pfcs[frame])
+    // a BATCH of frames in one set of launches (config 3, rt_pipeline_render_batch): frame f owns the pixel slots
+    // [f * fcap, (f + 1) * fcap), every queue is n_frames times as long, a slot's frame selects constants and lights
+    uint32_t n_frames, fcap;            // single frame: 1, cap
+    const rt_per_frame_constants *pfcs; // device array [n_frames] (batches only)
+    const LightRays *frame_lights;      // device array [n_frames] (batches only)
+    const rt_material_params *mats;
+    uint32_t nmats;
+    const float4 *env;
+    uint32_t env_size;
+    uint32_t env_filter;                // RT_CUBE_SEAMLESS / RT_CUBE_FACE_CLAMP
+    float env_const[3];
+    uint32_t width, height;
+    uint32_t x0, y0, tw, th, cap;       // tile rectangle; cap = n_frames * tiles_x * tiles_y * 64 pixel slots
+    uint32_t tiles_x;
+    uint32_t band_rows, band_rank, band_world;      // band_rows != 0: the rectangle's rows are interleaved bands of the image
+    uint32_t n_pixels;                  // pixels of the image this launch covers
+    uint32_t max_rad, max_shadow;
+    uint32_t accum_mode;
+    uint32_t skip_unlit;                // do not traverse shadow rays of lights with N.L == 0 (their visibility is multiplied by 0)
+    uint32_t shadow_compact;            // shadow queues hold ONE float4 per shaded hit (QueueSrc, "light rays")
+    uint32_t kind;                      // RT_PIPELINE_PROGRESSIVE / RT_PIPELINE_REALTIME
+    float4 *accum;
+    float4 *aov_direct, *aov_indirect;  // realtime pipeline outputs (RealtimeRaytracing.hlsl:3-4)
+    uint32_t *counters;
+    unsigned long long *totals;         // running sums over frames (rt_pipeline_get_totals); updated by the frame's last kernel
+    uint32_t *pools;            // chunk counters of the persistent launches: [1 + MAXD][RT_POOL_GROUPS], 128 B apart
+    LevelDev lv[MAXD + 1];
+};
+
+constexpr size_t POOL_BYTES = (size_t)(1 + MAXD) * RT_POOL_GROUPS * RT_POOL_STRIDE * 4;      // shadow launch, levels 1..MAXD
+constexpr size_t POOL_OFFSET_WORDS = 64;      // the pools start on a 256-B boundary after the scalar counters
+
+RT_DEV uint32_t hcap(const PipeDev &pd, int L) { return L == 0 ? pd.cap : 2u * pd.cap; }
+
+inline unsigned blocks(size_t n) { return (unsigned)((n + PBLOCK - 1) / PBLOCK); }
+
+}  // namespace rtp
+
+using namespace rtp;
+
+// ---- host object ------------------------------------------------------------------------
+
+struct rt_pipeline {
+    rt_context *ctx = nullptr;
+    uint32_t kind = RT_PIPELINE_PROGRESSIVE;
+    DevBuf aov_own;                    // realtime: second output (indirect specular); the first lives in accum_own
+    rt_scene *scene = nullptr;
+    std::vector<rt_material_params> mats;
+    DevBuf d_mats;
+    bool mats_dirty = true;
+    DevBuf d_env;
+    uint32_t env_size = 0;
+    uint32_t env_filter = RT_CUBE_SEAMLESS;
+    float env_const[3] = {0.5f, 0.5f, 0.5f};
+    uint32_t width = 0, height = 0, format = RT_FORMAT_R32G32B32A32_FLOAT;
+    DevBuf accum_own;
+    float4 *accum = nullptr;
+    rt_per_frame_constants pfc;
+    bool have_pfc = false;
+    uint32_t max_rad = 1, max_shadow = 2, accum_mode = RT_ACCUM_RUNNING_MEAN;
+    uint32_t skip_unlit = 0;           // off by default: every shadow ray the reference traces is traversed (rt_pipeline_set_skip_unlit_shadow_rays)
+    // queues (sized for `cap` pixels)
+    uint32_t cap = 0, sh0_batches = 0, levels = 0;
+    struct LevelBuf { DevBuf O, D, hit, inst, slot_j, jlist, pix, shO, shD, vis, color; } lv[MAXD + 1];
+    DevBuf counters;
+    DevBuf half_out;
+    std::vector<hipEvent_t> ring;      // EV_COUNT events per remembered frame
+    std::vector<uint8_t> ring_levels;  // radiance levels each remembered frame ran
+    std::vector<uint8_t> ring_nframes; // frames each remembered entry covers (a batch is one entry)
+    DevBuf batch_consts;               // per-frame constants and light rays of a batch (rt_pipeline_render_batch)
+    int ring_frames = 0;               // 0 = timing off
+    uint64_t ring_pos = 0;             // frames recorded since enable / reset
+    DevBuf totals, work;
+    PipeDev last_pd;
+    uint32_t last_shadow_slots = 2;
+    rt_stats stats;
+    uint32_t last_tile[4] = {0, 0, 0, 0};
+    uint32_t last_pixels = 0;
+    bool rendered = false;
+    uint32_t last_scene_gen = 0;       // generation of the scene last_pd was filled from
+};
+
+namespace rtp {
+
+
+// events of one frame: start | primary | shade 0 | (trace l, shade l) for l = 1..MAXD | shadow | resolve
+constexpr int EV_COUNT = 5 + 2 * MAXD;
+constexpr int EV_SHADOW = 3 + 2 * MAXD, EV_RESOLVE = 4 + 2 * MAXD;
+
+}  // namespace rtp

@@ -2,6 +2,7 @@
 // Python test can compare it with the committed golden frames (tests/golden/cornell64_golden.npz).
 //   test_wrapper <cornell.obj> <out.f32>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "DenoiseCompositor.h"
@@ -45,6 +46,20 @@ int main(int argc, char **argv)
         if (!f) return 4;
         std::fwrite(image.data(), 4, image.size(), f);
         std::fclose(f);
+        // the same four frames through ONE set of launches (renderBatch -> rt_pipeline_render_batch): the same bits
+        {
+            auto batched = ProgressiveRaytracingPipeline::create(context, 1234);
+            batched->setScene(scene);
+            batched->addMaterial(material);
+            batched->setCamera(camera);
+            batched->loadResources(3);
+            batched->createOutputResource(RT_FORMAT_R32G32B32A32_FLOAT, W, H);
+            batched->buildAccelerationStructures();
+            batched->renderBatch(0.0f, 1, 4, W, H);
+            std::vector<float> again(image.size());
+            batched->readOutput(again.data(), again.size() * 4);
+            if (std::memcmp(again.data(), image.data(), image.size() * 4) != 0) return 13;
+        }
         // error behaviour: a missing model falls back to the reference's single triangle, bad programs throw
         auto fallback = RtModel::create(context, "/nonexistent.obj");
         if (fallback->getNumTriangles() != 1) return 5;

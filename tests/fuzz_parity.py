@@ -6,7 +6,9 @@ by hand, on a GPU box, for as long as wanted:
 
 Every iteration draws a scene (triangle soups, blobs, displaced grids, Cornell; one identity instance or several
 transformed ones), materials, debug options, depth limits, an image size and a tile, renders two frames with the
-GPU pipeline (progressive or realtime) and with the CPU oracle, and demands bit-equal images and ray counts.
+GPU pipeline (progressive or realtime) and with the CPU oracle, and demands bit-equal images and ray counts; progressive
+draws then go on for one to five more frames through ONE set of launches (rt_pipeline_render_batch) against the oracle's
+frame-by-frame accumulation.
 Exits non-zero on the first difference and prints the draw that caused it."""
 import os
 import sys
@@ -112,6 +114,14 @@ def run(iters, seed, ctx, verbose=True):
             if not (ok and same):
                 oracle.set_cube_seamless(True)
                 return "MISMATCH %r frame %d image equal: %s gpu %r oracle %r" % (desc, f, ok, {k: gst[k] for k in ost if k in gst}, ost)
+        if not realtime:               # the same accumulation continued by a batch of frames in one set of launches
+            more = [host.update(cam, 0.0, 3 + k, W, H) for k in range(int(r.integers(1, 6)))]
+            p.render_batch(more)
+            for pfc in more:
+                acc, ost = osc.render(omats, pfc, W, H, accum=acc, env_faces=env, max_radiance_depth=depth[0], max_shadow_depth=depth[1], nthreads=8)
+            if not np.array_equal(p.read_output(), acc):
+                oracle.set_cube_seamless(True)
+                return "MISMATCH %r after a batch of %d frames" % (desc, len(more))
         if verbose and it % 10 == 0:
             print("ok", desc, flush=True)
     oracle.set_cube_seamless(True)

@@ -132,3 +132,35 @@ def test_config3_on_one_device_8_shards_of_32_frames(gpu, capi):
     shard_mean = (total / N).astype(np.float32)
     assert rms(shard_mean, mean) <= 1e-5
     assert shard_mean[..., 3].min() == 1.0 and np.isfinite(shard_mean).all()
+
+
+def test_config3_at_full_size_1080p_256_frames(gpu, capi):
+    """BASELINE configs[2] at the stated size on one device: 1920x1080, 256 frames.  The 256-frame running mean rendered in
+    batches of 16 against the same 256 frames as eight SUM shards of 32 (what the eight ranks of a node would hold before
+    their all-reduce): (sum of sums) / 256 within 1e-5 RMS; alpha stays exactly 1; and the first batch of the running mean
+    equals 16 single frames bit for bit (the oracle comparison of this scene runs at 192x108, test_gpu_pipeline.py)."""
+    W, H = 1920, 1080
+    v, i = scenes.sponza_class(seed=42)
+    p = make_gpu_pipeline(capi, gpu, [(v, i)], [(0, None)], [T.default_material()], W, H, env=scenes.sky_cubemap(64))
+    cam = cam_array(scenes.sponza_camera(), W / H)
+    N, R = 256, 8
+    pfcs = frames_of(capi, cam, N, W, H, seed=1234)
+    p.set_accumulation_mode(T.ACCUM_RUNNING_MEAN)
+    p.clear_output()
+    for c in pfcs[:16]:
+        p.update(c); p.render()
+    first16 = p.read_output()
+    p.clear_output()
+    p.render_batch(pfcs[:16])
+    assert np.array_equal(p.read_output(), first16), "a batch of 16 differs from 16 frames at 1080p"
+    p.render_batch(pfcs[16:])
+    mean = p.read_output()
+    p.set_accumulation_mode(T.ACCUM_SUM)
+    total = np.zeros_like(mean, dtype=np.float64)
+    for r in range(R):
+        p.clear_output()
+        p.render_batch(pfcs[r::R])
+        total += p.read_output()
+    shard_mean = (total / N).astype(np.float32)
+    assert rms(shard_mean, mean) <= 1e-5
+    assert shard_mean[..., 3].min() == 1.0 and shard_mean[..., 3].max() == 1.0 and np.isfinite(shard_mean).all()
