@@ -3,7 +3,8 @@
 # a kernel-trace pass and separate PMC passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950; SQ and TCC
 # sets in passes of their own), each around the same bench command.
 # usage: tools/run_profiles.sh <tag> [workloads...]    -> gpurun_out/<tag>/<workload>_<pass>.md (+ .log)
-# workloads: c2 (bench default), c5 (10 M triangles 4K), c4 (4096 instances 4K realtime + denoiser: tools/profile_c4.py)
+# workloads: c2 (bench default), c5 (10 M triangles 4K), c4 (4096 instances 4K realtime + denoiser: tools/profile_c4.py),
+#            c2b / c5b (the same two with 8 frames per set of launches, rt_pipeline_render_batch); PASSES="kt ea write" limits the passes
 TAG=${1:-r02}; shift
 WL=${@:-c2 c5}
 R=$PWD
@@ -12,7 +13,11 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for w in $WL; do
   PROG=$R/bench.py
-  if [ $w = c2 ]; then ARGS="--steps 8 --warmup 2 --cpu-seconds 0 --hbm-frames 0 --no-live-pmc"; elif [ $w = c5 ]; then ARGS="--workload c5 --hbm-frames 4 --no-live-pmc"; else PROG=$R/tools/profile_c4.py; ARGS="4"; fi
+  if [ $w = c2 ]; then ARGS="--steps 8 --warmup 2 --cpu-seconds 0 --hbm-frames 0 --no-live-pmc";
+  elif [ $w = c2b ]; then ARGS="--steps 16 --warmup 8 --batch 8 --cpu-seconds 0 --hbm-frames 0 --no-live-pmc";       # sample batches: 8 frames per launch set
+  elif [ $w = c5 ]; then ARGS="--workload c5 --hbm-frames 4 --no-live-pmc";
+  elif [ $w = c5b ]; then ARGS="--workload c5 --hbm-frames 8 --batch 8 --no-live-pmc";
+  else PROG=$R/tools/profile_c4.py; ARGS="4"; fi
   run() {   # name, rocprof options...
     n=$1; shift
     timeout 600 rocprofv3 "$@" -d $OUT/${w}_$n -o p --output-format csv -- python3 $PROG $ARGS > $OUT/${w}_$n.log 2>&1
@@ -20,7 +25,9 @@ for w in $WL; do
     rm -rf $OUT/${w}_$n
     tail -n 1 $OUT/${w}_$n.log | cut -c 1-300
   }
-  run kt --kernel-trace --stats
+  want() { [ -z "$PASSES" ] || echo " $PASSES " | grep -q " $1 "; }
+  want kt && run kt --kernel-trace --stats
+  [ -n "$PASSES" ] && { want ea && run ea --kernel-trace --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_sum; want write && run write --kernel-trace --pmc WRITE_SIZE; want sq && run sq --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU; want fetch && run fetch --kernel-trace --pmc FETCH_SIZE; continue; }
   run fetch --kernel-trace --pmc FETCH_SIZE
   run write --kernel-trace --pmc WRITE_SIZE
   run tcc --kernel-trace --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
@@ -29,12 +36,13 @@ for w in $WL; do
   # the vector-memory path between the lanes and the L2 (round 3): L1 tag accesses, L1 -> L2 read requests and their summed
   # latency, cycles the L1 waits for L2 data, address-unit busy cycles and the wave instructions it took
   run tcp --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum
-  run ta --kernel-trace --pmc TA_TA_BUSY_sum TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum
+  # (the TA set -- TA_TA_BUSY_sum TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum -- aborts rocprofv3 7.2 on
+  # this image with signal 6 and is not collected)
   run ta2 --kernel-trace --pmc TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum GRBM_GUI_ACTIVE
 done
 if [ -n "$CALIBRATE" ]; then
   # the same counters on tools/microbench/slab_fetch (known lines per lane and launch): counter units per 64-B line / 128-B block
-  for n in tcp ta ta2; do
+  for n in tcp ta2; do
     case $n in
       tcp) C="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum";;
       ta) C="TA_TA_BUSY_sum TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum";;

@@ -41,19 +41,23 @@ def main():
                          "Infinity-Cache hits are included (MI355X_MICROARCH.md, HBM section)",
            "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, text=True).stdout.strip(),
            "workloads": {}}
-    for w in ("c2", "c5", "c4"):
+    for w in ("c2", "c5", "c4", "c2b", "c5b"):          # (c2b / c5b: the same workloads at 8 frames per set of launches)
         kt, fe, wr = rows("%s/%s_kt.md" % (d, w)), rows("%s/%s_fetch.md" % (d, w)), rows("%s/%s_write.md" % (d, w))
         tcc, sq, ea = rows("%s/%s_tcc.md" % (d, w)), rows("%s/%s_sq.md" % (d, w)), rows("%s/%s_ea.md" % (d, w))
         tcp, ta2 = rows("%s/%s_tcp.md" % (d, w)), rows("%s/%s_ta2.md" % (d, w))
-        if not fe:
+        if not fe and not ea:
             continue
         ks = {}
         for k in KERNELS:
-            if (k, "FETCH_SIZE") not in fe:
+            if (k, "FETCH_SIZE") not in fe and (k, "TCC_EA0_RDREQ_128B_sum") not in ea:
                 continue
-            f, wv = fe[(k, "FETCH_SIZE")], wr.get((k, "WRITE_SIZE"), 0.0)
-            e = {"fetch_size_kib_per_launch": f, "write_size_kib_per_launch": wv, "dispatches": int(fe[(k, "FETCH_SIZE:n")]),
-                 "bytes_per_launch_fetch_x2": int((2.0 * f + wv) * 1024)}
+            wv = wr.get((k, "WRITE_SIZE"), 0.0)
+            if (k, "FETCH_SIZE") in fe:
+                f = fe[(k, "FETCH_SIZE")]
+                e = {"fetch_size_kib_per_launch": f, "write_size_kib_per_launch": wv, "dispatches": int(fe[(k, "FETCH_SIZE:n")]),
+                     "bytes_per_launch_fetch_x2": int((2.0 * f + wv) * 1024)}
+            else:                            # (passes limited to the read requests by size)
+                e = {"write_size_kib_per_launch": wv, "dispatches": int(ea[(k, "TCC_EA0_RDREQ_128B_sum:n")])}
             # read requests by size (their own pass): the calibrated figure for this access shape; FETCH_SIZE x 2 (the guide's
             # correction for wide streaming reads) is kept beside it
             sized = [ea.get((k, "TCC_EA0_RDREQ_%s_sum" % sz)) for sz in ("32B", "64B", "128B")]
@@ -62,6 +66,8 @@ def main():
                 e["bytes_per_launch"] = int(e["read_bytes_by_request_size"] + wv * 1024)
             else:
                 e["bytes_per_launch"] = e["bytes_per_launch_fetch_x2"]
+            if w.endswith("b"):
+                e["frames_per_launch"] = 8
             if (k, "avg_us") in kt:
                 e["avg_us"] = kt[(k, "avg_us")]
                 e["GBps"] = e["bytes_per_launch"] / (e["avg_us"] * 1e-6) / 1e9
