@@ -20,6 +20,7 @@
 #include <zlib.h>
 
 #include <map>
+#include <new>
 #include <string>
 
 #include "rt_internal.h"
@@ -64,6 +65,8 @@ bool read_array(const Reader &r, size_t &p, char type, Prop &out)
     p += 12;
     if (p + clen > r.n) return false;
     const size_t es = (type == 'd' || type == 'l') ? 8 : (type == 'b' ? 1 : 4);
+    // (a count the payload cannot possibly hold -- deflate expands at most ~1032 : 1 -- is a malformed file, not an allocation)
+    if ((size_t)count * es > (enc == 1 ? (size_t)clen * 1100 + 64 : (size_t)clen)) return false;
     std::vector<unsigned char> raw((size_t)count * es);
     if (enc == 0) {
         if (clen != raw.size()) return false;
@@ -107,7 +110,6 @@ bool read_node(const Reader &r, size_t off, Node &out, size_t *end, int depth)
     out.name.assign((const char *)r.d + off, nl);
     off += nl;
     size_t p = off;
-    const bool wanted = true;
     for (unsigned long long i = 0; i < np; i++) {
         Prop pr;
         char t = 0;
@@ -133,7 +135,7 @@ bool read_node(const Reader &r, size_t off, Node &out, size_t *end, int depth)
         }
         default: return false;
         }
-        if (wanted) out.props.push_back(std::move(pr));
+        out.props.push_back(std::move(pr));
     }
     if (p != off + pl) return false;
     size_t at = off + pl;
@@ -142,6 +144,7 @@ bool read_node(const Reader &r, size_t off, Node &out, size_t *end, int depth)
         size_t ke = 0;
         if (!read_node(r, at, k, &ke, depth + 1)) return false;
         if (ke == 0) break;                              // the null record: end of this node's children
+        if (ke <= at) return false;                      // (a record that does not advance: malformed)
         out.kids.push_back(std::move(k));
         at = ke;
     }
@@ -322,7 +325,19 @@ int add_geometry(const Node &geo, const M34 &xf, std::vector<rt_vertex> &verts, 
 
 }  // namespace
 
+static int fbx_parse_unguarded(const char *path, std::vector<rt_vertex> &verts, std::vector<uint32_t> &idx);
+
 int rt_fbx_parse(const char *path, std::vector<rt_vertex> &verts, std::vector<uint32_t> &idx)
+{
+    try {                                    // (no exception crosses the C ABI)
+        return fbx_parse_unguarded(path, verts, idx);
+    } catch (const std::bad_alloc &) {
+        rt_set_error("%s: out of host memory", path);
+        return RT_ERR_OOM;
+    }
+}
+
+static int fbx_parse_unguarded(const char *path, std::vector<rt_vertex> &verts, std::vector<uint32_t> &idx)
 {
     FILE *f = fopen(path, "rb");
     if (!f) { rt_set_error("cannot open %s", path); return RT_ERR_IO; }
@@ -344,7 +359,7 @@ int rt_fbx_parse(const char *path, std::vector<rt_vertex> &verts, std::vector<ui
     while (at + (r.wide ? 25 : 13) <= data.size()) {
         Node n;
         size_t e = 0;
-        if (!read_node(r, at, n, &e, 0)) { rt_set_error("%s: malformed FBX record at byte %zu", path, at); return RT_ERR_IO; }
+        if (!read_node(r, at, n, &e, 0) || (e != 0 && e <= at)) { rt_set_error("%s: malformed FBX record at byte %zu", path, at); return RT_ERR_IO; }
         if (e == 0) break;
         top.push_back(std::move(n));
         at = e;

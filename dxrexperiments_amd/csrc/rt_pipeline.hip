@@ -824,10 +824,16 @@ int rt_pipeline_render_batch(rt_pipeline *p, uint32_t width, uint32_t height, co
     // frames that disagree on what sizes the queues (the ambient-occlusion view) do not share a set of launches
     std::vector<rt_per_frame_constants> run;
     auto flush = [&]() -> int {
-        if (run.empty()) return RT_OK;
-        const int rc = render_region(p, width, height, 0, 0, width, height, 0, 0, 1, run.data(), (uint32_t)run.size());
+        // the queues grow with the batch: when the device cannot hold them, the same frames go through in smaller sets
+        for (size_t at = 0; at < run.size();) {
+            const size_t n_now = run.size() - at < batch_max ? run.size() - at : batch_max;
+            const int rc = render_region(p, width, height, 0, 0, width, height, 0, 0, 1, run.data() + at, (uint32_t)n_now);
+            if (rc == RT_ERR_OOM && n_now > 1) { batch_max = (uint32_t)(n_now / 2); continue; }
+            if (rc != RT_OK) { run.clear(); return rc; }
+            at += n_now;
+        }
         run.clear();
-        return rc;
+        return RT_OK;
     };
     for (uint32_t i = 0; i < n; i++) {
         const rt_per_frame_constants &c = constants[i];
