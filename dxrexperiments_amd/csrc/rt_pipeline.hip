@@ -607,6 +607,26 @@ hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots
     shadows.vis[0] = pd.lv[0].vis;
     shadows.nq = 1;
     size_t shadow_max = (size_t)cap * shadow_slots;
+    auto trace_shadows = [&](const ShadowQueues &sq, size_t rays_max, uint32_t *pool, hipStream_t s) {
+        if (B) k_trace_shadow<STACK, TWO_LEVEL, true><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL, true>, PBLOCK, rays_max), PBLOCK, 0, s>>>(
+            pd.sc, sq, pool, &pd.counters[C_SHADOW]);
+        else k_trace_shadow<STACK, TWO_LEVEL, false><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL, false>, PBLOCK, rays_max), PBLOCK, 0, s>>>(
+            pd.sc, sq, pool, &pd.counters[C_SHADOW]);
+    };
+    // The shadow rays of the primary hits depend on nothing the secondary rays produce: their launch goes to a second
+    // stream and runs BESIDE the secondary launch -- both are persistent launches sized to fill the chip, so the workgroups
+    // of the one that comes second start as those of the first run out of rays, and the machine stays full through what
+    // would be the first one's drain (a third of a stage at 1080p, profiles/r03/drain_vs_occupancy.txt).  The shadow rays of
+    // the deeper hits follow in a launch of their own at the end, as before.
+    const bool early = p->overlap_shadow0 > 0 && levels >= 1 && p->side != nullptr;
+    if (early) {
+        record(p->ev_fork, st);
+        if (hipStreamWaitEvent(p->side, p->ev_fork, 0) != hipSuccess && first_error == hipSuccess) first_error = hipErrorUnknown;
+        trace_shadows(shadows, shadow_max, pd.pools + (size_t)(1 + MAXD) * RT_POOL_GROUPS * RT_POOL_STRIDE, p->side);
+        record(p->ev_join, p->side);
+        shadows.nq = 0;
+        shadow_max = 0;
+    }
     for (uint32_t l = 1; l <= levels; l++) {
         // level 1: the diffuse and the specular batch of the primary hits; deeper: one ray per hit of level l-1
         const QueueSrc rays = {pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE, none};   // ProgressiveRaytracing.hlsl:53
@@ -627,10 +647,8 @@ hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots
             shadow_max += (size_t)cap * 4;
         }
     }
-    if (B) k_trace_shadow<STACK, TWO_LEVEL, true><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL, true>, PBLOCK, shadow_max), PBLOCK, 0, st>>>(
-        pd.sc, shadows, pd.pools, &pd.counters[C_SHADOW]);
-    else k_trace_shadow<STACK, TWO_LEVEL, false><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL, false>, PBLOCK, shadow_max), PBLOCK, 0, st>>>(
-        pd.sc, shadows, pd.pools, &pd.counters[C_SHADOW]);
+    if (shadows.nq > 0) trace_shadows(shadows, shadow_max, pd.pools, st);
+    if (early && hipStreamWaitEvent(st, p->ev_join, 0) != hipSuccess && first_error == hipSuccess) first_error = hipErrorUnknown;
     if (T) record(ev[EV_SHADOW], st);
     // (resolve: one thread per pixel slot of ONE frame; a batch's frames are accumulated in order inside the thread)
     if (levels <= 1) {                          // (level by level is slower here: 0.143 vs 0.118 ms at 1080p)
@@ -780,6 +798,15 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     static_assert(C_COUNT <= POOL_OFFSET_WORDS, "scalar counters overlap the chunk pools");
     pd.pools = pd.counters + POOL_OFFSET_WORDS;
     pd.totals = p->totals.as<unsigned long long>();
+    if (p->overlap_shadow0 < 0) {
+        const char *e = getenv("RT_OVERLAP_SHADOW0");
+        p->overlap_shadow0 = e ? (atoi(e) != 0 ? 1 : 0) : RT_OVERLAP_SHADOW0_DEFAULT;
+    }
+    if (p->overlap_shadow0 > 0 && p->side == nullptr) {
+        HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    }
     // 18 LDS stack rows + the 8-row top table = 26 KiB per 256-thread block = 6 resident blocks per CU, whatever
     // the depth of the tree; the rare deeper walk continues in global rows (rt_trace_wave.h)
     HIP_TRY(ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST ? launch_frame_any<RT_LDS_STACK_ROWS_TEST>(p, pd, shadow_slots)
@@ -955,6 +982,18 @@ int rt_debug_trace_stats(unsigned long long out[8 + 64])
     HIP_TRY(hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(rtd::g_trace_sp_hist), sizeof zero));
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rtd::g_trace_stats), zero, 8 * sizeof zero[0]));
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rtd::g_trace_sp_hist), zero, sizeof zero));
+    return RT_OK;
+}
+#endif
+
+#ifdef RT_TRACE_TIMES
+// instrumentation build only: select the launches whose waves record their times (0 closest-hit queues, 1 any-hit queues) /
+// read the 4 x 8192 records of the last such launch
+int rt_debug_wave_times(int select, unsigned long long *out)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    if (out) HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rtd::g_trace_wave_t), 4 * 8192 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rtd::g_trace_sel), &select, sizeof select));
     return RT_OK;
 }
 #endif

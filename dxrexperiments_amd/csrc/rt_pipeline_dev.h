@@ -89,11 +89,14 @@ struct PipeDev {
     float4 *aov_direct, *aov_indirect;  // realtime pipeline outputs (RealtimeRaytracing.hlsl:3-4)
     uint32_t *counters;
     unsigned long long *totals;         // running sums over frames (rt_pipeline_get_totals); updated by the frame's last kernel
-    uint32_t *pools;            // chunk counters of the persistent launches: [1 + MAXD][RT_POOL_GROUPS], 128 B apart
+    uint32_t *pools;            // chunk counters of the persistent launches: [2 + MAXD][RT_POOL_GROUPS], 128 B apart
     LevelDev lv[MAXD + 1];
 };
 
-constexpr size_t POOL_BYTES = (size_t)(1 + MAXD) * RT_POOL_GROUPS * RT_POOL_STRIDE * 4;      // shadow launch, levels 1..MAXD
+constexpr size_t POOL_BYTES = (size_t)(2 + MAXD) * RT_POOL_GROUPS * RT_POOL_STRIDE * 4;      // shadow launch, levels 1..MAXD, early shadow launch
+#ifndef RT_OVERLAP_SHADOW0_DEFAULT
+#define RT_OVERLAP_SHADOW0_DEFAULT 0
+#endif
 constexpr size_t POOL_OFFSET_WORDS = 64;      // the pools start on a 256-B boundary after the scalar counters
 
 RT_DEV uint32_t hcap(const PipeDev &pd, int L) { return L == 0 ? pd.cap : 2u * pd.cap; }
@@ -135,6 +138,11 @@ struct rt_pipeline {
     std::vector<uint8_t> ring_nframes; // frames each remembered entry covers (a batch is one entry)
     DevBuf batch_consts;               // per-frame constants and light rays of a batch (rt_pipeline_render_batch)
     int ring_frames = 0;               // 0 = timing off
+    // the shadow rays of the primary hits are traced beside the secondary rays (launch_frame): a second stream and the fork /
+    // join events of that launch
+    int overlap_shadow0 = -1;          // -1: not decided yet (RT_OVERLAP_SHADOW0)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint64_t ring_pos = 0;             // frames recorded since enable / reset
     DevBuf totals, work;
     PipeDev last_pd;

@@ -56,6 +56,10 @@ int rt_pipeline_destroy(rt_pipeline *p)
         for (DevBuf *b : lb) b->release();
     }
     for (hipEvent_t e : p->ring) if (e) (void)hipEventDestroy(e);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+    if (p->side) (void)hipStreamDestroy(p->side);
+    p->ev_fork = p->ev_join = nullptr; p->side = nullptr;
     if (p->scene) rt_scene_destroy(p->scene);
     rt_context *ctx = p->ctx;
     delete p;

@@ -63,6 +63,12 @@ RT_DEV v4f ldg16(const void *base, size_t byte_off)
 #define RT_POOL_GROUPS 32u              // chunk counters per traversal launch (8: 3.08, 32: 3.07, 128: 3.09, 512: 3.12 ms; static: 3.21)
 #endif
 #define RT_POOL_STRIDE 32u              // words between two counters: one 128-B L2 line each
+#ifndef RT_DRAIN_COMPACT
+#define RT_DRAIN_COMPACT 0              // 1: compact the last rays of a workgroup's waves into one wave (see trace_wave; measured slower)
+#endif
+#ifndef RT_COMPACT_LANES
+#define RT_COMPACT_LANES 16             // a wave deposits once its queue is exhausted and at most this many lanes are alive
+#endif
 #ifndef RT_EXIT_K
 #define RT_EXIT_K 1                     // leave the node loop once (lanes still on internal nodes) * K < lanes waiting on a leaf
                                         //   (four-wide nodes, ms per frame 1080p / 10 M triangles 4K: K = 0 3.31 / 21.9, 1 2.80 / 15.5, 2 2.86 / 16.5, 3 2.88 / 16.9)
@@ -79,6 +85,12 @@ __device__ unsigned long long g_trace_sp_hist[64];      // rays by the deepest s
 #else
 #define RT_STAT_WAVE(k) ((void)0)
 #define RT_STAT_LANE(k) ((void)0)
+#endif
+#ifdef RT_TRACE_TIMES      /* instrumentation build only (tools/drain_timeline.py) */
+// per wave of the persistent launch selected by g_trace_sel (0 closest-hit queues, 1 any-hit queues; the last such launch wins):
+// wall clock (100 MHz) at start, when the pool ran dry for it, at exit; + lanes alive when the pool ran dry
+__device__ unsigned long long g_trace_wave_t[4 * 8192];
+__device__ int g_trace_sel;
 #endif
 
 // -DRT_PREFETCH_POP (round 3's experiment for the HBM-bound scene, VERDICT r2 task 4): more misses in flight per lane.  After
@@ -431,17 +443,36 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
             for (uint32_t i = threadIdx.x; i < sc.blas_top_n[k] * RT_TOP_WORDS; i += BLOCK) dst[i] = src_top[(i / RT_TOP_WORDS) * (uint32_t)(sizeof(WNode) / 4) + i % RT_TOP_WORDS];
         }
     }
-    if (sc.top_n != 0 || TWO_LEVEL) __syncthreads();
     const int *top_cur = topl;                    // LDS table of the structure being walked
 #else
-    if (sc.top_n != 0) __syncthreads();
     const int *const top_cur = topl;
 #endif
+    // Drain compaction (round 3).  A persistent launch ends with every wave finishing its last rays at a few lanes each, and
+    // the time of that drain is proportional to the number of resident waves (profiles/r03/drain_vs_occupancy.txt: 45 us per
+    // workgroup per CU on the 1080p secondary stage, a third of the stage): the SIMDs are busy issuing for waves that are
+    // mostly empty.  So once a wave's queue is exhausted and at most RT_COMPACT_LANES of its lanes are alive, it DEPOSITS
+    // those rays -- the walk state goes into the free rows at the top of each ray's own LDS stack column, the column's lane
+    // number into the workgroup's mailbox -- and leaves; the LAST wave of the workgroup to get there adopts all deposited
+    // rays (at most 4 x 16 = 64: one full wave), copies their stack columns into its own lanes and walks them to the end.
+    // No wave waits for another (one LDS atomic each decides who is last), results cannot change (which lane walks a ray
+    // never matters), and the launch drains with a quarter of the waves.
+    int *mail = smem + (STACK + RT_TOP_ROWS(BLOCK)) * BLOCK - RT_MAIL_INTS;      // [0] waves that have joined, [1] rays deposited, [2..] their lanes (bytes)
+    constexpr int NSTATE = ANYHIT ? 4 : 9;                   // rows of walk state: idx, node, sp, (in_blas, instance), t, u, v, prim, inst
+    constexpr bool COMPACT = RT_DRAIN_COMPACT != 0 && !COUNT && BLOCK / 64 <= 4 && STACK >= NSTATE + 4;
+    if (COMPACT && threadIdx.x < RT_MAIL_INTS) mail[threadIdx.x] = 0;
+    if (sc.top_n != 0 || COMPACT) __syncthreads();
+    bool joined = false;
     const int root0 = TWO_LEVEL ? sc.tlas_root_code : in0->root_code;
     uint32_t top_lim = sc.top_n;                  // node indices below this are read from LDS (two-level: 0 while inside a BLAS)
 
     bool alive = false;
     bool exhausted = false;          // wave-uniform: the global pool has nothing left
+#ifdef RT_TRACE_TIMES
+    const bool st_timed = !COUNT && g_trace_sel == (ANYHIT ? 1 : 0) && gridDim.x * (BLOCK / 64) <= 8192u && (threadIdx.x & 63u) == 0u;
+    const uint32_t st_wave = blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
+    if (st_timed) { g_trace_wave_t[4 * st_wave] = wall_clock64(); g_trace_wave_t[4 * st_wave + 1] = 0ull; }
+    bool st_noted = false;
+#endif
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the chunk of the queue being handed out
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
     uint32_t next_chunk = blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;   // wave-uniform
@@ -529,6 +560,100 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 }
             }
             chunk_next += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
+        }
+#ifdef RT_TRACE_TIMES
+        if (exhausted && !st_noted) {
+            st_noted = true;
+            const int na_now = __popcll(__ballot(alive));
+            if (st_timed) { g_trace_wave_t[4 * st_wave + 1] = wall_clock64(); g_trace_wave_t[4 * st_wave + 3] = (unsigned long long)na_now; }
+        }
+#endif
+        if (COMPACT && exhausted && !joined) {
+            const unsigned long long am = __ballot(alive);
+            const int na = __popcll(am);
+            // (the state rows sit above the ray's own entries: every alive lane needs NSTATE free rows)
+#ifdef RT_TRACE_STATS
+            if (na <= RT_COMPACT_LANES && __ballot(alive && sp > STACK - NSTATE) != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&g_trace_sp_hist[63], 1ull);   // waited: a stack too tall
+#endif
+            if (na <= RT_COMPACT_LANES && __ballot(alive && sp > STACK - NSTATE) == 0ull) {
+                joined = true;
+                const uint32_t lane = threadIdx.x & 63u;
+#ifdef RT_TRACE_STATS
+                if (lane == 0u) { atomicAdd(&g_trace_sp_hist[60], 1ull); atomicAdd(&g_trace_sp_hist[61], (unsigned long long)na); }
+#endif
+                uint32_t base = 0;
+                if (na) {
+                    if (lane == (uint32_t)__builtin_ctzll(am)) base = atomicAdd((unsigned int *)&mail[1], (unsigned int)na);
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(am));
+                }
+                if (alive) {
+                    const uint32_t k = base + (uint32_t)__popcll(am & lanemask_lt());
+                    atomicOr((unsigned int *)&mail[2 + (k >> 2)], threadIdx.x << (8u * (k & 3u)));
+                    int *row = st.lds + (STACK - NSTATE) * BLOCK;
+                    row[0 * BLOCK] = (int)idx; row[1 * BLOCK] = node; row[2 * BLOCK] = sp; row[3 * BLOCK] = (int)((in_blas ? 1u : 0u) | (ii << 1));
+                    if (!ANYHIT) {
+                        row[4 * BLOCK] = __float_as_int(best.t); row[5 * BLOCK] = __float_as_int(best.u); row[6 * BLOCK] = __float_as_int(best.v);
+                        row[7 * BLOCK] = (int)best.prim; row[8 * BLOCK] = (int)best.inst;
+                    }
+                    alive = false;
+                }
+                // deposits first, then the count of waves that have joined: the last one finds everything in place
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                uint32_t before = 0;
+                if (lane == 0u) before = atomicAdd((unsigned int *)&mail[0], 1u);
+                before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
+                if (before == (uint32_t)(BLOCK / 64 - 1)) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const uint32_t cnt = (uint32_t)mail[1];
+#ifdef RT_TRACE_STATS
+                    if (lane == 0u && cnt) atomicAdd(&g_trace_sp_hist[62], 1ull);
+#endif
+                    if (lane < cnt) {
+                        const uint32_t d = ((uint32_t)mail[2 + (lane >> 2)] >> (8u * (lane & 3u))) & 0xffu;      // the depositor's lane in the workgroup
+                        const int *col = smem + d;
+                        const int *row = col + (STACK - NSTATE) * BLOCK;
+                        idx = (uint32_t)row[0 * BLOCK]; node = row[1 * BLOCK];
+                        const int sp_d = row[2 * BLOCK];
+                        const uint32_t state = (uint32_t)row[3 * BLOCK];
+                        HitD adopted;
+                        adopted.t = 0.0f; adopted.u = 0.0f; adopted.v = 0.0f; adopted.prim = RT_NO_HIT; adopted.inst = RT_NO_HIT;
+                        if (!ANYHIT) {
+                            adopted.t = __int_as_float(row[4 * BLOCK]); adopted.u = __int_as_float(row[5 * BLOCK]); adopted.v = __int_as_float(row[6 * BLOCK]);
+                            adopted.prim = (uint32_t)row[7 * BLOCK]; adopted.inst = (uint32_t)row[8 * BLOCK];
+                        }
+                        (void)src.load(idx, r);                          // the ray itself comes from where it came from the first time
+                        wri = make_inv(r.o, r.d);
+                        cur.o = r.o; cur.d = r.d; cur.ri = wri;
+                        best = ANYHIT ? make_miss(r) : adopted;
+                        if (TWO_LEVEL) {
+                            in_blas = (state & 1u) != 0u;
+                            ii = state >> 1;
+                            if (in_blas) {
+                                in = sc.inst + ii;
+                                cur = to_object(*in, r);
+                                nodes = in->wide;
+                                tris = in->tris;
+                                top_lim = 0;
+                            } else {
+                                nodes = sc.tlas_wide;
+                                top_lim = sc.top_n;
+                            }
+                        }
+                        sp = sp_d;
+                        alive = true;
+                        // the ray's stack: row by row (every lane reads row k before any lane writes it: a lane's own column may be
+                        // another lane's source)
+                        for (int k = 0; k < STACK - NSTATE; k++) {
+                            int v = 0;
+                            if (k < sp_d) v = col[k * BLOCK];
+                            if (k < sp_d) st.lds[k * BLOCK] = v;
+                        }
+#ifdef RT_PREFETCH_POP
+                        pf.code = RT_NODE_EMPTY;
+#endif
+                    }
+                }
+            }
         }
         if (__ballot(alive) == 0ull) {
             if (exhausted) break;
@@ -653,6 +778,9 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
             }
         }
     }
+#ifdef RT_TRACE_TIMES
+    if (st_timed) g_trace_wave_t[4 * st_wave + 2] = wall_clock64();
+#endif
 #ifdef RT_TRACE_STATS
     for (int k = 0; k < 4; k++) {
         if (st_w[k]) atomicAdd(&g_trace_stats[2 * k], st_w[k]);
