@@ -154,12 +154,9 @@ struct SceneDev {
 // a library built with -DRT_LDS_BLAS_TOPS: in two-level scenes the table holds the top of the TLAS and the tops of the two
 // most-instanced BLASes (rt_trace_wave.h); otherwise the TLAS has all of it
 #define RT_TOP_TLAS (RT_TOP_NODES / 2)
-#define RT_TOP_BLAS (RT_TOP_NODES / 4 - 1)
+#define RT_TOP_BLAS (RT_TOP_NODES / 4)
 #define RT_TOP_ROWS(BLOCK) ((RT_TOP_NODES * RT_TOP_WORDS + (BLOCK) - 1) / (BLOCK))      // LDS rows (of BLOCK ints) the top table takes
-// The last RT_MAIL_INTS ints of the table are the workgroup's "mailbox" of the drain compaction (rt_trace_wave.h): the table
-// itself holds RT_TOP_USABLE nodes
-#define RT_MAIL_INTS 32
-#define RT_TOP_USABLE (RT_TOP_NODES - (RT_MAIL_INTS + RT_TOP_WORDS - 1) / RT_TOP_WORDS)
+
 
 // ---- host objects --------------------------------------------------------------
 
@@ -310,7 +307,7 @@ static inline int rt_scene_dev_for_launch(rt_context *ctx, const rt_scene *s, ui
     *out = s->dev();
     if (ctx->lds_top) {          // one identity instance: rays walk its BLAS directly; otherwise the top of the TLAS
         const BvhDev &bv = s->two_level ? s->tlas : s->inst[0].model->blas;
-        const uint32_t room = s->two_level && (s->lds_blas[0] || s->lds_blas[1]) ? RT_TOP_TLAS : RT_TOP_USABLE;
+        const uint32_t room = s->two_level && (s->lds_blas[0] || s->lds_blas[1]) ? RT_TOP_TLAS : RT_TOP_NODES;
         out->top_n = bv.wide_n < room ? bv.wide_n : room;
         if (s->two_level)
             for (int k = 0; k < 2; k++)

@@ -83,8 +83,11 @@ struct PrimarySink {
     }
 };
 
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU
+#endif
 template <int STACK, bool TWO_LEVEL, bool BATCH>
-__global__ void __launch_bounds__(PBLOCK) k_primary(PipeDev pd)
+__global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_primary(PipeDev pd)
 {
     __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     // the frame's counters and chunk pools start at zero: its first kernel clears them (nothing here uses them, every later
@@ -348,7 +351,7 @@ struct ShadowSinkN {      // ShadowMiss sets visibility 1 (ProgressiveRaytracing
 };
 
 template <int STACK, bool TWO_LEVEL, bool BATCH>
-__global__ void __launch_bounds__(PBLOCK) k_trace_shadow(SceneDev sc, ShadowQueues queues, uint32_t *pool, uint32_t *stat)
+__global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_trace_shadow(SceneDev sc, ShadowQueues queues, uint32_t *pool, uint32_t *stat)
 {
     __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     ShadowSrcN<BATCH> src;
@@ -358,7 +361,7 @@ __global__ void __launch_bounds__(PBLOCK) k_trace_shadow(SceneDev sc, ShadowQueu
 }
 
 template <int STACK, bool TWO_LEVEL>
-__global__ void __launch_bounds__(PBLOCK) k_trace_secondary(SceneDev sc, QueueSrc src, float4 *hit1, uint32_t *inst1, uint32_t *pool, uint32_t *stat)
+__global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_trace_secondary(SceneDev sc, QueueSrc src, float4 *hit1, uint32_t *inst1, uint32_t *pool, uint32_t *stat)
 {
     __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     SecondarySink sink = {src, hit1, inst1};

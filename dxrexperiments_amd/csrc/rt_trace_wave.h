@@ -63,11 +63,12 @@ RT_DEV v4f ldg16(const void *base, size_t byte_off)
 #define RT_POOL_GROUPS 32u              // chunk counters per traversal launch (8: 3.08, 32: 3.07, 128: 3.09, 512: 3.12 ms; static: 3.21)
 #endif
 #define RT_POOL_STRIDE 32u              // words between two counters: one 128-B L2 line each
-#ifndef RT_DRAIN_COMPACT
-#define RT_DRAIN_COMPACT 0              // 1: compact the last rays of a workgroup's waves into one wave (see trace_wave; measured slower)
+#ifndef RT_DRAIN_SPLIT
+#define RT_DRAIN_SPLIT 0                // 1: once a wave's queue is dry, its idle lanes take pending subtrees off the busy lanes' stacks (see trace_wave;
+                                        //    round 3's experiment, bit-exact and measured slower: profiles/r03/drain_experiments.md)
 #endif
-#ifndef RT_COMPACT_LANES
-#define RT_COMPACT_LANES 16             // a wave deposits once its queue is exhausted and at most this many lanes are alive
+#ifndef RT_SPLIT_MIN_IDLE
+#define RT_SPLIT_MIN_IDLE 4             // ... when at least this many lanes are idle
 #endif
 #ifndef RT_EXIT_K
 #define RT_EXIT_K 1                     // leave the node loop once (lanes still on internal nodes) * K < lanes waiting on a leaf
@@ -447,26 +448,21 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 #else
     const int *const top_cur = topl;
 #endif
-    // Drain compaction (round 3).  A persistent launch ends with every wave finishing its last rays at a few lanes each, and
-    // the time of that drain is proportional to the number of resident waves (profiles/r03/drain_vs_occupancy.txt: 45 us per
-    // workgroup per CU on the 1080p secondary stage, a third of the stage): the SIMDs are busy issuing for waves that are
-    // mostly empty.  So once a wave's queue is exhausted and at most RT_COMPACT_LANES of its lanes are alive, it DEPOSITS
-    // those rays -- the walk state goes into the free rows at the top of each ray's own LDS stack column, the column's lane
-    // number into the workgroup's mailbox -- and leaves; the LAST wave of the workgroup to get there adopts all deposited
-    // rays (at most 4 x 16 = 64: one full wave), copies their stack columns into its own lanes and walks them to the end.
-    // No wave waits for another (one LDS atomic each decides who is last), results cannot change (which lane walks a ray
-    // never matters), and the launch drains with a quarter of the waves.
-    int *mail = smem + (STACK + RT_TOP_ROWS(BLOCK)) * BLOCK - RT_MAIL_INTS;      // [0] waves that have joined, [1] rays deposited, [2..] their lanes (bytes)
-    constexpr int NSTATE = ANYHIT ? 4 : 9;                   // rows of walk state: idx, node, sp, (in_blas, instance), t, u, v, prim, inst
-    constexpr bool COMPACT = RT_DRAIN_COMPACT != 0 && !COUNT && BLOCK / 64 <= 4 && STACK >= NSTATE + 4;
-    if (COMPACT && threadIdx.x < RT_MAIL_INTS) mail[threadIdx.x] = 0;
-    if (sc.top_n != 0 || COMPACT) __syncthreads();
-    bool joined = false;
+    if (sc.top_n != 0) __syncthreads();
     const int root0 = TWO_LEVEL ? sc.tlas_root_code : in0->root_code;
     uint32_t top_lim = sc.top_n;                  // node indices below this are read from LDS (two-level: 0 while inside a BLAS)
 
     bool alive = false;
     bool exhausted = false;          // wave-uniform: the global pool has nothing left
+    // the drain's ray splitting (see the loop): what this lane is to the ray it holds
+    constexpr bool SPLIT = RT_DRAIN_SPLIT != 0 && !COUNT;
+    constexpr uint32_t META_HOME = 63u;             // thief: the lane that stores the ray
+    constexpr uint32_t META_THIEF = 64u;            // this lane walks a part of another lane's ray
+    constexpr uint32_t META_PARKED = 128u;          // own part done, parts handed out still on their way
+    constexpr uint32_t META_FOUND = 256u;           // any-hit rays: a part has found a hit
+    constexpr uint32_t META_PEND1 = 1u << 16, META_PEND = 0xffu << 16;     // parts handed out and not yet back
+    uint32_t meta = 0u;
+    const bool may_split = ANYHIT || !first;        // an ordered first-hit search depends on the order of the walk
 #ifdef RT_TRACE_TIMES
     const bool st_timed = !COUNT && g_trace_sel == (ANYHIT ? 1 : 0) && gridDim.x * (BLOCK / 64) <= 8192u && (threadIdx.x & 63u) == 0u;
     const uint32_t st_wave = blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
@@ -568,95 +564,131 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
             if (st_timed) { g_trace_wave_t[4 * st_wave + 1] = wall_clock64(); g_trace_wave_t[4 * st_wave + 3] = (unsigned long long)na_now; }
         }
 #endif
-        if (COMPACT && exhausted && !joined) {
-            const unsigned long long am = __ballot(alive);
-            const int na = __popcll(am);
-            // (the state rows sit above the ray's own entries: every alive lane needs NSTATE free rows)
-#ifdef RT_TRACE_STATS
-            if (na <= RT_COMPACT_LANES && __ballot(alive && sp > STACK - NSTATE) != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&g_trace_sp_hist[63], 1ull);   // waited: a stack too tall
-#endif
-            if (na <= RT_COMPACT_LANES && __ballot(alive && sp > STACK - NSTATE) == 0ull) {
-                joined = true;
-                const uint32_t lane = threadIdx.x & 63u;
-#ifdef RT_TRACE_STATS
-                if (lane == 0u) { atomicAdd(&g_trace_sp_hist[60], 1ull); atomicAdd(&g_trace_sp_hist[61], (unsigned long long)na); }
-#endif
-                uint32_t base = 0;
-                if (na) {
-                    if (lane == (uint32_t)__builtin_ctzll(am)) base = atomicAdd((unsigned int *)&mail[1], (unsigned int)na);
-                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(am));
-                }
-                if (alive) {
-                    const uint32_t k = base + (uint32_t)__popcll(am & lanemask_lt());
-                    atomicOr((unsigned int *)&mail[2 + (k >> 2)], threadIdx.x << (8u * (k & 3u)));
-                    int *row = st.lds + (STACK - NSTATE) * BLOCK;
-                    row[0 * BLOCK] = (int)idx; row[1 * BLOCK] = node; row[2 * BLOCK] = sp; row[3 * BLOCK] = (int)((in_blas ? 1u : 0u) | (ii << 1));
-                    if (!ANYHIT) {
-                        row[4 * BLOCK] = __float_as_int(best.t); row[5 * BLOCK] = __float_as_int(best.u); row[6 * BLOCK] = __float_as_int(best.v);
-                        row[7 * BLOCK] = (int)best.prim; row[8 * BLOCK] = (int)best.inst;
+        // ---- the drain: split the rays that are left over the lanes that are free (-DRT_DRAIN_SPLIT=1, off by default) ----
+        // Once the queue is dry a wave only finishes the rays it holds, and how long that takes is set by its LONGEST ray
+        // while more and more lanes sit idle: a third of a persistent launch at 1080p passes this way
+        // (profiles/r03/drain_timeline.txt).  A walk is not one chain, though: every entry on a ray's stack is a subtree that
+        // can be walked by itself.  So idle lanes (THIEVES) take the top stack entry of busy ones: a thief copies the ray and
+        // its running best from the victim lane, walks that one subtree with a stack of its own, and hands what it found to
+        // the ray's HOME lane (the lane that loaded the ray), which merges it with hit_better -- the same total order every
+        // candidate goes through anyway, so the result is the one any order of the walk gives (rt_trace_device.h) -- and
+        // stores the ray when its own part and all handed-out parts are done.  Everything stays inside the wave: lanes
+        // exchange registers (ds_bpermute / readlane), no memory, no waiting.  Unordered any-hit rays hand over one bit;
+        // ordered first-hit rays (whose result depends on the order) are never split.
+        if (SPLIT && exhausted && may_split) {
+            const uint32_t lane = threadIdx.x & 63u;
+            // 1. parts that have finished: hand the result to the home lane
+            unsigned long long fin = __ballot((meta & META_THIEF) != 0u && !alive);
+            while (fin) {
+                const int t = __builtin_ctzll(fin);
+                fin &= fin - 1ull;
+                const uint32_t mt = (uint32_t)__builtin_amdgcn_readlane((int)meta, t);
+                const uint32_t h = mt & META_HOME;
+                if (ANYHIT) {
+                    if (lane == h) {
+                        meta = (meta - META_PEND1) | (mt & META_FOUND);
+                        if ((mt & META_FOUND) != 0u && alive) { node = RT_NODE_EMPTY; sp = 0; }      // one hit is all an any-hit ray asks for
                     }
-                    alive = false;
+                } else {
+                    const float bt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best.t), t));
+                    const float bu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best.u), t));
+                    const float bv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best.v), t));
+                    const uint32_t bp = (uint32_t)__builtin_amdgcn_readlane((int)best.prim, t);
+                    const uint32_t bi = (uint32_t)__builtin_amdgcn_readlane((int)best.inst, t);
+                    if (lane == h) {
+                        meta -= META_PEND1;
+                        if (bi != RT_NO_HIT && hit_better(bt, bi, bp, best)) { best.t = bt; best.u = bu; best.v = bv; best.prim = bp; best.inst = bi; }
+                    }
                 }
-                // deposits first, then the count of waves that have joined: the last one finds everything in place
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                uint32_t before = 0;
-                if (lane == 0u) before = atomicAdd((unsigned int *)&mail[0], 1u);
-                before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
-                if (before == (uint32_t)(BLOCK / 64 - 1)) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    const uint32_t cnt = (uint32_t)mail[1];
-#ifdef RT_TRACE_STATS
-                    if (lane == 0u && cnt) atomicAdd(&g_trace_sp_hist[62], 1ull);
-#endif
-                    if (lane < cnt) {
-                        const uint32_t d = ((uint32_t)mail[2 + (lane >> 2)] >> (8u * (lane & 3u))) & 0xffu;      // the depositor's lane in the workgroup
-                        const int *col = smem + d;
-                        const int *row = col + (STACK - NSTATE) * BLOCK;
-                        idx = (uint32_t)row[0 * BLOCK]; node = row[1 * BLOCK];
-                        const int sp_d = row[2 * BLOCK];
-                        const uint32_t state = (uint32_t)row[3 * BLOCK];
-                        HitD adopted;
-                        adopted.t = 0.0f; adopted.u = 0.0f; adopted.v = 0.0f; adopted.prim = RT_NO_HIT; adopted.inst = RT_NO_HIT;
-                        if (!ANYHIT) {
-                            adopted.t = __int_as_float(row[4 * BLOCK]); adopted.u = __int_as_float(row[5 * BLOCK]); adopted.v = __int_as_float(row[6 * BLOCK]);
-                            adopted.prim = (uint32_t)row[7 * BLOCK]; adopted.inst = (uint32_t)row[8 * BLOCK];
+            }
+            if ((meta & META_THIEF) != 0u && !alive) meta = 0u;
+            // 2. rays whose own part and all handed-out parts are done
+            if ((meta & META_PARKED) != 0u && (meta & META_PEND) == 0u) {
+                if (ANYHIT) {
+                    HitD res = make_miss(r);
+                    if ((meta & META_FOUND) != 0u) { res.t = r.tmin; res.prim = 0u; res.inst = 0u; }     // (any-hit sinks only ask whether inst is RT_NO_HIT)
+                    sink.store(idx, res, true);
+                } else sink.store(idx, best, true);
+                meta = 0u;
+            }
+            // 3. idle lanes take the top stack entry of busy ones
+            const unsigned long long free_lanes = __ballot(!alive && meta == 0u);
+            const int n_free = __popcll(free_lanes);
+            if (n_free >= RT_SPLIT_MIN_IDLE) {
+                const int top_row = sp > 0 ? sp - 1 : 0;
+                const int top_entry = st.read(top_row);
+                const bool can_give = alive && sp >= 1 && !(TWO_LEVEL && (top_entry == RT_NODE_SENTINEL || node == RT_NODE_SENTINEL));    // (a lane about to leave its BLAS: the entries below the sentinel belong to the TLAS)
+                unsigned long long victims = __ballot(can_give && sp >= 2);
+                if (victims == 0ull) victims = __ballot(can_give);
+                const int n_victims = __popcll(victims);
+                const int n_pairs = n_free < n_victims ? n_free : n_victims;
+                if (n_pairs > 0) {
+                    const int my_free_rank = __popcll(free_lanes & lanemask_lt());
+                    const bool thief = !alive && meta == 0u && my_free_rank < n_pairs;
+                    const bool gives = (victims >> lane) & 1ull ? __popcll(victims & lanemask_lt()) < n_pairs : false;
+                    // the lane this thief takes from: the victim of its rank
+                    int from = 0;
+                    {
+                        int k = thief ? my_free_rank : 0;
+#pragma unroll
+                        for (int w = 32; w >= 1; w >>= 1) {
+                            const int c = __popcll((victims >> from) & ((1ull << w) - 1ull));
+                            if (k >= c) { k -= c; from += w; }
                         }
-                        (void)src.load(idx, r);                          // the ray itself comes from where it came from the first time
-                        wri = make_inv(r.o, r.d);
-                        cur.o = r.o; cur.d = r.d; cur.ri = wri;
-                        best = ANYHIT ? make_miss(r) : adopted;
-                        if (TWO_LEVEL) {
+                    }
+                    const int sel = from << 2;                                     // ds_bpermute addresses bytes
+                    // (each value goes straight into the thief's own register: nothing else stays live across the exchange)
+#define RT_TAKE_F(x) { const float pulled_ = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(x))); x = thief ? pulled_ : x; }
+#define RT_TAKE_U(x) { const uint32_t pulled_ = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)(x)); x = thief ? pulled_ : x; }
+                    const int p_entry = __builtin_amdgcn_ds_bpermute(sel, top_entry);
+                    const uint32_t p_meta = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)meta);
+                    RT_TAKE_F(r.o.x) RT_TAKE_F(r.o.y) RT_TAKE_F(r.o.z) RT_TAKE_F(r.d.x) RT_TAKE_F(r.d.y) RT_TAKE_F(r.d.z)
+                    RT_TAKE_F(r.tmin) RT_TAKE_F(r.tmax)
+                    RT_TAKE_F(wri.inv.x) RT_TAKE_F(wri.inv.y) RT_TAKE_F(wri.inv.z)
+                    if (!ANYHIT) { RT_TAKE_F(best.t) RT_TAKE_F(best.u) RT_TAKE_F(best.v) RT_TAKE_U(best.prim) RT_TAKE_U(best.inst) }
+                    if (TWO_LEVEL) {
+                        uint32_t state = (in_blas ? 1u : 0u) | (ii << 1);
+                        RT_TAKE_U(state)
+                        RT_TAKE_F(cur.o.x) RT_TAKE_F(cur.o.y) RT_TAKE_F(cur.o.z) RT_TAKE_F(cur.d.x) RT_TAKE_F(cur.d.y) RT_TAKE_F(cur.d.z)
+                        RT_TAKE_F(cur.ri.inv.x) RT_TAKE_F(cur.ri.inv.y) RT_TAKE_F(cur.ri.inv.z)
+                        if (thief) {
                             in_blas = (state & 1u) != 0u;
                             ii = state >> 1;
-                            if (in_blas) {
-                                in = sc.inst + ii;
-                                cur = to_object(*in, r);
-                                nodes = in->wide;
-                                tris = in->tris;
-                                top_lim = 0;
-                            } else {
-                                nodes = sc.tlas_wide;
-                                top_lim = sc.top_n;
-                            }
+                            cur.ri.o = cur.o;
+                            if (in_blas) { in = sc.inst + ii; nodes = in->wide; tris = in->tris; top_lim = 0; }
+                            else { nodes = sc.tlas_wide; top_lim = sc.top_n; }
                         }
-                        sp = sp_d;
+                    }
+#undef RT_TAKE_F
+#undef RT_TAKE_U
+                    if (gives) sp--;
+                    // (for every lane, not only the thieves: these are copies of one another throughout the loop, and saying so in
+                    // the same form everywhere lets the compiler keep them in one set of registers)
+                    wri.o = r.o;
+                    if (!TWO_LEVEL) { cur.o = r.o; cur.d = r.d; cur.ri = wri; }
+                    if (thief) {
+                        node = p_entry;
+                        sp = 0;
                         alive = true;
-                        // the ray's stack: row by row (every lane reads row k before any lane writes it: a lane's own column may be
-                        // another lane's source)
-                        for (int k = 0; k < STACK - NSTATE; k++) {
-                            int v = 0;
-                            if (k < sp_d) v = col[k * BLOCK];
-                            if (k < sp_d) st.lds[k * BLOCK] = v;
-                        }
+                        // home: the victim's home if the victim is itself walking a part, else the victim
+                        meta = META_THIEF | ((p_meta & META_THIEF) != 0u ? (p_meta & META_HOME) : (uint32_t)from);
 #ifdef RT_PREFETCH_POP
                         pf.code = RT_NODE_EMPTY;
 #endif
+                    }
+                    // every home counts the parts it now waits for
+                    unsigned long long fresh = __ballot(thief);
+                    while (fresh) {
+                        const int t = __builtin_ctzll(fresh);
+                        fresh &= fresh - 1ull;
+                        const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)meta, t) & META_HOME;
+                        if (lane == h) meta += META_PEND1;
                     }
                 }
             }
         }
         if (__ballot(alive) == 0ull) {
-            if (exhausted) break;
+            if (exhausted && (!SPLIT || __ballot(meta != 0u) == 0ull)) break;
             continue;
         }
 
@@ -705,7 +737,9 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 atomicAdd(&g_trace_sp_hist[st_maxsp < 63 ? st_maxsp : 63], 1ull);
                 st_maxsp = 0;
 #endif
-                sink.store(idx, ANYHIT ? make_miss(r) : best, true);
+                if (SPLIT && meta != 0u) {             // a split ray (see the drain): a part goes to the home lane, the home waits for its parts
+                    if ((meta & META_THIEF) == 0u) meta |= META_PARKED;
+                } else sink.store(idx, ANYHIT ? make_miss(r) : best, true);
                 alive = false;
                 pop = false;
                 if (COUNT) { const unsigned long long w = ((unsigned long long)(wk_glob + wk_top - wk_ray0) << 32) | idx; wk_longest = w > wk_longest ? w : wk_longest; }
@@ -764,7 +798,8 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     const bool accepted = accept_candidate(*in, ii, prim, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), r, wri, cur, cull, found);
                     if (!ANYHIT) best = found;
                     if (accepted && first) {
-                        sink.store(idx, found, true);
+                        if (SPLIT && meta != 0u) meta |= (meta & META_THIEF) != 0u ? META_FOUND : META_FOUND | META_PARKED;
+                        else sink.store(idx, found, true);
                         alive = false;
                         pop = false;
                         if (COUNT) { const unsigned long long w = ((unsigned long long)(wk_glob + wk_top - wk_ray0) << 32) | idx; wk_longest = w > wk_longest ? w : wk_longest; }
