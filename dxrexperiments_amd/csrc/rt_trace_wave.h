@@ -516,6 +516,8 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     uint32_t k = 0;
                     if ((threadIdx.x & 63u) == 0u) k = atomicAdd(&pool[pool_group * RT_POOL_STRIDE], 1u);
                     k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+                    // (contiguous bands of the queue per group, so that an XCD's L2 sees four parts of the image instead of all
+                    // of it, with dry groups moving on to their neighbours' bands: 2.63 vs 2.56 ms, profiles/r03/pool_contiguous.txt)
                     cidx = pool_group + k * n_groups;
                 } else {
                     cidx = next_chunk;           // static: wave w of W owns chunks w, w+W, w+2W, ...
