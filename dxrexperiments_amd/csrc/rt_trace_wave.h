@@ -75,8 +75,10 @@ RT_DEV v4f ldg16(const void *base, size_t byte_off)
                                         //   (four-wide nodes, ms per frame 1080p / 10 M triangles 4K: K = 0 3.31 / 21.9, 1 2.80 / 15.5, 2 2.86 / 16.5, 3 2.88 / 16.9)
 #endif
 
-// (Packed fp32 -- v_pk_add_f32 / v_pk_mul_f32 on the (lo, hi) plane pairs -- was measured and is no faster
-// on gfx950: a packed op issues in twice the time of a scalar one, tools/microbench/valu_rate.hip.)
+// (Packed fp32: v_pk_add_f32 / v_pk_mul_f32 issue in twice the time of the scalar forms, so packing (lo, hi) plane pairs buys
+// nothing there; v_pk_fma_f32 does issue two fmas in the 4 cycles one v_fma_f32 takes (profiles/r03/valu_rate.txt), but the
+// step with its 24 plane fmas as 12 packed ones measured 2 % SLOWER (profiles/r03/pk_fma.txt): what the step waits for is
+// its own dependent chain, not issue slots.)
 
 #ifdef RT_TRACE_STATS      /* instrumentation build only (tools/trace_stats.py): SIMD-utilisation counters */
 __device__ unsigned long long g_trace_stats[8];
