@@ -36,7 +36,17 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, ch
 L2_REQUEST_PEAK_PER_S = 120.6e9
 GATHER_PEAK_GBS = L2_REQUEST_PEAK_PER_S * 64 / 1e9
 N_CU, N_SIMD, N_XCD = 256, 1024, 8
-VALU_ISSUE_CYCLES = 2.0        # a wave64 VALU instruction occupies a SIMD-32 for 2 cycles (MI355X_MICROARCH.md, "Wave scheduling")
+VALU_ISSUE_CYCLES = 2.0        # a wave64 VALU instruction occupies a SIMD-32 for 2 cycles (MI355X_MICROARCH.md, "Wave scheduling") -- the nominal figure
+# ... which only v_add / v_sub / v_mul / v_mov and the simple integer forms reach: measured with eight waves per SIMD issuing
+# independent instructions (tools/microbench/valu_rate under rocprofv3, cycles = GRBM_GUI_ACTIVE / 8: profiles/r03/valu_rate_pmc.md),
+# v_fma_f32, v_min / v_max and their three-operand forms, v_cmp, v_cndmask, v_cvt_f32_ubyte, v_lshl_or take 4 cycles (the
+# packed f32 forms 4 for two operations), the transcendental unit 8 (guide).  The traversal step is mostly made of those, so
+# the issue ceiling of a kernel is N_SIMD x clock / (the mean cost of ITS instructions), from the SQ_INSTS_VALU_* class counters.
+# INT32 is a mix of 2- and 4-cycle forms and is priced at 2 (a lower bound: the fraction reported cannot overstate);
+# "other" = everything the class counters do not name: min / max / med3 / cmp / cndmask (4) and a few moves.
+VALU_CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.0, "SQ_INSTS_VALU_MUL_F32": 2.0, "SQ_INSTS_VALU_FMA_F32": 4.0, "SQ_INSTS_VALU_CVT": 4.0,
+                     "SQ_INSTS_VALU_INT32": 2.0, "SQ_INSTS_VALU_TRANS_F32": 8.0}
+VALU_OTHER_CYCLES = 4.0
 LINE_BYTES = 64
 RAY_BYTES, NODE_BYTES, TRI_BYTES = 48, 32, 36   # 32 B ray in + 16 B hit out; node; triangle
 # what the production kernels request per unit (DESIGN.md sections 3 / 4): one 64-B node per step that is not served by the
@@ -59,6 +69,8 @@ def parse(argv=None):
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget (rank 0, N=1 only); 0 = skip")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-sample-batches", action="store_true", help="skip the sample_batches section (profiling passes: keeps the per-kernel "
+                    "averages to single-frame launches)")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not re-run a few frames under rocprofv3 for roofline.traffic; use the "
                     "committed profiles/<round>/traffic.json only")
     ap.add_argument("--hbm-frames", type=int, default=8, help="frames of the HBM-bound 10 M-triangle 4K workload timed for roofline_hbm "
@@ -178,10 +190,12 @@ LIVE_PMC_PASSES = {"ea": ["TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC
                    # round 3: what the SIMDs issue and where the waves' cycles go (SQ; GRBM_GUI_ACTIVE has slots of its own), and what
                    # the lanes ask of the L1 and the L1 of the L2 (TCP)
                    "sq": ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"],
-                   "tcp": ["TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"]}
+                   "tcp": ["TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"],
+                   # the vector instructions by class (SQ_INSTS_VALU_MIX is SQ_INSTS_VALU of the same pass: shares are taken within one pass)
+                   "mix": ["SQ_INSTS_VALU"] + sorted(VALU_CLASS_CYCLES)}
 
 
-def live_traffic(workload, width, height, budget_s=90.0, passes=("ea", "write", "sq", "tcp")):
+def live_traffic(workload, width, height, budget_s=110.0, passes=("ea", "write", "sq", "tcp", "mix")):
     """Memory-side bytes per launch of the traversal kernels, measured IN THIS RUN: bench.py re-runs itself for a few frames
     as a child of `rocprofv3 --kernel-trace --pmc ...`, one pass for the L2's read requests by size (32 / 64 / 128 B: the
     calibrated byte count for this access shape, MI355X_MICROARCH.md HBM section) and one for WRITE_SIZE (they do not fit one
@@ -196,7 +210,7 @@ def live_traffic(workload, width, height, budget_s=90.0, passes=("ea", "write", 
         return {}
     here = os.path.dirname(os.path.abspath(__file__))
     child = [os.path.join(here, "bench.py"), "--cpu-seconds", "0", "--no-roofline", "--no-live-pmc"]
-    child += (["--steps", "3", "--warmup", "1", "--hbm-frames", "0", "--width", str(width), "--height", str(height)] if workload == "c2"
+    child += (["--steps", "8", "--warmup", "2", "--hbm-frames", "0", "--width", str(width), "--height", str(height)] if workload == "c2"
               else ["--workload", "c5", "--hbm-frames", "2"])
     out, t0 = {}, time.perf_counter()
     env = dict(os.environ, TMPDIR="/tmp")
@@ -225,7 +239,7 @@ def live_traffic(workload, width, height, budget_s=90.0, passes=("ea", "write", 
                         a[0] += 1
                         a[1] += float(row["Counter_Value"])
             for (k, c), (n, v) in acc.items():
-                out.setdefault(k, {})[c] = v / n
+                out.setdefault(k, {})["SQ_INSTS_VALU_MIX" if name == "mix" and c == "SQ_INSTS_VALU" else c] = v / n
                 out[k]["dispatches"] = n
             if name == "sq":                 # the same pass's launch durations: with GRBM_GUI_ACTIVE they give the clock under this load
                 dur = {}
@@ -648,15 +662,27 @@ def main():
                   "traffic": lv.get("bytes_per_launch", prof.get("bytes_per_launch")),
                   "traffic_source": ("this run: %d launches under rocprofv3 --pmc (read requests by size, WRITE_SIZE)" % lv["dispatches"])
                                     if "bytes_per_launch" in lv else "committed profile",
-                  "counters_source": ("this run (rocprofv3 --pmc child passes: %s)" % ", ".join(sorted(k for k in ("sq", "tcp") if any(c in lv for c in LIVE_PMC_PASSES[k]))))
+                  "counters_source": ("this run (rocprofv3 --pmc child passes: %s)" % ", ".join(sorted(k for k in ("sq", "tcp", "mix") if any(c in lv for c in LIVE_PMC_PASSES[k][1:] or LIVE_PMC_PASSES[k]))))
                                      if any(c in lv for c in LIVE_PMC_PASSES["sq"]) else "committed profile %s" % committed_profile("c2").get("source"),
                   "traffic_fallback": LIVE_PMC_NOTES or None,
                   "avg_launch_ms": d["avg_ms"], "launches_timed": n_t}
             if have_sq:
                 clk_hz = pm["GRBM_GUI_ACTIVE"] / N_XCD / ((pm.get("sq_pass_avg_us") or pm["avg_us"]) * 1e-6)
                 rl["achieved"] = pm["SQ_INSTS_VALU"] / (d["avg_ms"] * 1e-3) / 1e9
-                rl["peak"] = N_SIMD * clk_hz / VALU_ISSUE_CYCLES / 1e9
+                # the mean issue cost of this kernel's own instructions (class counters of one pass x the measured cycles per class)
+                cost, tot = VALU_ISSUE_CYCLES, pm.get("SQ_INSTS_VALU_MIX")
+                if tot and all(c in pm for c in VALU_CLASS_CYCLES):
+                    named = sum(pm[c] for c in VALU_CLASS_CYCLES)
+                    cost = (sum(pm[c] * cy for c, cy in VALU_CLASS_CYCLES.items()) + max(tot - named, 0.0) * VALU_OTHER_CYCLES) / tot
+                    rl["issue_cost"] = {"cycles_per_instruction": cost,
+                                        "class_shares": dict({c[len("SQ_INSTS_VALU_"):]: pm[c] / tot for c in sorted(VALU_CLASS_CYCLES)}, other=max(tot - named, 0.0) / tot),
+                                        "class_cycles": dict({c[len("SQ_INSTS_VALU_"):]: cy for c, cy in sorted(VALU_CLASS_CYCLES.items())}, other=VALU_OTHER_CYCLES),
+                                        "calibration": "profiles/r03/valu_rate_pmc.md"}
+                else:
+                    rl["issue_cost"] = {"cycles_per_instruction": cost, "note": "no class counters: the nominal SIMD-32 figure"}
+                rl["peak"] = N_SIMD * clk_hz / cost / 1e9
                 rl["frac"] = rl["achieved"] / rl["peak"]
+                rl["frac_at_2_cycles_per_instruction"] = rl["achieved"] / (N_SIMD * clk_hz / VALU_ISSUE_CYCLES / 1e9)
                 rl["clock_GHz_under_load"] = clk_hz / 1e9
                 wc = pm["SQ_WAVE_CYCLES"]
                 rl["wave_cycles"] = {"parked_on_waitcnt": pm.get("SQ_WAIT_ANY", 0.0) / wc, "issue_stalled": pm.get("SQ_WAIT_INST_ANY", 0.0) / wc,
@@ -676,8 +702,12 @@ def main():
                 mp["l1_tag_accesses_per_launch"] = pm["TCP_TOTAL_CACHE_ACCESSES_sum"]
                 mp["l1_tag_rate_frac"] = pm["TCP_TOTAL_CACHE_ACCESSES_sum"] / (d["avg_ms"] * 1e-3) / (N_CU * clk_hz)
             rl["memory_path"] = mp
-            rl["definition"] = ("frac = SQ_INSTS_VALU per launch / HIP-event launch duration / (1024 SIMDs x clock / 2 cycles per wave64 VALU "
-                                "instruction on a SIMD-32); clock = GRBM_GUI_ACTIVE / 8 / launch duration in the counter pass.  memory_path: "
+            rl["definition"] = ("frac = the share of the launch's SIMD cycles in which a vector pipe was taken: SQ_INSTS_VALU per launch / HIP-event "
+                                "launch duration / (1024 SIMDs x clock / issue_cost.cycles_per_instruction), the cost being the kernel's own "
+                                "instruction classes (SQ_INSTS_VALU_* of one pass) x the cycles each class takes on a SIMD with eight waves issuing "
+                                "(tools/microbench/valu_rate under rocprofv3: add / sub / mul / mov 2, fma / min / max / cmp / cndmask / cvt 4, "
+                                "transcendental 8; INT32 priced at 2, a lower bound); frac_at_2_cycles_per_instruction is the same against the nominal "
+                                "SIMD-32 figure; clock = GRBM_GUI_ACTIVE / 8 / launch duration in the counter pass.  memory_path: "
                                 "TCP_TCC_READ_REQ (one per 64-B line gathered: calibrated on tools/microbench/slab_fetch, profiles/r03/"
                                 "slab_131072_tcp.md) against the 120.6 G requests/s the chip sustains for this access shape; "
                                 "TCP_TOTAL_CACHE_ACCESSES against one per clock per CU; hbm_frac = traffic / duration / 8 TB/s.  "
@@ -689,14 +719,15 @@ def main():
                                      "over_hbm_peak": d["canonical"]["GBps"] / HBM_PEAK_GBS}
             rl["pmc"] = {k: pm.get(k) for k in ("TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
                                                 "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "TCP_TCC_READ_REQ_sum",
-                                                "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_LATENCY_sum", "TCP_PENDING_STALL_CYCLES_sum") if k in pm}
+                                                "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_LATENCY_sum", "TCP_PENDING_STALL_CYCLES_sum", "SQ_INSTS_VALU_MIX")
+                         + tuple(sorted(VALU_CLASS_CYCLES)) if k in pm}
             rl["pmc_source"] = committed_profile("c2").get("source")
             rl["pmc_commit"] = committed_profile("c2").get("commit")
             out["roofline"] = rl
             tb = sum(stages[s]["gathered_bytes"] for s in TRACE_STAGES)
             out["roofline"]["all_stages_GBps_over_step"] = tb / (out["ms_per_step"] * 1e-3) / 1e9
             out["stages"] = stages
-        if world == 1 and not args.no_roofline and S == 1:
+        if world == 1 and not args.no_roofline and not args.no_sample_batches and S == 1:
             # the same K frames again, eight per set of launches (rt_pipeline_render_batch: BASELINE configs[2]'s sample batches):
             # the persistent traversal stages and their tails are paid once per batch, the image is the same bit for bit
             SB = 8

@@ -13,7 +13,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for w in $WL; do
   PROG=$R/bench.py
-  if [ $w = c2 ]; then ARGS="--steps 8 --warmup 2 --cpu-seconds 0 --hbm-frames 0 --no-live-pmc";
+  if [ $w = c2 ]; then ARGS="--steps 8 --warmup 2 --cpu-seconds 0 --hbm-frames 0 --no-live-pmc --no-sample-batches";
   elif [ $w = c2b ]; then ARGS="--steps 16 --warmup 8 --batch 8 --cpu-seconds 0 --hbm-frames 0 --no-live-pmc";       # sample batches: 8 frames per launch set
   elif [ $w = c5 ]; then ARGS="--workload c5 --hbm-frames 4 --no-live-pmc";
   elif [ $w = c5b ]; then ARGS="--workload c5 --hbm-frames 8 --batch 8 --no-live-pmc";
@@ -27,7 +27,7 @@ for w in $WL; do
   }
   want() { [ -z "$PASSES" ] || echo " $PASSES " | grep -q " $1 "; }
   want kt && run kt --kernel-trace --stats
-  [ -n "$PASSES" ] && { want ea && run ea --kernel-trace --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_sum; want write && run write --kernel-trace --pmc WRITE_SIZE; want sq && run sq --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU; want fetch && run fetch --kernel-trace --pmc FETCH_SIZE; continue; }
+  [ -n "$PASSES" ] && { want ea && run ea --kernel-trace --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_sum; want write && run write --kernel-trace --pmc WRITE_SIZE; want sq && run sq --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU; want fetch && run fetch --kernel-trace --pmc FETCH_SIZE; want mix && run mix --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_TRANS_F32 GRBM_GUI_ACTIVE; want mix2 && run mix2 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE; continue; }
   run fetch --kernel-trace --pmc FETCH_SIZE
   run write --kernel-trace --pmc WRITE_SIZE
   run tcc --kernel-trace --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
@@ -38,6 +38,10 @@ for w in $WL; do
   run tcp --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum
   # (the TA set -- TA_TA_BUSY_sum TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum -- aborts rocprofv3 7.2 on
   # this image with signal 6 and is not collected)
+  # the vector instructions by class (round 3): with the per-instruction issue costs of tools/microbench/valu_rate they give the
+  # cycles the SIMDs' vector pipes were actually taken
+  run mix --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_TRANS_F32 GRBM_GUI_ACTIVE
+  run mix2 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE
   run ta2 --kernel-trace --pmc TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum GRBM_GUI_ACTIVE
 done
 if [ -n "$CALIBRATE" ]; then

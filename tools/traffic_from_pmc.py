@@ -45,6 +45,8 @@ def main():
         kt, fe, wr = rows("%s/%s_kt.md" % (d, w)), rows("%s/%s_fetch.md" % (d, w)), rows("%s/%s_write.md" % (d, w))
         tcc, sq, ea = rows("%s/%s_tcc.md" % (d, w)), rows("%s/%s_sq.md" % (d, w)), rows("%s/%s_ea.md" % (d, w))
         tcp, ta2 = rows("%s/%s_tcp.md" % (d, w)), rows("%s/%s_ta2.md" % (d, w))
+        mix = rows("%s/%s_mix.md" % (d, w))              # vector instructions by class (their SQ_INSTS_VALU kept apart: shares within one pass)
+        mix = {(k, "SQ_INSTS_VALU_MIX" if c == "SQ_INSTS_VALU" else c): v for (k, c), v in mix.items() if c != "GRBM_GUI_ACTIVE" and not c.startswith("GRBM_GUI_ACTIVE")}
         if not fe and not ea:
             continue
         ks = {}
@@ -71,7 +73,7 @@ def main():
             if (k, "avg_us") in kt:
                 e["avg_us"] = kt[(k, "avg_us")]
                 e["GBps"] = e["bytes_per_launch"] / (e["avg_us"] * 1e-6) / 1e9
-            for src in (tcc, sq, ea, tcp, ta2):
+            for src in (tcc, sq, ea, tcp, ta2, mix):
                 for (kk, c), v in src.items():
                     if kk == k and not c.endswith(":n"):
                         e[c] = v
