@@ -69,14 +69,15 @@ def parse(argv=None):
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget (rank 0, N=1 only); 0 = skip")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-sample-batches", action="store_true", help="skip the sample_batches section (profiling passes: keeps the per-kernel "
-                    "averages to single-frame launches)")
+    ap.add_argument("--no-frame-by-frame", "--no-sample-batches", dest="no_sample_batches", action="store_true",
+                    help="skip the frame_by_frame section (profiling passes: keeps the per-kernel averages to one kind of launch)")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not re-run a few frames under rocprofv3 for roofline.traffic; use the "
                     "committed profiles/<round>/traffic.json only")
     ap.add_argument("--hbm-frames", type=int, default=8, help="frames of the HBM-bound 10 M-triangle 4K workload timed for roofline_hbm "
                     "(rank 0, N=1 only); 0 = skip")
-    ap.add_argument("--batch", type=int, default=1, help="frames per rt_pipeline_render_batch call (1 = one render() per frame, the headline; "
-                    "up to 8 frames share one set of launches: the sample-batch mode of BASELINE configs[2])")
+    ap.add_argument("--batch", type=int, default=16, help="frames per set of launches (rt_pipeline_render_batch, at most 16: the sample-batch mode "
+                    "of BASELINE configs[2]; the K timed frames are split evenly over ceil(K / batch) sets); 1 = one update() + render() "
+                    "per frame, which the default run also measures and reports as `frame_by_frame`")
     ap.add_argument("--obj", default=None, help="render this Wavefront OBJ instead of the procedural atrium (e.g. the real Sponza); "
                     "config.workload then names the file and its triangle count")
     ap.add_argument("--camera", type=float, nargs=6, default=None, metavar=("EX", "EY", "EZ", "AX", "AY", "AZ"),
@@ -86,7 +87,9 @@ def parse(argv=None):
     ap.add_argument("--partition", choices=("samples", "tiles"), default="samples",
                     help="samples (default, the headline): frames sharded over the GPUs, one all-reduce.  tiles: BASELINE configs[4], the "
                          "10 M-triangle 4K 4-bounce frame split into interleaved 16-row bands over the GPUs, one all-gather of the bands")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    args.batch_given = any(a == "--batch" or a.startswith("--batch=") for a in (sys.argv[1:] if argv is None else argv))
+    return args
 
 
 def relaunch_distributed(args):
@@ -195,7 +198,7 @@ LIVE_PMC_PASSES = {"ea": ["TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC
                    "mix": ["SQ_INSTS_VALU"] + sorted(VALU_CLASS_CYCLES)}
 
 
-def live_traffic(workload, width, height, budget_s=110.0, passes=("ea", "write", "sq", "tcp", "mix")):
+def live_traffic(workload, width, height, budget_s=110.0, passes=("ea", "write", "sq", "tcp", "mix"), per_set=1):
     """Memory-side bytes per launch of the traversal kernels, measured IN THIS RUN: bench.py re-runs itself for a few frames
     as a child of `rocprofv3 --kernel-trace --pmc ...`, one pass for the L2's read requests by size (32 / 64 / 128 B: the
     calibrated byte count for this access shape, MI355X_MICROARCH.md HBM section) and one for WRITE_SIZE (they do not fit one
@@ -210,7 +213,8 @@ def live_traffic(workload, width, height, budget_s=110.0, passes=("ea", "write",
         return {}
     here = os.path.dirname(os.path.abspath(__file__))
     child = [os.path.join(here, "bench.py"), "--cpu-seconds", "0", "--no-roofline", "--no-live-pmc"]
-    child += (["--steps", "8", "--warmup", "2", "--hbm-frames", "0", "--width", str(width), "--height", str(height)] if workload == "c2"
+    child += (["--steps", str(8 if per_set == 1 else 4 * per_set), "--warmup", str(2 if per_set == 1 else per_set), "--batch", str(per_set),
+               "--hbm-frames", "0", "--width", str(width), "--height", str(height)] if workload == "c2"
               else ["--workload", "c5", "--hbm-frames", "2"])
     out, t0 = {}, time.perf_counter()
     env = dict(os.environ, TMPDIR="/tmp")
@@ -504,7 +508,8 @@ def main():
     live = {}
     if world == 1 and not args.no_roofline and not args.no_live_pmc and args.partition == "samples" and args.workload == "c2":
         t_live = time.perf_counter()
-        live["c2"] = live_traffic("c2", args.width, args.height, budget_s=100.0)
+        n_sets_ = (args.steps + max(1, min(args.batch, 16)) - 1) // max(1, min(args.batch, 16))
+        live["c2"] = live_traffic("c2", args.width, args.height, budget_s=100.0, per_set=(args.steps + n_sets_ - 1) // n_sets_)
         if args.hbm_frames > 0:           # (the 10 M-triangle child runs take ~30 s each: the two traffic passes only)
             live["c5"] = live_traffic("c5", args.width, args.height, budget_s=max(20.0, 190.0 - (time.perf_counter() - t_live)), passes=("ea", "write"))
 
@@ -529,7 +534,7 @@ def main():
     if args.workload == "c5":            # profiling passes: only the HBM-bound workload, one JSON line of its own
         assert world == 1, "--workload c5 is a single-GPU profiling mode"
         ctx = capi.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-        h = hbm_workload(ctx, capi, T, scenes, max(args.hbm_frames, 1), 2, batch=args.batch)
+        h = hbm_workload(ctx, capi, T, scenes, max(args.hbm_frames, 1), 2, batch=args.batch if args.batch_given else 1)
         print(json.dumps({"metric": "Mrays/s, 10 M triangles 4K 4-bounce (roofline workload)", "value": h["Mrays_per_s"], "unit": "Mrays/s",
                           "n_gpus": 1, "roofline_hbm": h}))
         return
@@ -566,21 +571,26 @@ def main():
     mine = D.shard_frames(rank, world, total_frames)
     pipe.set_accumulation_mode(T.ACCUM_SUM if world > 1 else T.ACCUM_RUNNING_MEAN)
 
-    S = max(1, args.batch)
+    # frames per set of launches: the K timed frames go through ceil(K / batch) sets of (almost) equal size
+    n_sets = (K + max(1, min(args.batch, 16)) - 1) // max(1, min(args.batch, 16))
+    S = (K + n_sets - 1) // n_sets
 
     def step(i):
         pipe.update(pfcs[mine[i]])
         pipe.render()
 
-    def steps(lo, hi):
-        """frames lo..hi-1 of this rank: one render() each, or rt_pipeline_render_batch calls of S frames"""
-        if S == 1:
+    def steps(lo, hi, per_set=None):
+        """frames lo..hi-1 of this rank: one update() + render() each, or rt_pipeline_render_batch calls of per_set frames"""
+        per_set = S if per_set is None else per_set
+        if per_set == 1:
             for i in range(lo, hi):
                 step(i)
         else:
-            for i in range(lo, hi, S):
-                pipe.render_batch([pfcs[mine[j]] for j in range(i, min(i + S, hi))])
+            for i in range(lo, hi, per_set):
+                pipe.render_batch([pfcs[mine[j]] for j in range(i, min(i + per_set, hi))])
 
+    if S > 1:
+        pipe.reserve_batch(S)           # the work memory of a set of S frames: sized outside the timed region, like the output
     steps(0, Wu)
     if world > 1:                       # warm the collective too
         dist.all_reduce(torch.zeros_like(acc))
@@ -630,7 +640,8 @@ def main():
                        "camera": {"eye": list(cam["eye"]), "at": list(cam["at"]), "vfov": cam["fov"]},
                        "frames_per_gpu": K, "parallelism": "sample-sharded x%d, one RCCL all-reduce of the fp32 accumulation buffer" % world
                        if world > 1 else "single GPU", "accumulation": "sum+allreduce" if world > 1 else "running mean",
-                       "frames_per_launch_set": S},
+                       "frames_per_launch_set": S, "launch_sets": n_sets,
+                       "entry_point": "rt_pipeline_render_batch" if S > 1 else "rt_pipeline_update + rt_pipeline_render"},
             "primary_mrays_per_s": primary_all / elapsed / 1e6,
             "frames_per_s": K * world / elapsed,
             "rays_per_frame": rays_all / (K * world),
@@ -641,11 +652,17 @@ def main():
             "ranks": report,
         }
         if not args.no_roofline:
+            if S > 1:
+                step(Wu + K - 1)        # (the walk counters below are those of ONE frame: the last one again, by itself, after the timed region)
             stages, n_t = stage_table(pipe, tot)
             dom = max(TRACE_STAGES, key=lambda s: stages[s]["avg_ms"])
             d = stages[dom]
-            prof = committed_profile("c2").get("kernels", {}).get(d["kernel"], {})
+            prof_name = "c2" if S == 1 else "c2b"
+            prof = committed_profile(prof_name).get("kernels", {}).get(d["kernel"], {})
             lv = live.get("c2", {}).get(d["kernel"], {})
+            # a launch covers a set of frames: stage times are per frame (stage_table), hardware counters per launch
+            fpl = float(S) if lv else float(prof.get("frames_per_launch", 1))     # frames per launch in the counter passes
+            launch_ms = d["avg_ms"] * n_t / n_sets                                 # this run's average launch of the stage
             # What bounds the dominant kernel (round 3, counters under the round-2 self-count).  The C2 working set (~4 MB of nodes
             # + 12 MB of triangle records) lives in the L2s and the Infinity Cache, so HBM cannot bound it (`traffic`: a few % of
             # what the lanes gather).  The vector-memory path is not saturated either: the L1 -> L2 read requests run at about a
@@ -665,10 +682,11 @@ def main():
                   "counters_source": ("this run (rocprofv3 --pmc child passes: %s)" % ", ".join(sorted(k for k in ("sq", "tcp", "mix") if any(c in lv for c in LIVE_PMC_PASSES[k][1:] or LIVE_PMC_PASSES[k]))))
                                      if any(c in lv for c in LIVE_PMC_PASSES["sq"]) else "committed profile %s" % committed_profile("c2").get("source"),
                   "traffic_fallback": LIVE_PMC_NOTES or None,
-                  "avg_launch_ms": d["avg_ms"], "launches_timed": n_t}
+                  "avg_launch_ms": launch_ms, "launches_timed": n_sets, "frames_per_launch": n_t / n_sets, "avg_ms_per_frame": d["avg_ms"],
+                  "frames_per_launch_in_counter_passes": fpl}
             if have_sq:
                 clk_hz = pm["GRBM_GUI_ACTIVE"] / N_XCD / ((pm.get("sq_pass_avg_us") or pm["avg_us"]) * 1e-6)
-                rl["achieved"] = pm["SQ_INSTS_VALU"] / (d["avg_ms"] * 1e-3) / 1e9
+                rl["achieved"] = pm["SQ_INSTS_VALU"] / fpl / (d["avg_ms"] * 1e-3) / 1e9      # (counters per launch -> per frame; stage time per frame)
                 # the mean issue cost of this kernel's own instructions (class counters of one pass x the measured cycles per class)
                 cost, tot = VALU_ISSUE_CYCLES, pm.get("SQ_INSTS_VALU_MIX")
                 if tot and all(c in pm for c in VALU_CLASS_CYCLES):
@@ -687,20 +705,20 @@ def main():
                 wc = pm["SQ_WAVE_CYCLES"]
                 rl["wave_cycles"] = {"parked_on_waitcnt": pm.get("SQ_WAIT_ANY", 0.0) / wc, "issue_stalled": pm.get("SQ_WAIT_INST_ANY", 0.0) / wc,
                                      "issuing": pm.get("SQ_ACTIVE_INST_ANY", 0.0) / wc}
-                if "SQ_ACTIVE_INST_VALU" in pm:
-                    rl["valu_busy_gfx9_formula"] = pm["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * pm["GRBM_GUI_ACTIVE"] / N_XCD)
+                # (the gfx9 VALUBusy formula -- SQ_ACTIVE_INST_VALU x 4 / SIMD cycles -- prices every instruction at 4 cycles and reads
+                # above 1 here; issue_cost is the measured version of the same idea)
             else:
                 rl.update({"achieved": None, "peak": None, "frac": None})
             mp = {"lines_counted_by_count_walk": d["gathered_bytes"] // LINE_BYTES, "gathered_GBps_count_walk": d["gathered_GBps"],
-                  "hbm_frac": (rl["traffic"] / (d["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if rl["traffic"] else None}
+                  "hbm_frac": (rl["traffic"] / fpl / (d["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if rl["traffic"] else None}
             if "TCP_TCC_READ_REQ_sum" in pm:
                 req = pm["TCP_TCC_READ_REQ_sum"]
-                mp.update({"l2_read_requests_per_launch": req, "l2_request_rate_frac": req / (d["avg_ms"] * 1e-3) / L2_REQUEST_PEAK_PER_S,
-                           "l2_request_GBps": req * LINE_BYTES / (d["avg_ms"] * 1e-3) / 1e9, "l2_request_peak_GBps": GATHER_PEAK_GBS,
-                           "l1_served_share_of_counted_lines": 1.0 - req / max(d["gathered_bytes"] / LINE_BYTES, 1.0)})
+                mp.update({"l2_read_requests_per_launch": req, "l2_request_rate_frac": req / fpl / (d["avg_ms"] * 1e-3) / L2_REQUEST_PEAK_PER_S,
+                           "l2_request_GBps": req / fpl * LINE_BYTES / (d["avg_ms"] * 1e-3) / 1e9, "l2_request_peak_GBps": GATHER_PEAK_GBS,
+                           "l1_served_share_of_counted_lines": 1.0 - req / fpl / max(d["gathered_bytes"] / LINE_BYTES, 1.0)})
             if "TCP_TOTAL_CACHE_ACCESSES_sum" in pm and have_sq:
                 mp["l1_tag_accesses_per_launch"] = pm["TCP_TOTAL_CACHE_ACCESSES_sum"]
-                mp["l1_tag_rate_frac"] = pm["TCP_TOTAL_CACHE_ACCESSES_sum"] / (d["avg_ms"] * 1e-3) / (N_CU * clk_hz)
+                mp["l1_tag_rate_frac"] = pm["TCP_TOTAL_CACHE_ACCESSES_sum"] / fpl / (d["avg_ms"] * 1e-3) / (N_CU * clk_hz)
             rl["memory_path"] = mp
             rl["definition"] = ("frac = the share of the launch's SIMD cycles in which a vector pipe was taken: SQ_INSTS_VALU per launch / HIP-event "
                                 "launch duration / (1024 SIMDs x clock / issue_cost.cycles_per_instruction), the cost being the kernel's own "
@@ -727,24 +745,26 @@ def main():
             tb = sum(stages[s]["gathered_bytes"] for s in TRACE_STAGES)
             out["roofline"]["all_stages_GBps_over_step"] = tb / (out["ms_per_step"] * 1e-3) / 1e9
             out["stages"] = stages
-        if world == 1 and not args.no_roofline and not args.no_sample_batches and S == 1:
-            # the same K frames again, eight per set of launches (rt_pipeline_render_batch: BASELINE configs[2]'s sample batches):
-            # the persistent traversal stages and their tails are paid once per batch, the image is the same bit for bit
-            SB = 8
+        if world == 1 and not args.no_roofline and not args.no_sample_batches and S > 1:
+            # the same K frames again, one update() + render() per frame as the reference's app loop issues them
+            # (DXRExperimentsApp::OnUpdate / OnRender): the same image bit for bit, every persistent traversal launch and its tail
+            # paid per frame instead of per set
             pipe.clear_output()
-            pipe.render_batch([pfcs[mine[j]] for j in range(0, min(SB, Wu))] or [pfcs[mine[0]]])
+            steps(0, Wu, per_set=1)
             ctx.synchronize()
+            pipe.enable_timing(K)
             pipe.reset_totals()
             tb0 = time.perf_counter()
-            for i in range(Wu, Wu + K, SB):
-                pipe.render_batch([pfcs[mine[j]] for j in range(i, min(i + SB, Wu + K))])
+            steps(Wu, Wu + K, per_set=1)
             ctx.synchronize()
             tb = time.perf_counter() - tb0
             totb = pipe.totals()
             raysb = totb["rays_primary"] + totb["rays_secondary"] + totb["rays_shadow"] - totb["rays_shadow_skipped"]
-            out["sample_batches"] = {"frames_per_launch_set": SB, "frames": K, "ms_per_frame": tb / K * 1e3, "Mrays_per_s": raysb / tb / 1e6,
-                                     "frames_per_s": K / tb, "speedup_over_frame_by_frame": (elapsed / K) / (tb / K),
-                                     "note": "rt_pipeline_render_batch: same frames, same bits, 8 frames per set of launches; `value` above is frame by frame"}
+            fb_stages = {name: sum(totb[k] for k in keys) / max(int(totb["frames"]), 1) for name, (keys, _, _) in TRACE_STAGES.items()}
+            out["frame_by_frame"] = {"frames": K, "ms_per_frame": tb / K * 1e3, "Mrays_per_s": raysb / tb / 1e6, "frames_per_s": K / tb,
+                                     "stage_ms": fb_stages, "value_over_frame_by_frame": (tb / K) / (elapsed / K),
+                                     "note": "rt_pipeline_update + rt_pipeline_render per frame: same frames, same bits; `value` above renders them "
+                                             "%d per set of launches (rt_pipeline_render_batch)" % S}
         if world == 1 and args.hbm_frames > 0 and not args.no_roofline:
             del pipe, scene, model
             h = hbm_workload(ctx, capi, T, scenes, args.hbm_frames, 2)

@@ -106,6 +106,7 @@ SIGNATURES = {
     "rt_pipeline_update": (_i, [_p, _p]),
     "rt_pipeline_render": (_i, [_p, _u32, _u32]),
     "rt_pipeline_render_batch": (_i, [_p, _u32, _u32, _p, _u32]),
+    "rt_pipeline_reserve_batch": (_i, [_p, _u32, _u32, _u32]),
     "rt_pipeline_render_tile": (_i, [_p, _u32, _u32, _u32, _u32, _u32, _u32]),
     "rt_pipeline_get_num_outputs": (_i, [_p, C.POINTER(_i)]),
     "rt_pipeline_get_output_device_ptr": (_i, [_p, _u32, _pp]),
@@ -514,6 +515,10 @@ class Pipeline:
         buf = np.ascontiguousarray(np.stack([np.frombuffer(np.asarray(c).tobytes(), np.uint8) for c in constants]))
         assert buf.shape[1] == 188
         _check(lib().rt_pipeline_render_batch(self.h, self.width, self.height, _ptr(buf), buf.shape[0]))
+
+    def reserve_batch(self, frames):
+        """Size the ray queues for sets of `frames` frames now (the first render_batch of that size then allocates nothing)."""
+        _check(lib().rt_pipeline_reserve_batch(self.h, self.width, self.height, int(frames)))
 
     def render_bands(self, band_rows, rank, world):
         """One frame over this rank's interleaved row bands (tile-partitioned multi-GPU runs)."""

@@ -876,6 +876,18 @@ int rt_pipeline_render_batch(rt_pipeline *p, uint32_t width, uint32_t height, co
     return RT_OK;
 }
 
+int rt_pipeline_reserve_batch(rt_pipeline *p, uint32_t width, uint32_t height, uint32_t frames)
+{
+    RT_REQUIRE(p && width > 0 && height > 0 && frames >= 1 && frames <= RT_MAX_BATCH, "reserve_batch: bad argument");
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    const uint32_t fcap = ((width + 7u) / 8u) * ((height + 7u) / 8u) * 64u;
+    RT_REQUIRE((uint64_t)fcap * frames < 0x40000000ull, "batch: more than 2^30 pixel slots in one set of launches");
+    const bool ao_view = p->have_pfc && p->pfc.options.showAmbientOcclusionOnly != 0;
+    RT_TRY(ensure_queues(p, fcap * frames, ao_view ? 4u : 2u, frame_levels(p)));
+    if (frames > 1) RT_TRY(p->batch_consts.reserve((sizeof(rt_per_frame_constants) + sizeof(LightRays)) * RT_MAX_BATCH));
+    return RT_OK;
+}
+
 int rt_pipeline_count_work(rt_pipeline *p, rt_stage_work *out)
 {
     RT_REQUIRE(p && out, "null argument");

@@ -72,6 +72,9 @@ public:
         if (n) mConstants = constants[n - 1];
     }
 
+    // sizes the work memory of renderBatch calls of n frames ahead of time (optional)
+    void reserveBatch(UINT n, UINT width, UINT height) { DXRFramework::ThrowIfFailed(rt_pipeline_reserve_batch(mPipeline, width, height, n)); }
+
     // what render() does before DispatchRays (:217-240): per-instance hit records, miss records, apply
     void fillShaderTable()
     {

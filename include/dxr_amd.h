@@ -205,6 +205,10 @@ int rt_pipeline_render(rt_pipeline *p, uint32_t width, uint32_t height);
  * the one n single frames leave.  Frames with accumCount >= maxIterations are skipped (:14-16).  Progressive pipeline only;
  * afterwards the pipeline's constants are constants[n - 1].  Queue memory grows with the batch (1080p: ~0.8 GB per frame). */
 int rt_pipeline_render_batch(rt_pipeline *p, uint32_t width, uint32_t height, const rt_per_frame_constants *constants, uint32_t n);
+/* Sizes the ray queues for sets of `frames` frames of width x height now, so that the first rt_pipeline_render_batch of that size
+ * does not allocate (the counterpart of createOutputResource for the per-frame work memory the reference's Fallback Layer keeps
+ * inside DispatchRays).  Optional: queues also grow on demand. */
+int rt_pipeline_reserve_batch(rt_pipeline *p, uint32_t width, uint32_t height, uint32_t frames);
 /* same, restricted to pixel rectangle [x0,x1) x [y0,y1) (tile sharding) */
 int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height,
                             uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);

@@ -111,6 +111,34 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float s)
 #define OP(n) "v_min_u32 %" #n ", %" #n ", %8\n"
             asm volatile(R8(OP) : REGS : "v"(s));
 #undef OP
+        } else if (MODE == 25) {
+#define OP(n) "v_perm_b32 %" #n ", %" #n ", %8, %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 26) {      // f16 sources converted inside the fma: src0 = low half of the register, src1 / src2 f32
+#define OP(n) "v_fma_mix_f32 %" #n ", %" #n ", %8, %8 op_sel_hi:[1,0,0]\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 27) {
+#define OP(n) "v_bfe_u32 %" #n ", %" #n ", 8, 8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 28) {
+#define OP(n) "v_and_or_b32 %" #n ", %" #n ", %8, %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 29) {
+#define OP(n) "v_lshl_add_u32 %" #n ", %" #n ", 2, %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 30) {
+#define OP(n) "v_cvt_f32_u32 %" #n ", %" #n "\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 31) {
+#define OP(n) "v_lshrrev_b32 %" #n ", 8, %" #n "\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
         } else if (MODE == 24) {
             asm volatile("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
                          : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(s2));
@@ -139,13 +167,14 @@ int main()
     float *d; hipMalloc(&d, blocks * 256 * 4);
     const char *names[] = {"v_mul_f32", "v_pk_mul_f32", "v_min_f32", "v_min3_f32", "v_cndmask_b32 vcc", "v_cndmask_b32 sgpr", "v_sub_f32", "v_fma_f32",
                            "v_add_u32", "v_cmp_lt_f32 vcc", "v_cmp_lt_f32 sgpr", "v_max_f32", "v_lshl_or_b32", "v_mov_b32", "v_med3_f32", "v_mul_f32 literal", "cmp+add+cndmask (x3)", "v_fmac_f32 (VOP2)", "v_pk_fma_f32", "v_cvt_f32_ubyte1", "v_add_f32", "v_and_b32",
-                           "v_max3_f32", "v_min_u32", "v_pk_add_f32"};
-    float ms[25] = {run<0>(d, blocks, iters), run<1>(d, blocks, iters), run<2>(d, blocks, iters), run<3>(d, blocks, iters), run<4>(d, blocks, iters),
+                           "v_max3_f32", "v_min_u32", "v_pk_add_f32", "v_perm_b32", "v_fma_mix_f32", "v_bfe_u32", "v_and_or_b32", "v_lshl_add_u32", "v_cvt_f32_u32", "v_lshrrev_b32"};
+    float ms[32] = {run<0>(d, blocks, iters), run<1>(d, blocks, iters), run<2>(d, blocks, iters), run<3>(d, blocks, iters), run<4>(d, blocks, iters),
                     run<5>(d, blocks, iters), run<6>(d, blocks, iters), run<7>(d, blocks, iters), run<8>(d, blocks, iters), run<9>(d, blocks, iters),
                     run<10>(d, blocks, iters), run<11>(d, blocks, iters), run<12>(d, blocks, iters), run<13>(d, blocks, iters), run<14>(d, blocks, iters),
                     run<15>(d, blocks, iters), run<16>(d, blocks, iters), run<17>(d, blocks, iters), run<18>(d, blocks, iters), run<19>(d, blocks, iters),
-                    run<20>(d, blocks, iters), run<21>(d, blocks, iters), run<22>(d, blocks, iters), run<23>(d, blocks, iters), run<24>(d, blocks, iters)};
-    for (int m = 0; m < 25; m++) {
+                    run<20>(d, blocks, iters), run<21>(d, blocks, iters), run<22>(d, blocks, iters), run<23>(d, blocks, iters), run<24>(d, blocks, iters),
+                    run<25>(d, blocks, iters), run<26>(d, blocks, iters), run<27>(d, blocks, iters), run<28>(d, blocks, iters), run<29>(d, blocks, iters), run<30>(d, blocks, iters), run<31>(d, blocks, iters)};
+    for (int m = 0; m < 32; m++) {
         const int per = (m == 1 || m == 18 || m == 24) ? 4 : 8;
         const double wave_insts = (double)blocks * 4 * iters * per;
         printf("%-20s %8.3f ms  %.3f ns per wave64 instruction per SIMD\n", names[m], ms[m], ms[m] * 1e6 / (wave_insts / 1024.0));

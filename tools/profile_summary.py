@@ -38,6 +38,24 @@ def main():
         for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             print("| %s | %d | %.3f | %.1f | %.1f | %.1f | %.2f |" % (k, a[0], a[1] / 1e6, a[1] / a[0] / 1e3, a[2] / 1e3, a[3] / 1e3, 100 * a[1] / tot))
         print()
+    # the traversal kernels launch by launch (template arguments kept: <LDS stack rows, two-level, frames-per-launch > 1>), so that a
+    # figure quoted for ONE kind of launch -- bench.py's roofline.avg_launch_ms -- can be read off even when the run holds several kinds
+    for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)):
+        per = defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            m = re.search(r"(k_primary|k_trace_secondary|k_trace_shadow)<([^>]*)>", r["Kernel_Name"])
+            if m:
+                per["%s<%s>" % (m.group(1), m.group(2).replace(" ", ""))].append((float(r["Start_Timestamp"]), float(r["End_Timestamp"]) - float(r["Start_Timestamp"])))
+        if per:
+            print("## traversal launches in issue order (%s): duration of every launch, ms\n" % os.path.basename(f))
+            print("| kernel<LDS stack rows, two-level, set of frames> | launches | median ms | each launch, ms |")
+            print("|---|---:|---:|---|")
+            for k in sorted(per):
+                ds = [x[1] / 1e6 for x in sorted(per[k])]
+                med = sorted(ds)[len(ds) // 2]
+                shown = ds if len(ds) <= 24 else ds[:8] + [float("nan")] + ds[-12:]
+                print("| %s | %d | %.3f | %s |" % (k, len(ds), med, " ".join("..." if x != x else "%.3f" % x for x in shown)))
+            print()
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         rows = list(csv.DictReader(open(f)))
         agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
