@@ -37,13 +37,17 @@ L2_REQUEST_PEAK_PER_S = 120.6e9
 GATHER_PEAK_GBS = L2_REQUEST_PEAK_PER_S * 64 / 1e9
 N_CU, N_SIMD, N_XCD = 256, 1024, 8
 VALU_ISSUE_CYCLES = 2.0        # a wave64 VALU instruction occupies a SIMD-32 for 2 cycles (MI355X_MICROARCH.md, "Wave scheduling") -- the nominal figure
-# ... which only v_add / v_sub / v_mul / v_mov and the simple integer forms reach: measured with eight waves per SIMD issuing
-# independent instructions (tools/microbench/valu_rate under rocprofv3, cycles = GRBM_GUI_ACTIVE / 8: profiles/r03/valu_rate_pmc.md),
-# v_fma_f32, v_min / v_max and their three-operand forms, v_cmp, v_cndmask, v_cvt_f32_ubyte, v_lshl_or take 4 cycles (the
-# packed f32 forms 4 for two operations), the transcendental unit 8 (guide).  The traversal step is mostly made of those, so
-# the issue ceiling of a kernel is N_SIMD x clock / (the mean cost of ITS instructions), from the SQ_INSTS_VALU_* class counters.
-# INT32 is a mix of 2- and 4-cycle forms and is priced at 2 (a lower bound: the fraction reported cannot overstate);
-# "other" = everything the class counters do not name: min / max / med3 / cmp / cndmask (4) and a few moves.
+# ... which only v_add / v_sub / v_mul / v_mov and the simple integer forms reach.  Measured with six to eight waves per SIMD
+# issuing independent instructions (tools/microbench/valu_rate under rocprofv3, cycles = GRBM_GUI_ACTIVE / 8:
+# profiles/r03/valu_rate_pmc.md, valu_rate_pmc_w6.md): those take 2.4, v_fma_f32, v_min / v_max and their three-operand forms,
+# v_cmp, v_cndmask, v_cvt_f32_ubyte, v_lshl_or take 4.2 - 4.5 (the packed f32 forms 4.7 for two operations) -- but the costs
+# do not add up in a mixed stream (v_cvt + v_fma alternating: 2.8 each).  So the ceiling is measured on the mix itself: a
+# synthetic stream with the class shares of the traversal kernels (add 9, mul 9, fma 16, cvt 12, int 16, min / max / compare /
+# select 38 %: mode "traversal-kernel mix") issues one instruction per VALU_MIX_CYCLES per SIMD at the kernels' six waves per
+# SIMD (2.66 at eight, 2.71 at five, 3.25 at three, 7.9 for one wave alone).  The live class counters (SQ_INSTS_VALU_*) are
+# reported beside it so that the shares can be compared; the additive per-class prices (an upper bound on the cost) likewise.
+VALU_MIX_CYCLES = 2.65
+VALU_MIX_STREAM_SHARES = {"ADD_F32": 3 / 32, "MUL_F32": 3 / 32, "FMA_F32": 5 / 32, "CVT": 4 / 32, "INT32": 5 / 32, "TRANS_F32": 0.0, "other": 12 / 32}
 VALU_CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.0, "SQ_INSTS_VALU_MUL_F32": 2.0, "SQ_INSTS_VALU_FMA_F32": 4.0, "SQ_INSTS_VALU_CVT": 4.0,
                      "SQ_INSTS_VALU_INT32": 2.0, "SQ_INSTS_VALU_TRANS_F32": 8.0}
 VALU_OTHER_CYCLES = 4.0
@@ -687,18 +691,19 @@ def main():
             if have_sq:
                 clk_hz = pm["GRBM_GUI_ACTIVE"] / N_XCD / ((pm.get("sq_pass_avg_us") or pm["avg_us"]) * 1e-6)
                 rl["achieved"] = pm["SQ_INSTS_VALU"] / fpl / (d["avg_ms"] * 1e-3) / 1e9      # (counters per launch -> per frame; stage time per frame)
-                # the mean issue cost of this kernel's own instructions (class counters of one pass x the measured cycles per class)
-                cost, tot = VALU_ISSUE_CYCLES, pm.get("SQ_INSTS_VALU_MIX")
+                # the issue ceiling of this kernel's instruction mix: measured on a synthetic stream with the same class shares
+                # (VALU_MIX_CYCLES); this run's class counters beside the stream's shares, and the additive per-class price as an upper bound
+                rl["issue_cost"] = {"cycles_per_instruction": VALU_MIX_CYCLES,
+                                    "source": "tools/microbench/valu_rate, mode 'traversal-kernel mix', 6 waves per SIMD: profiles/r03/valu_rate_pmc_w6.md",
+                                    "class_shares_of_the_stream": VALU_MIX_STREAM_SHARES}
+                tot = pm.get("SQ_INSTS_VALU_MIX")
                 if tot and all(c in pm for c in VALU_CLASS_CYCLES):
                     named = sum(pm[c] for c in VALU_CLASS_CYCLES)
-                    cost = (sum(pm[c] * cy for c, cy in VALU_CLASS_CYCLES.items()) + max(tot - named, 0.0) * VALU_OTHER_CYCLES) / tot
-                    rl["issue_cost"] = {"cycles_per_instruction": cost,
-                                        "class_shares": dict({c[len("SQ_INSTS_VALU_"):]: pm[c] / tot for c in sorted(VALU_CLASS_CYCLES)}, other=max(tot - named, 0.0) / tot),
-                                        "class_cycles": dict({c[len("SQ_INSTS_VALU_"):]: cy for c, cy in sorted(VALU_CLASS_CYCLES.items())}, other=VALU_OTHER_CYCLES),
-                                        "calibration": "profiles/r03/valu_rate_pmc.md"}
-                else:
-                    rl["issue_cost"] = {"cycles_per_instruction": cost, "note": "no class counters: the nominal SIMD-32 figure"}
-                rl["peak"] = N_SIMD * clk_hz / cost / 1e9
+                    rl["issue_cost"]["class_shares_of_this_kernel"] = dict({c[len("SQ_INSTS_VALU_"):]: pm[c] / tot for c in sorted(VALU_CLASS_CYCLES)},
+                                                                          other=max(tot - named, 0.0) / tot)
+                    rl["issue_cost"]["additive_upper_bound_cycles"] = (sum(pm[c] * cy for c, cy in VALU_CLASS_CYCLES.items())
+                                                                      + max(tot - named, 0.0) * VALU_OTHER_CYCLES) / tot
+                rl["peak"] = N_SIMD * clk_hz / VALU_MIX_CYCLES / 1e9
                 rl["frac"] = rl["achieved"] / rl["peak"]
                 rl["frac_at_2_cycles_per_instruction"] = rl["achieved"] / (N_SIMD * clk_hz / VALU_ISSUE_CYCLES / 1e9)
                 rl["clock_GHz_under_load"] = clk_hz / 1e9
@@ -720,12 +725,12 @@ def main():
                 mp["l1_tag_accesses_per_launch"] = pm["TCP_TOTAL_CACHE_ACCESSES_sum"]
                 mp["l1_tag_rate_frac"] = pm["TCP_TOTAL_CACHE_ACCESSES_sum"] / fpl / (d["avg_ms"] * 1e-3) / (N_CU * clk_hz)
             rl["memory_path"] = mp
-            rl["definition"] = ("frac = the share of the launch's SIMD cycles in which a vector pipe was taken: SQ_INSTS_VALU per launch / HIP-event "
-                                "launch duration / (1024 SIMDs x clock / issue_cost.cycles_per_instruction), the cost being the kernel's own "
-                                "instruction classes (SQ_INSTS_VALU_* of one pass) x the cycles each class takes on a SIMD with eight waves issuing "
-                                "(tools/microbench/valu_rate under rocprofv3: add / sub / mul / mov 2, fma / min / max / cmp / cndmask / cvt 4, "
-                                "transcendental 8; INT32 priced at 2, a lower bound); frac_at_2_cycles_per_instruction is the same against the nominal "
-                                "SIMD-32 figure; clock = GRBM_GUI_ACTIVE / 8 / launch duration in the counter pass.  memory_path: "
+            rl["definition"] = ("frac = achieved / peak, both in wave64 VALU instructions per second: achieved = SQ_INSTS_VALU per frame / this run's "
+                                "HIP-event stage time per frame; peak = 1024 SIMDs x clock / issue_cost.cycles_per_instruction, the rate at which a "
+                                "SIMD issues a synthetic stream of independent instructions with this kernel's class shares at six waves per SIMD "
+                                "(tools/microbench/valu_rate under rocprofv3); frac_at_2_cycles_per_instruction is the same against the nominal "
+                                "SIMD-32 figure, which only add / mul / mov streams reach; clock = GRBM_GUI_ACTIVE / 8 / launch duration in the "
+                                "counter pass.  memory_path: "
                                 "TCP_TCC_READ_REQ (one per 64-B line gathered: calibrated on tools/microbench/slab_fetch, profiles/r03/"
                                 "slab_131072_tcp.md) against the 120.6 G requests/s the chip sustains for this access shape; "
                                 "TCP_TOTAL_CACHE_ACCESSES against one per clock per CU; hbm_frac = traffic / duration / 8 TB/s.  "

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box): tools/bench_env.sh "VAR=val ..." "VAR=val ..."   -> one bench line per environment setting
 for e in "$@"; do
-  env $e timeout 300 python bench.py --steps 30 --warmup 5 --batch ${BATCH:-1} --cpu-seconds 0 --no-live-pmc --hbm-frames ${HBM:-0} 2>/dev/null | python -c "
+  env $e timeout 300 python bench.py --steps ${STEPS:-30} --warmup ${WARM:-5} --batch ${BATCH:-1} --cpu-seconds 0 --no-live-pmc --hbm-frames ${HBM:-0} 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 f=lambda st:{k:(round(v['avg_ms'],3), round(v['nodes_global_per_ray']+v['nodes_lds_per_ray'],2), round(v['tris_per_ray'],2)) for k,v in st.items() if isinstance(v,dict)}

@@ -4,6 +4,7 @@
 // copies of one instruction; reported: ns per wave64 instruction per SIMD.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 #define R8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
@@ -139,6 +140,35 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float s)
 #define OP(n) "v_lshrrev_b32 %" #n ", 8, %" #n "\n"
             asm volatile(R8(OP) : REGS : "v"(s));
 #undef OP
+        } else if (MODE == 32) {      // mixed streams: are the costs additive?  4 x (v_fma_f32 ; v_mul_f32)
+            asm volatile("v_fma_f32 %0, %0, %8, %8\n v_mul_f32 %1, %1, %8\n v_fma_f32 %2, %2, %8, %8\n v_mul_f32 %3, %3, %8\n"
+                         "v_fma_f32 %4, %4, %8, %8\n v_mul_f32 %5, %5, %8\n v_fma_f32 %6, %6, %8, %8\n v_mul_f32 %7, %7, %8\n" : REGS : "v"(s));
+        } else if (MODE == 33) {      // 4 x (v_cvt_f32_ubyte1 ; v_fma_f32)
+            asm volatile("v_cvt_f32_ubyte1 %0, %0\n v_fma_f32 %1, %1, %8, %8\n v_cvt_f32_ubyte1 %2, %2\n v_fma_f32 %3, %3, %8, %8\n"
+                         "v_cvt_f32_ubyte1 %4, %4\n v_fma_f32 %5, %5, %8, %8\n v_cvt_f32_ubyte1 %6, %6\n v_fma_f32 %7, %7, %8, %8\n" : REGS : "v"(s));
+        } else if (MODE == 34) {      // 4 x (v_cndmask_b32 sgpr ; v_max3_f32)
+            asm volatile("v_cndmask_b32_e64 %0, %0, %8, %9\n v_max3_f32 %1, %1, %8, %8\n v_cndmask_b32_e64 %2, %2, %8, %9\n v_max3_f32 %3, %3, %8, %8\n"
+                         "v_cndmask_b32_e64 %4, %4, %8, %9\n v_max3_f32 %5, %5, %8, %8\n v_cndmask_b32_e64 %6, %6, %8, %9\n v_max3_f32 %7, %7, %8, %8\n" : REGS : "v"(s), "s"(m));
+        } else if (MODE == 35) {      // the step's own mix, roughly: cvt fma cvt fma min max3 cmp cndmask
+            asm volatile("v_cvt_f32_ubyte1 %0, %0\n v_fma_f32 %1, %1, %8, %8\n v_cvt_f32_ubyte2 %2, %2\n v_fma_f32 %3, %3, %8, %8\n"
+                         "v_min_f32 %4, %4, %8\n v_max3_f32 %5, %5, %8, %8\n v_cmp_le_f32_e64 s[20:21], %6, %8\n v_cndmask_b32_e64 %7, %7, %8, %9\n" : REGS : "v"(s), "s"(m) : "s20", "s21");
+        } else if (MODE == 36) {      // dependent chain: each instruction reads the one before (what ONE wave's step mostly is)
+            asm volatile("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %0, %0, %8, %8\n"
+                         "v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %0, %0, %8, %8\n" : REGS : "v"(s));
+        } else if (MODE == 37) {      // dependent chain of 2-cycle instructions
+            asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %0, %0, %8\n v_mul_f32 %0, %0, %8\n v_mul_f32 %0, %0, %8\n"
+                         "v_mul_f32 %0, %0, %8\n v_mul_f32 %0, %0, %8\n v_mul_f32 %0, %0, %8\n v_mul_f32 %0, %0, %8\n" : REGS : "v"(s));
+        } else if (MODE == 38) {      // a stream with the class shares of the traversal kernels (profiles/r03/c2_mix.md: add 9, mul 10, fma 18, cvt 12,
+                                      // int 15, min / max / compare / select 36 %), 32 independent instructions over 8 registers
+            asm volatile("v_cvt_f32_ubyte0 %0, %0\n v_fma_f32 %1, %1, %8, %8\n v_sub_f32 %2, %2, %8\n v_max3_f32 %3, %3, %8, %8\n"
+                         "v_cmp_le_f32_e64 s[20:21], %4, %8\n v_cndmask_b32_e64 %5, %5, %8, %9\n v_mul_f32 %6, %6, %8\n v_add_u32 %7, %7, %8\n"
+                         "v_cvt_f32_ubyte1 %0, %0\n v_fma_f32 %1, %1, %8, %8\n v_min_f32 %2, %2, %8\n v_lshl_or_b32 %3, %3, 10, %8\n"
+                         "v_cndmask_b32_e64 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %8\n v_mul_f32 %6, %6, %8\n v_cmp_ne_u32_e64 s[22:23], %7, %8\n"
+                         "v_cvt_f32_ubyte2 %0, %0\n v_fma_f32 %1, %1, %8, %8\n v_add_f32 %2, %2, %8\n v_min3_f32 %3, %3, %8, %8\n"
+                         "v_cmp_lt_f32_e64 s[20:21], %4, %8\n v_cndmask_b32_e64 %5, %5, %8, %9\n v_mul_f32 %6, %6, %8\n v_and_b32 %7, %7, %8\n"
+                         "v_cvt_f32_ubyte3 %0, %0\n v_fma_f32 %1, %1, %8, %8\n v_max_f32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
+                         "v_cndmask_b32_e64 %4, %4, %8, %9\n v_fmac_f32 %5, %8, %8\n v_sub_f32 %6, %6, %8\n v_lshlrev_b32 %7, 6, %7\n"
+                         : REGS : "v"(s), "s"(m) : "s20", "s21", "s22", "s23");
         } else if (MODE == 24) {
             asm volatile("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
                          : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(s2));
@@ -161,21 +191,24 @@ float run(float *d, int blocks, int iters)
     return ms;
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    const int blocks = 256 * 8, iters = 100000;
+    // argv[1]: workgroups per CU (each 4 waves = one per SIMD): 8 (default) = eight waves per SIMD, 6 = the traversal kernels' occupancy, 1 = one wave alone
+    const int blocks = 256 * (argc > 1 ? atoi(argv[1]) : 8), iters = 100000;
     float *d; hipMalloc(&d, blocks * 256 * 4);
     const char *names[] = {"v_mul_f32", "v_pk_mul_f32", "v_min_f32", "v_min3_f32", "v_cndmask_b32 vcc", "v_cndmask_b32 sgpr", "v_sub_f32", "v_fma_f32",
                            "v_add_u32", "v_cmp_lt_f32 vcc", "v_cmp_lt_f32 sgpr", "v_max_f32", "v_lshl_or_b32", "v_mov_b32", "v_med3_f32", "v_mul_f32 literal", "cmp+add+cndmask (x3)", "v_fmac_f32 (VOP2)", "v_pk_fma_f32", "v_cvt_f32_ubyte1", "v_add_f32", "v_and_b32",
-                           "v_max3_f32", "v_min_u32", "v_pk_add_f32", "v_perm_b32", "v_fma_mix_f32", "v_bfe_u32", "v_and_or_b32", "v_lshl_add_u32", "v_cvt_f32_u32", "v_lshrrev_b32"};
-    float ms[32] = {run<0>(d, blocks, iters), run<1>(d, blocks, iters), run<2>(d, blocks, iters), run<3>(d, blocks, iters), run<4>(d, blocks, iters),
+                           "v_max3_f32", "v_min_u32", "v_pk_add_f32", "v_perm_b32", "v_fma_mix_f32", "v_bfe_u32", "v_and_or_b32", "v_lshl_add_u32", "v_cvt_f32_u32", "v_lshrrev_b32",
+                           "mixed fma+mul", "mixed cvt+fma", "mixed cndmask+max3", "mixed step-like", "dependent fma chain", "dependent mul chain", "traversal-kernel mix"};
+    float ms[39] = {run<0>(d, blocks, iters), run<1>(d, blocks, iters), run<2>(d, blocks, iters), run<3>(d, blocks, iters), run<4>(d, blocks, iters),
                     run<5>(d, blocks, iters), run<6>(d, blocks, iters), run<7>(d, blocks, iters), run<8>(d, blocks, iters), run<9>(d, blocks, iters),
                     run<10>(d, blocks, iters), run<11>(d, blocks, iters), run<12>(d, blocks, iters), run<13>(d, blocks, iters), run<14>(d, blocks, iters),
                     run<15>(d, blocks, iters), run<16>(d, blocks, iters), run<17>(d, blocks, iters), run<18>(d, blocks, iters), run<19>(d, blocks, iters),
                     run<20>(d, blocks, iters), run<21>(d, blocks, iters), run<22>(d, blocks, iters), run<23>(d, blocks, iters), run<24>(d, blocks, iters),
-                    run<25>(d, blocks, iters), run<26>(d, blocks, iters), run<27>(d, blocks, iters), run<28>(d, blocks, iters), run<29>(d, blocks, iters), run<30>(d, blocks, iters), run<31>(d, blocks, iters)};
-    for (int m = 0; m < 32; m++) {
-        const int per = (m == 1 || m == 18 || m == 24) ? 4 : 8;
+                    run<25>(d, blocks, iters), run<26>(d, blocks, iters), run<27>(d, blocks, iters), run<28>(d, blocks, iters), run<29>(d, blocks, iters), run<30>(d, blocks, iters), run<31>(d, blocks, iters),
+                    run<32>(d, blocks, iters), run<33>(d, blocks, iters), run<34>(d, blocks, iters), run<35>(d, blocks, iters), run<36>(d, blocks, iters), run<37>(d, blocks, iters), run<38>(d, blocks, iters)};
+    for (int m = 0; m < 39; m++) {
+        const int per = (m == 1 || m == 18 || m == 24) ? 4 : (m == 38 ? 32 : 8);
         const double wave_insts = (double)blocks * 4 * iters * per;
         printf("%-20s %8.3f ms  %.3f ns per wave64 instruction per SIMD\n", names[m], ms[m], ms[m] * 1e6 / (wave_insts / 1024.0));
     }
