@@ -164,3 +164,38 @@ def test_config3_at_full_size_1080p_256_frames(gpu, capi):
     shard_mean = (total / N).astype(np.float32)
     assert rms(shard_mean, mean) <= 1e-5
     assert shard_mean[..., 3].min() == 1.0 and shard_mean[..., 3].max() == 1.0 and np.isfinite(shard_mean).all()
+
+
+def test_reserve_batch(gpu, capi):
+    """rt_pipeline_reserve_batch sizes the queues of a set of frames ahead of time: afterwards sets up to that size render
+    (same bits as frame by frame) without the device allocator being called, and bad sizes are refused."""
+    import ctypes
+
+    def free_bytes():
+        hip = ctypes.CDLL("libamdhip64.so")
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+    W, H = 96, 64
+    m = capi.Model(gpu, path=CORNELL_OBJ)
+    sc = capi.Scene(gpu)
+    sc.add_model(m)
+    p = capi.Pipeline(gpu)
+    p.set_scene(sc)
+    p.add_material(T.default_material())
+    p.set_environment_constant((0.5, 0.5, 0.5))
+    p.create_output(W, H)
+    p.build_acceleration_structures()
+    cam = cam_array(scenes.cornell_camera(), W / H)
+    pfcs = frames_of(capi, cam, 12, W, H)
+    p.reserve_batch(12)
+    gpu.synchronize()
+    free0 = free_bytes()
+    both_ways(p, pfcs)
+    both_ways(p, pfcs[:5])
+    gpu.synchronize()
+    assert free_bytes() == free0, "a reserved set of frames allocated device memory"
+    with pytest.raises(capi.RtError):
+        p.reserve_batch(0)
+    with pytest.raises(capi.RtError):
+        p.reserve_batch(17)

@@ -286,3 +286,16 @@ def test_bench_obj_workload(capi):
     args = bench.parse([])
     v, t, workload, cam = bench.headline_workload(args, capi, scenes, np)
     assert "BASELINE configs[1]" in workload and t.shape[0] == 261936 and cam == scenes.sponza_camera()
+
+
+def test_bench_frame_sets():
+    """bench.py splits its K timed frames evenly over ceil(K / --batch) sets of launches (at most 16 frames each)"""
+    import re
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert re.search(r'"--batch", type=int, default=16', src)
+    def split(K, batch):
+        n_sets = (K + max(1, min(batch, 16)) - 1) // max(1, min(batch, 16))
+        return n_sets, (K + n_sets - 1) // n_sets
+    assert split(20, 16) == (2, 10) and split(60, 16) == (4, 15) and split(5, 16) == (1, 5) and split(20, 1) == (20, 1) and split(64, 99) == (4, 16)
+    # ... and that is the expression bench.py uses
+    assert "n_sets = (K + max(1, min(args.batch, 16)) - 1) // max(1, min(args.batch, 16))" in src and "S = (K + n_sets - 1) // n_sets" in src
