@@ -299,6 +299,13 @@ static inline unsigned rt_persistent_grid(const rt_context *ctx, K kernel, int b
 #endif                                  // single-level walks, top of the TLAS for two-level ones) 26 KiB per 256-thread block = 6 blocks per CU.
                                         // Bench-scene rays: 98.1 % never hold more than 8 entries, 99.97 % not more than 12, none more than 17.
 #define RT_LDS_STACK_ROWS_TEST 6        // second instantiation (env RT_LDS_STACK_ROWS=6): tests force rays onto the global rows
+// Sets of frames (rt_pipeline_render_batch) run long launches whose ramp and drain no longer matter, and there a seventh wave
+// per SIMD pays (-3.5 % on the bench scene; frame by frame it costs 2 %, the drain grows with the resident waves:
+// profiles/r03/seven_waves.txt): their single-level kernels keep 14 stack rows in LDS (22 KiB per block = 7 blocks per CU) and
+// are compiled for seven waves (72 VGPRs; the 74 - 78 of the 18-row kernels shed two to six into scratch, off the step).
+#ifndef RT_LDS_STACK_ROWS_SETS
+#define RT_LDS_STACK_ROWS_SETS 14
+#endif
 
 // The scene as the traversal kernels see it, with the global stack rows a launch of `threads` threads whose
 // kernels keep `lds_rows` rows in LDS may need: the tree bounds a walk to stack_need (+1 speculative) entries.

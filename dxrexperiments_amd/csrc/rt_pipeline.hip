@@ -83,8 +83,10 @@ struct PrimarySink {
     }
 };
 
+// (see RT_LDS_STACK_ROWS_SETS: the single-level instantiations with that many stack rows are compiled for seven waves per SIMD;
+// every other instantiation is left to the compiler -- a floor of 1 constrains nothing)
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU __attribute__((amdgpu_waves_per_eu(STACK == RT_LDS_STACK_ROWS_SETS && !TWO_LEVEL ? 7 : 1)))
 #endif
 template <int STACK, bool TWO_LEVEL, bool BATCH>
 __global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_primary(PipeDev pd)
@@ -748,7 +750,8 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     }
     PipeDev pd;
     // (threads of the largest launch: the primary stage runs one thread per pixel slot, the persistent stages fewer)
-    RT_TRY(rt_scene_dev_for_launch(ctx, p->scene, rt_lds_stack_rows(ctx), cap > ctx->cu_count * 16u * PBLOCK ? cap : ctx->cu_count * 16u * PBLOCK, &pd.sc));
+    const bool set_rows = n_frames > 1 && !p->scene->two_level && ctx->lds_stack_rows != RT_LDS_STACK_ROWS_TEST && RT_LDS_STACK_ROWS_SETS != RT_LDS_STACK_ROWS;
+    RT_TRY(rt_scene_dev_for_launch(ctx, p->scene, set_rows ? RT_LDS_STACK_ROWS_SETS : rt_lds_stack_rows(ctx), cap > ctx->cu_count * 16u * PBLOCK ? cap : ctx->cu_count * 16u * PBLOCK, &pd.sc));
     pd.pfc = frames[0];
     pd.n_frames = n_frames; pd.fcap = fcap;
     pd.pfcs = nullptr; pd.frame_lights = nullptr;
@@ -812,8 +815,11 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     }
     // 18 LDS stack rows + the 8-row top table = 26 KiB per 256-thread block = 6 resident blocks per CU, whatever
     // the depth of the tree; the rare deeper walk continues in global rows (rt_trace_wave.h)
-    HIP_TRY(ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST ? launch_frame_any<RT_LDS_STACK_ROWS_TEST>(p, pd, shadow_slots)
-                                                           : launch_frame_any<RT_LDS_STACK_ROWS>(p, pd, shadow_slots));
+    hipError_t launched;
+    if (ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST) launched = launch_frame_any<RT_LDS_STACK_ROWS_TEST>(p, pd, shadow_slots);
+    else if (set_rows) launched = launch_frame<RT_LDS_STACK_ROWS_SETS, false>(p, pd, shadow_slots);
+    else launched = launch_frame_any<RT_LDS_STACK_ROWS>(p, pd, shadow_slots);
+    HIP_TRY(launched);
     HIP_TRY(hipGetLastError());
     p->last_pd = pd;
     p->last_shadow_slots = shadow_slots;
