@@ -79,7 +79,7 @@ def parse(argv=None):
                     "committed profiles/<round>/traffic.json only")
     ap.add_argument("--hbm-frames", type=int, default=8, help="frames of the HBM-bound 10 M-triangle 4K workload timed for roofline_hbm "
                     "(rank 0, N=1 only); 0 = skip")
-    ap.add_argument("--batch", type=int, default=16, help="frames per set of launches (rt_pipeline_render_batch, at most 16: the sample-batch mode "
+    ap.add_argument("--batch", type=int, default=32, help="frames per set of launches (rt_pipeline_render_batch, at most 32: the sample-batch mode "
                     "of BASELINE configs[2]; the K timed frames are split evenly over ceil(K / batch) sets); 1 = one update() + render() "
                     "per frame, which the default run also measures and reports as `frame_by_frame`")
     ap.add_argument("--obj", default=None, help="render this Wavefront OBJ instead of the procedural atrium (e.g. the real Sponza); "
@@ -512,7 +512,7 @@ def main():
     live = {}
     if world == 1 and not args.no_roofline and not args.no_live_pmc and args.partition == "samples" and args.workload == "c2":
         t_live = time.perf_counter()
-        n_sets_ = (args.steps + max(1, min(args.batch, 16)) - 1) // max(1, min(args.batch, 16))
+        n_sets_ = (args.steps + max(1, min(args.batch, 32)) - 1) // max(1, min(args.batch, 32))
         live["c2"] = live_traffic("c2", args.width, args.height, budget_s=100.0, per_set=(args.steps + n_sets_ - 1) // n_sets_)
         if args.hbm_frames > 0:           # (the 10 M-triangle child runs take ~30 s each: the two traffic passes only)
             live["c5"] = live_traffic("c5", args.width, args.height, budget_s=max(20.0, 190.0 - (time.perf_counter() - t_live)), passes=("ea", "write"))
@@ -576,7 +576,7 @@ def main():
     pipe.set_accumulation_mode(T.ACCUM_SUM if world > 1 else T.ACCUM_RUNNING_MEAN)
 
     # frames per set of launches: the K timed frames go through ceil(K / batch) sets of (almost) equal size
-    n_sets = (K + max(1, min(args.batch, 16)) - 1) // max(1, min(args.batch, 16))
+    n_sets = (K + max(1, min(args.batch, 32)) - 1) // max(1, min(args.batch, 32))
     S = (K + n_sets - 1) // n_sets
 
     def step(i):

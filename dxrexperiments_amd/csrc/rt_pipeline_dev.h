@@ -59,7 +59,7 @@ struct LightRays {
     float point_pos[3];         // pointLight.worldPos
 };
 
-#define RT_MAX_BATCH 16u                // frames one set of launches renders (rt_pipeline_render_batch)
+#define RT_MAX_BATCH 32u                // frames one set of launches renders (rt_pipeline_render_batch)
 
 struct PipeDev {
     SceneDev sc;

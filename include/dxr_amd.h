@@ -197,7 +197,7 @@ int rt_pipeline_update(rt_pipeline *p, const rt_per_frame_constants *constants);
 /* render(cmdList, frameIndex, w, h) (.cpp:215-247): one 1-spp progressive frame. */
 int rt_pipeline_render(rt_pipeline *p, uint32_t width, uint32_t height);
 /* n frames = n x { update(&constants[i]); render(w, h) } with the same bits in the output, rendered through SHARED sets of
- * launches (up to 16 frames each): the sample-batch mode of BASELINE configs[2] (256 spp accumulated).  The reference issues one
+ * launches (up to 32 frames each): the sample-batch mode of BASELINE configs[2] (256 spp accumulated).  The reference issues one
  * DispatchRays per frame (src/ProgressiveRaytracingPipeline.cpp:188-195, :244) and RayGen folds each frame into gOutput
  * with that frame's accumCount (assets/shaders/ProgressiveRaytracing.hlsl:36-38); here the rays of the frames of a batch
  * share the ray queues (a slot's frame selects constants, lights and RNG seed), so the persistent traversal launches and

@@ -3,7 +3,7 @@
 The reference renders one DispatchRays per frame and folds it into gOutput with that frame's accumCount
 (src/ProgressiveRaytracingPipeline.cpp:188-195, assets/shaders/ProgressiveRaytracing.hlsl:36-38).  The batch mode (BASELINE
 configs[2]: 256 spp accumulated) puts the rays of up to 8 frames into the same queues; the image and the ray counts must
-not be able to tell.  Covered: partial batches, chunking beyond 8, multi-bounce paths (the level-by-level resolve), the
+not be able to tell.  Covered: partial batches, sets of the maximum size (32) and chunking beyond it, multi-bounce paths (the level-by-level resolve), the
 debug / AO views (their own queue layouts), instanced two-level scenes, frames past maxIterations, SUM accumulation, and
 config 3 end to end on one device (8 logical shards x 32 frames)."""
 import numpy as np
@@ -39,7 +39,7 @@ def both_ways(p, pfcs):
     return batched
 
 
-@pytest.mark.parametrize("n", [1, 2, 5, 8, 11])
+@pytest.mark.parametrize("n", [1, 2, 5, 8, 11, 32, 35])
 def test_cornell_batches(gpu, capi, n):
     W = H = 64
     m = capi.Model(gpu, path=CORNELL_OBJ)
@@ -198,4 +198,4 @@ def test_reserve_batch(gpu, capi):
     with pytest.raises(capi.RtError):
         p.reserve_batch(0)
     with pytest.raises(capi.RtError):
-        p.reserve_batch(17)
+        p.reserve_batch(33)

@@ -289,13 +289,13 @@ def test_bench_obj_workload(capi):
 
 
 def test_bench_frame_sets():
-    """bench.py splits its K timed frames evenly over ceil(K / --batch) sets of launches (at most 16 frames each)"""
+    """bench.py splits its K timed frames evenly over ceil(K / --batch) sets of launches (at most 32 frames each)"""
     import re
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert re.search(r'"--batch", type=int, default=16', src)
+    assert re.search(r'"--batch", type=int, default=32', src)
     def split(K, batch):
-        n_sets = (K + max(1, min(batch, 16)) - 1) // max(1, min(batch, 16))
+        n_sets = (K + max(1, min(batch, 32)) - 1) // max(1, min(batch, 32))
         return n_sets, (K + n_sets - 1) // n_sets
-    assert split(20, 16) == (2, 10) and split(60, 16) == (4, 15) and split(5, 16) == (1, 5) and split(20, 1) == (20, 1) and split(64, 99) == (4, 16)
+    assert split(20, 32) == (1, 20) and split(60, 32) == (2, 30) and split(20, 16) == (2, 10) and split(5, 32) == (1, 5) and split(20, 1) == (20, 1) and split(128, 99) == (4, 32)
     # ... and that is the expression bench.py uses
-    assert "n_sets = (K + max(1, min(args.batch, 16)) - 1) // max(1, min(args.batch, 16))" in src and "S = (K + n_sets - 1) // n_sets" in src
+    assert "n_sets = (K + max(1, min(args.batch, 32)) - 1) // max(1, min(args.batch, 32))" in src and "S = (K + n_sets - 1) // n_sets" in src
