@@ -47,6 +47,7 @@ VALU_ISSUE_CYCLES = 2.0        # a wave64 VALU instruction occupies a SIMD-32 fo
 # SIMD (2.66 at eight, 2.71 at five, 3.25 at three, 7.9 for one wave alone).  The live class counters (SQ_INSTS_VALU_*) are
 # reported beside it so that the shares can be compared; the additive per-class prices (an upper bound on the cost) likewise.
 VALU_MIX_CYCLES = 2.65
+HBM_SET = 8                    # frames per set of launches of the 10 M-triangle workload
 VALU_MIX_STREAM_SHARES = {"ADD_F32": 3 / 32, "MUL_F32": 3 / 32, "FMA_F32": 5 / 32, "CVT": 4 / 32, "INT32": 5 / 32, "TRANS_F32": 0.0, "other": 12 / 32}
 VALU_CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.0, "SQ_INSTS_VALU_MUL_F32": 2.0, "SQ_INSTS_VALU_FMA_F32": 4.0, "SQ_INSTS_VALU_CVT": 4.0,
                      "SQ_INSTS_VALU_INT32": 2.0, "SQ_INSTS_VALU_TRANS_F32": 8.0}
@@ -219,7 +220,7 @@ def live_traffic(workload, width, height, budget_s=110.0, passes=("ea", "write",
     child = [os.path.join(here, "bench.py"), "--cpu-seconds", "0", "--no-roofline", "--no-live-pmc"]
     child += (["--steps", str(8 if per_set == 1 else 4 * per_set), "--warmup", str(2 if per_set == 1 else per_set), "--batch", str(per_set),
                "--hbm-frames", "0", "--width", str(width), "--height", str(height)] if workload == "c2"
-              else ["--workload", "c5", "--hbm-frames", "2"])
+              else ["--workload", "c5", "--hbm-frames", "2"] if per_set == 1 else ["--workload", "c5", "--hbm-frames", str(per_set), "--batch", str(per_set)])
     out, t0 = {}, time.perf_counter()
     env = dict(os.environ, TMPDIR="/tmp")
     for name in passes:
@@ -315,7 +316,7 @@ def stage_table(pipe, tot, with_canonical=True, levels=1):
     return stages, n_t
 
 
-def hbm_workload(ctx, capi, T, scenes, frames, warm, batch=1):
+def hbm_workload(ctx, capi, T, scenes, frames, warm, batch=1, one_frame_walk=True):
     """The one configuration whose traversal working set (~0.8 GB of slabs + triangle records) does not fit the 256 MB
     Infinity Cache: BASELINE configs[4], the 10 M-triangle mesh at 3840x2160 with 4 radiance bounces (SURVEY 7 "Roofline
     honesty").  Rendered on the same context after the headline measurement; returns the stage table of `frames` frames."""
@@ -362,11 +363,15 @@ def hbm_workload(ctx, capi, T, scenes, frames, warm, batch=1):
     ctx.synchronize()
     dt = time.perf_counter() - t0
     tot = pipe.totals()
+    if batch > 1 and one_frame_walk:           # (the walk counters of the stage table are those of ONE frame: the next one, by itself, after the timed region;
+                                               #  not under the profiler: every launch of a counter pass covers a whole set)
+        pipe.update(host.update(cam, 0.0, warm + frames + 1, W, H))
+        pipe.render()
     stages, n_t = stage_table(pipe, tot, with_canonical=False, levels=4)
     rays = tot["rays_primary"] + tot["rays_secondary"] + tot["rays_shadow"] - tot["rays_shadow_skipped"]      # rays actually traversed
     return {"workload": "BASELINE configs[4] on one GPU: displaced-grid mesh (seed 7, %d triangles), %dx%d, 4 radiance bounces, "
                         "1 spp/frame" % (tri.shape[0], W, H),
-            "frames": frames, "ms_per_frame": dt / frames * 1e3, "Mrays_per_s": rays / dt / 1e6, "rays_per_frame": rays / frames,
+            "frames": frames, "frames_per_launch_set": min(batch, frames) if batch > 1 else 1, "ms_per_frame": dt / frames * 1e3, "Mrays_per_s": rays / dt / 1e6, "rays_per_frame": rays / frames,
             "bvh_build_ms": scene.build_ms(), "generate_s": gen_s, "stages": stages, "launches_timed": n_t}
 
 
@@ -515,7 +520,8 @@ def main():
         n_sets_ = (args.steps + max(1, min(args.batch, 32)) - 1) // max(1, min(args.batch, 32))
         live["c2"] = live_traffic("c2", args.width, args.height, budget_s=100.0, per_set=(args.steps + n_sets_ - 1) // n_sets_)
         if args.hbm_frames > 0:           # (the 10 M-triangle child runs take ~30 s each: the two traffic passes only)
-            live["c5"] = live_traffic("c5", args.width, args.height, budget_s=max(20.0, 190.0 - (time.perf_counter() - t_live)), passes=("ea", "write"))
+            live["c5"] = live_traffic("c5", args.width, args.height, budget_s=max(20.0, 190.0 - (time.perf_counter() - t_live)), passes=("ea", "write"),
+                                      per_set=HBM_SET if args.batch > 1 else 1)
 
     import numpy as np
     import torch
@@ -538,7 +544,7 @@ def main():
     if args.workload == "c5":            # profiling passes: only the HBM-bound workload, one JSON line of its own
         assert world == 1, "--workload c5 is a single-GPU profiling mode"
         ctx = capi.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-        h = hbm_workload(ctx, capi, T, scenes, max(args.hbm_frames, 1), 2, batch=args.batch if args.batch_given else 1)
+        h = hbm_workload(ctx, capi, T, scenes, max(args.hbm_frames, 1), 2, batch=args.batch if args.batch_given else 1, one_frame_walk=not args.no_roofline)
         print(json.dumps({"metric": "Mrays/s, 10 M triangles 4K 4-bounce (roofline workload)", "value": h["Mrays_per_s"], "unit": "Mrays/s",
                           "n_gpus": 1, "roofline_hbm": h}))
         return
@@ -772,15 +778,18 @@ def main():
                                              "%d per set of launches (rt_pipeline_render_batch)" % S}
         if world == 1 and args.hbm_frames > 0 and not args.no_roofline:
             del pipe, scene, model
-            h = hbm_workload(ctx, capi, T, scenes, args.hbm_frames, 2)
+            hb = HBM_SET if S > 1 else 1                       # like the headline: sets of frames (8: the queues of a 4K 4-bounce frame are 4 GB)
+            h = hbm_workload(ctx, capi, T, scenes, args.hbm_frames, 2, batch=hb)
             dom = max(TRACE_STAGES, key=lambda s: h["stages"][s]["avg_ms"])
             d = h["stages"][dom]
-            prof5 = committed_profile("c5")
+            prof5 = committed_profile("c5b" if hb > 1 else "c5")
             k5 = prof5.get("kernels", {}).get(d["kernel"], {})
             lv5 = live.get("c5", {}).get(d["kernel"], {})
+            fpl5 = float(hb) if lv5 else float(k5.get("frames_per_launch", 1))         # frames per launch in the counter passes
             traffic = lv5.get("bytes_per_launch", k5.get("bytes_per_launch"))
+            traffic = traffic / fpl5 if traffic else traffic                            # ... per frame, like the stage time
             prof_us = k5.get("avg_us")
-            live_ms = d["avg_ms"] / d["launches_per_frame"]          # the stage time covers one launch per radiance level
+            live_ms = d["avg_ms"] / d["launches_per_frame"]          # per frame; the stage time covers one launch per radiance level
             h["roofline"] = {"bound": "hbm", "kernel": d["kernel"], "stage": dom, "launches_per_frame": d["launches_per_frame"],
                              # memory-side bytes per launch (PMC passes of THIS workload, profiles/<round>/traffic.json: read requests
                              # by size + WRITE_SIZE) / this run's HIP-event duration of the same launches; the profiling session's own
@@ -788,7 +797,8 @@ def main():
                              "achieved": traffic / (live_ms * 1e-3) / 1e9 if traffic else None,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": traffic / (live_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
-                             "traffic": traffic, "avg_launch_ms": live_ms, "launches_timed": h["launches_timed"],
+                             "traffic": traffic, "avg_launch_ms": live_ms * h["frames_per_launch_set"], "avg_ms_per_frame": live_ms,
+                             "frames_per_launch": h["frames_per_launch_set"], "frames_timed": h["launches_timed"],
                              "traffic_source": ("this run: %d launches under rocprofv3 --pmc (read requests by size, WRITE_SIZE)" % lv5["dispatches"])
                                                if "bytes_per_launch" in lv5 else "committed profile",
                              "traffic_committed_profile": k5.get("bytes_per_launch"),

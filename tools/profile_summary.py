@@ -43,7 +43,7 @@ def main():
     for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)):
         per = defaultdict(list)
         for r in csv.DictReader(open(f)):
-            m = re.search(r"(k_primary|k_trace_secondary|k_trace_shadow)<([^>]*)>", r["Kernel_Name"])
+            m = re.search(r"(?<![a-z_])(k_primary|k_trace_secondary|k_trace_shadow)<([^>]*)>", r["Kernel_Name"])
             if m:
                 per["%s<%s>" % (m.group(1), m.group(2).replace(" ", ""))].append((float(r["Start_Timestamp"]), float(r["End_Timestamp"]) - float(r["Start_Timestamp"])))
         if per:
