@@ -50,10 +50,19 @@ int main(int argc, char **argv)
         pipeline->buildAccelerationStructures();
 
         const auto t0 = std::chrono::steady_clock::now();
-        for (UINT frame = 1; frame <= frames; ++frame) {               // the first rendered frame has frameCount 1
-            pipeline->update(0.0f, frame, (frame + 2) % 3, frame % 3, width, height);
-            pipeline->render(frame % 3, width, height);
-        }
+        // DXR_SETS=n (1..32): the frames go through shared sets of launches, n at a time (renderBatch: the same image bit for bit,
+        // a quarter less time); default: one update + render per frame as the reference's app loop issues them
+        const char *sets_env = std::getenv("DXR_SETS");
+        const UINT per_set = sets_env ? (UINT)std::atoi(sets_env) : 1u;
+        if (per_set > 1) {
+            pipeline->reserveBatch(per_set < frames ? per_set : frames, width, height);
+            for (UINT first = 1; first <= frames; first += per_set)
+                pipeline->renderBatch(0.0f, first, first + per_set - 1 <= frames ? per_set : frames - first + 1, width, height);
+        } else
+            for (UINT frame = 1; frame <= frames; ++frame) {           // the first rendered frame has frameCount 1
+                pipeline->update(0.0f, frame, (frame + 2) % 3, frame % 3, width, height);
+                pipeline->render(frame % 3, width, height);
+            }
         std::vector<float> image(size_t(width) * height * 4);
         pipeline->readOutput(image.data(), image.size() * sizeof(float));
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

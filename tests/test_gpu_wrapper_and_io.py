@@ -62,6 +62,14 @@ def test_headless_example_writes_pfm(tmp_path):
     assert "Million Primary Rays/s" in r.stdout and "Progressive Ray Tracing Pipeline" in r.stdout
     data = open(out, "rb").read()
     assert data.startswith(b"PF\n96 64\n-1.0\n") and len(data) == len(b"PF\n96 64\n-1.0\n") + 96 * 64 * 12
+    # DXR_SETS=n: the same frames through shared sets of launches (renderBatch of the C++ mirror): the same file, byte for byte
+    out2 = tmp_path / "out_sets.pfm"
+    r = subprocess.run([exe, CORNELL_OBJ, "96", "64", "7", str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    r = subprocess.run([exe, CORNELL_OBJ, "96", "64", "7", str(out2)], env=dict(os.environ, DXR_SETS="3"), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    assert open(out, "rb").read() == open(out2, "rb").read()
 
 
 def write_dds_cube(path, faces, fmt):
