@@ -103,8 +103,18 @@ __device__ int g_trace_sel;
 // it is therefore issued right BEHIND them (the step waits with vmcnt(1), the touch stays in flight during the step's
 // arithmetic and has a whole step to land) and its value is "consumed" by an empty asm one step later, which keeps the
 // destination register reserved until then.
+// -DRT_PREFETCH_LEAF (second half of round 3): the same touch, but only where it is nearly free -- at the start of a leaf phase,
+// ahead of the triangle loads, for the node this lane will pop when the leaf is done (known when the step that led here pushed it).
+// Measured: +2 % in sets of frames (a live register more than the 72 of seven waves hold), +-0 frame by frame, +0.8 % on the
+// 10 M-triangle scene (profiles/r03/prefetch_leaf.txt): off.
+#if defined(RT_PREFETCH_LEAF) && !defined(RT_PREFETCH_ANY)
+#define RT_PREFETCH_ANY
+#endif
+#if defined(RT_PREFETCH_POP) && !defined(RT_PREFETCH_ANY)
+#define RT_PREFETCH_ANY
+#endif
 struct PopPrefetch {
-#ifdef RT_PREFETCH_POP
+#ifdef RT_PREFETCH_ANY
     int code;           // node to touch behind the next node loads (RT_NODE_EMPTY: none)
     float val;          // destination of the touch in flight
 #endif
@@ -358,7 +368,7 @@ RT_DEV void wide_step(const WNode *nodes, const int *top, uint32_t top_lim, cons
     if (p3) { if (DEEP) st.write(sp, c[3]); else st.lds[sp * BLOCK] = c[3]; sp++; }
     if (p2) { if (DEEP) st.write(sp, c[2]); else st.lds[sp * BLOCK] = c[2]; sp++; }
     if (p1) { if (DEEP) st.write(sp, c[1]); else st.lds[sp * BLOCK] = c[1]; sp++; }
-#ifdef RT_PREFETCH_POP
+#ifdef RT_PREFETCH_ANY
     // the new top of the stack, if this step pushed one (else: what was touched before, or unknown after a pop)
     pf.code = p1 ? c[1] : (p2 ? c[2] : (p3 ? c[3] : RT_NODE_EMPTY));
 #endif
@@ -487,7 +497,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
     int node = RT_NODE_EMPTY;
     int sp = 0;
     PopPrefetch pf;
-#ifdef RT_PREFETCH_POP
+#ifdef RT_PREFETCH_ANY
     pf.code = RT_NODE_EMPTY; pf.val = 0.0f;
 #endif
     // two-level state
@@ -546,7 +556,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     cur.o = r.o; cur.d = r.d; cur.ri = wri;
                     node = root0;
                     sp = 0;
-#ifdef RT_PREFETCH_POP
+#ifdef RT_PREFETCH_ANY
                     pf.code = RT_NODE_EMPTY;
 #endif
                     if (TWO_LEVEL) {
@@ -680,7 +690,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                         alive = true;
                         // home: the victim's home if the victim is itself walking a part, else the victim
                         meta = META_THIEF | ((p_meta & META_THIEF) != 0u ? (p_meta & META_HOME) : (uint32_t)from);
-#ifdef RT_PREFETCH_POP
+#ifdef RT_PREFETCH_ANY
                         pf.code = RT_NODE_EMPTY;
 #endif
                     }
@@ -754,7 +764,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
             } else if (TWO_LEVEL && node == RT_NODE_SENTINEL) {
                 in_blas = false;
                 nodes = sc.tlas_wide;
-#ifdef RT_PREFETCH_POP
+#ifdef RT_PREFETCH_ANY
                 pf.code = RT_NODE_EMPTY;                     // (codes of the structure just left)
 #endif
                 top_lim = sc.top_n;
@@ -774,7 +784,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 if (enter) {
                     cur = to_object(*in, r);
                     nodes = in->wide;
-#ifdef RT_PREFETCH_POP
+#ifdef RT_PREFETCH_ANY
                     pf.code = RT_NODE_EMPTY;
 #endif
                     tris = in->tris;
@@ -796,6 +806,13 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
             } else {
                 const uint32_t code = (uint32_t)~node;
                 const uint32_t first_tri = code >> 3, cnt = (code & 7u) + 1u;
+#ifdef RT_PREFETCH_LEAF
+                // the node this lane pops after the leaf: its line is asked for now, ahead of the triangle records (loads return in
+                // order: the wait for the records covers it), so that the pop finds it in the L2 at least
+                if (sp > 0 && (uint32_t)pf.code >= top_lim && pf.code >= 0 && pf.code < RT_NODE_EMPTY)
+                    pf.val = *(const __attribute__((address_space(1))) float *)((const char *)nodes + ((uint32_t)pf.code << 6));
+                pf.code = RT_NODE_EMPTY;
+#endif
                 for (uint32_t k = 0; k < cnt; k++) {
                     RT_STAT_WAVE(2); RT_STAT_LANE(2);
                     if (COUNT) { wk_tri++; const uint32_t by = (first_tri + k) * 48u; wk_lines += 1u + ((by & 63u) > 16u ? 1u : 0u); }   // a 48-B record spans one or two lines
@@ -815,6 +832,9 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     }
                 }
             }
+#ifdef RT_PREFETCH_LEAF
+            asm volatile("" :: "v"(pf.val));
+#endif
             if (pop) {
                 if (sp > 0) { sp--; node = st.read(sp); }
                 else node = RT_NODE_EMPTY;
