@@ -668,7 +668,9 @@ def main():
             dom = max(TRACE_STAGES, key=lambda s: stages[s]["avg_ms"])
             d = stages[dom]
             prof_name = "c2" if S == 1 else "c2b"
-            prof = committed_profile(prof_name).get("kernels", {}).get(d["kernel"], {})
+            # (the committed counters are those of the default workload: they stand in for live ones only when this run is that workload)
+            default_workload = (W, H) == (1920, 1080) and not args.obj and not args.camera
+            prof = committed_profile(prof_name).get("kernels", {}).get(d["kernel"], {}) if default_workload else {}
             lv = live.get("c2", {}).get(d["kernel"], {})
             # a launch covers a set of frames: stage times are per frame (stage_table), hardware counters per launch
             fpl = float(S) if lv else float(prof.get("frames_per_launch", 1))     # frames per launch in the counter passes

@@ -171,6 +171,18 @@ def test_bench_two_ranks_on_one_gpu():
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     # weak scaling: two ranks trace twice the frames, i.e. about twice the rays per step
     assert abs(d["value"] * d["ms_per_step"] / (d1["value"] * d1["ms_per_step"]) - 2.0) < 0.05
+    # the single-GPU line carries the contract's objects: sets of frames as the entry point, frame by frame beside it, and a
+    # roofline whose fraction is achieved / peak of the same unit
+    assert d1["config"]["frames_per_launch_set"] == 4 and d1["config"]["launch_sets"] == 1 and d1["config"]["entry_point"] == "rt_pipeline_render_batch"
+    fb = d1["frame_by_frame"]
+    assert fb["frames"] == 4 and fb["ms_per_frame"] > 0 and fb["Mrays_per_s"] > 0
+    rl = d1["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "frames_per_launch", "memory_path"):
+        assert k in rl, k
+    assert rl["frac"] is None          # (no live counters asked for and not the default workload: the committed profile does not apply)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in d1 and key in d, key
+    assert json.loads(json.dumps(d1)) == d1          # (no NaN / Infinity in the line)
 
 
 def test_tile_partition_two_ranks_on_one_gpu():
