@@ -415,8 +415,8 @@ template <int STACK, int BLOCK, bool TWO_LEVEL, uint32_t CHUNK, bool ANYHIT = fa
 RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uint32_t *pool, int *smem, uint32_t *traced_counter,
                        unsigned long long *walk = nullptr)
 {
-    uint32_t n_traced = 0;           // rays this lane actually traversed (statistics)
-    uint32_t n_skipped = 0;          // any-hit launches: queue slots marked RT_TMAX_SKIPPED
+    uint32_t n_traced = 0;           // rays this WAVE actually traversed (statistics; wave-uniform: a scalar register, not a lane's)
+    uint32_t n_skipped = 0;          // any-hit launches: queue slots marked RT_TMAX_SKIPPED (likewise)
     uint32_t wk_glob = 0, wk_top = 0, wk_tri = 0, wk_inst = 0, wk_lines = 0;
     uint32_t wk_ray0 = 0;                        // node steps tallied when the lane's current ray started
     unsigned long long wk_longest = 0;           // (node steps << 32 | ray index) of the lane's longest walk
@@ -546,6 +546,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
             }
             const uint32_t avail = chunk_end - chunk_next;
             const uint32_t rank = (uint32_t)__popcll(idle & lanemask_lt());
+            bool started = false, skipped = false;
             if (!alive && rank < avail) {
                 const uint32_t my = chunk_next + rank;
                 idx = my;
@@ -566,13 +567,15 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 #endif
                     }
                     alive = true;
-                    n_traced++;
+                    started = true;
                     if (COUNT) wk_ray0 = wk_glob + wk_top;
                 } else {
-                    if (ANYHIT && r.tmax == RT_TMAX_SKIPPED) n_skipped++;
+                    if (ANYHIT && r.tmax == RT_TMAX_SKIPPED) skipped = true;
                     sink.store(my, best, traced);
                 }
             }
+            n_traced += (uint32_t)__popcll(__ballot(started));
+            if (ANYHIT) n_skipped += (uint32_t)__popcll(__ballot(skipped));
             chunk_next += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
         }
 #ifdef RT_TRACE_TIMES
@@ -851,7 +854,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
     }
 #endif
     if (COUNT && walk) {
-        unsigned long long w5[6] = {n_traced, wk_glob, wk_top, wk_tri, wk_inst, wk_lines};
+        unsigned long long w5[6] = {(threadIdx.x & 63u) == 0u ? n_traced : 0u, wk_glob, wk_top, wk_tri, wk_inst, wk_lines};
         for (int k = 0; k < 6; k++) {
             unsigned long long v = w5[k];
             for (int o = 32; o > 0; o >>= 1) v += (unsigned long long)__shfl_xor((long long)v, o, 64);
@@ -860,12 +863,8 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
         atomicMax(&walk[6], wk_longest);
     }
     if (traced_counter) {            // one no-return atomic per persistent wave
-        for (int o = 32; o > 0; o >>= 1) n_traced += (uint32_t)__shfl_xor((int)n_traced, o, 64);
         if ((threadIdx.x & 63u) == 0u && n_traced) atomicAdd(traced_counter, n_traced);
-        if (ANYHIT) {                // (the word behind an any-hit launch's ray counter tallies its skipped slots)
-            for (int o = 32; o > 0; o >>= 1) n_skipped += (uint32_t)__shfl_xor((int)n_skipped, o, 64);
-            if ((threadIdx.x & 63u) == 0u && n_skipped) atomicAdd(traced_counter + 1, n_skipped);
-        }
+        if (ANYHIT && (threadIdx.x & 63u) == 0u && n_skipped) atomicAdd(traced_counter + 1, n_skipped);       // (the word behind an any-hit launch's ray counter tallies its skipped slots)
     }
 }
 
