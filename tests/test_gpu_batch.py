@@ -2,7 +2,7 @@
 
 The reference renders one DispatchRays per frame and folds it into gOutput with that frame's accumCount
 (src/ProgressiveRaytracingPipeline.cpp:188-195, assets/shaders/ProgressiveRaytracing.hlsl:36-38).  The batch mode (BASELINE
-configs[2]: 256 spp accumulated) puts the rays of up to 8 frames into the same queues; the image and the ray counts must
+configs[2]: 256 spp accumulated) puts the rays of up to 32 frames into the same queues; the image and the ray counts must
 not be able to tell.  Covered: partial batches, sets of the maximum size (32) and chunking beyond it, multi-bounce paths (the level-by-level resolve), the
 debug / AO views (their own queue layouts), instanced two-level scenes, frames past maxIterations, SUM accumulation, and
 config 3 end to end on one device (8 logical shards x 32 frames)."""
