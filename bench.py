@@ -47,7 +47,7 @@ VALU_ISSUE_CYCLES = 2.0        # a wave64 VALU instruction occupies a SIMD-32 fo
 # SIMD (2.66 at eight, 2.71 at five, 3.25 at three, 7.9 for one wave alone).  The live class counters (SQ_INSTS_VALU_*) are
 # reported beside it so that the shares can be compared; the additive per-class prices (an upper bound on the cost) likewise.
 VALU_MIX_CYCLES = 2.65
-HBM_SET = 8                    # frames per set of launches of the 10 M-triangle workload
+HBM_SET = 16                   # frames per set of launches of the 10 M-triangle workload (8: 12.3 ms per frame, 16: 12.0; 4 GB of queues per frame)
 VALU_MIX_STREAM_SHARES = {"ADD_F32": 3 / 32, "MUL_F32": 3 / 32, "FMA_F32": 5 / 32, "CVT": 4 / 32, "INT32": 5 / 32, "TRANS_F32": 0.0, "other": 12 / 32}
 VALU_CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.0, "SQ_INSTS_VALU_MUL_F32": 2.0, "SQ_INSTS_VALU_FMA_F32": 4.0, "SQ_INSTS_VALU_CVT": 4.0,
                      "SQ_INSTS_VALU_INT32": 2.0, "SQ_INSTS_VALU_TRANS_F32": 8.0}
@@ -78,7 +78,7 @@ def parse(argv=None):
                     help="skip the frame_by_frame section (profiling passes: keeps the per-kernel averages to one kind of launch)")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not re-run a few frames under rocprofv3 for roofline.traffic; use the "
                     "committed profiles/<round>/traffic.json only")
-    ap.add_argument("--hbm-frames", type=int, default=8, help="frames of the HBM-bound 10 M-triangle 4K workload timed for roofline_hbm "
+    ap.add_argument("--hbm-frames", type=int, default=16, help="frames of the HBM-bound 10 M-triangle 4K workload timed for roofline_hbm "
                     "(rank 0, N=1 only); 0 = skip")
     ap.add_argument("--batch", type=int, default=32, help="frames per set of launches (rt_pipeline_render_batch, at most 32: the sample-batch mode "
                     "of BASELINE configs[2]; the K timed frames are split evenly over ceil(K / batch) sets); 1 = one update() + render() "
@@ -780,7 +780,7 @@ def main():
                                              "%d per set of launches (rt_pipeline_render_batch)" % S}
         if world == 1 and args.hbm_frames > 0 and not args.no_roofline:
             del pipe, scene, model
-            hb = HBM_SET if S > 1 else 1                       # like the headline: sets of frames (8: the queues of a 4K 4-bounce frame are 4 GB)
+            hb = HBM_SET if S > 1 else 1                       # like the headline: sets of frames
             h = hbm_workload(ctx, capi, T, scenes, args.hbm_frames, 2, batch=hb)
             dom = max(TRACE_STAGES, key=lambda s: h["stages"][s]["avg_ms"])
             d = h["stages"][dom]

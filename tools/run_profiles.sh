@@ -17,7 +17,7 @@ for w in $WL; do
   elif [ $w = c2 ]; then ARGS="--steps 8 --warmup 2 --batch 1 --cpu-seconds 0 --hbm-frames 0 --no-live-pmc";
   elif [ $w = c2b ]; then ARGS="--steps 60 --warmup 30 --cpu-seconds 0 --hbm-frames 0 --no-live-pmc --no-frame-by-frame --no-roofline";       # the headline launches only: sets of 30 frames
   elif [ $w = c5 ]; then ARGS="--workload c5 --hbm-frames 4 --no-live-pmc";
-  elif [ $w = c5b ]; then ARGS="--workload c5 --hbm-frames 8 --batch 8 --no-live-pmc --no-roofline";
+  elif [ $w = c5b ]; then ARGS="--workload c5 --hbm-frames 16 --batch 16 --no-live-pmc --no-roofline";
   else PROG=$R/tools/profile_c4.py; ARGS="4"; fi
   run() {   # name, rocprof options...
     n=$1; shift

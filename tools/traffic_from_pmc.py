@@ -41,7 +41,7 @@ def main():
                          "Infinity-Cache hits are included (MI355X_MICROARCH.md, HBM section)",
            "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, text=True).stdout.strip(),
            "workloads": {}}
-    for w in ("c2", "c5", "c4", "c2b", "c5b"):          # (c2b / c5b: the same workloads at 30 / 8 frames per set of launches)
+    for w in ("c2", "c5", "c4", "c2b", "c5b"):          # (c2b / c5b: the same workloads at 30 / 16 frames per set of launches)
         kt, fe, wr = rows("%s/%s_kt.md" % (d, w)), rows("%s/%s_fetch.md" % (d, w)), rows("%s/%s_write.md" % (d, w))
         tcc, sq, ea = rows("%s/%s_tcc.md" % (d, w)), rows("%s/%s_sq.md" % (d, w)), rows("%s/%s_ea.md" % (d, w))
         tcp, ta2 = rows("%s/%s_tcp.md" % (d, w)), rows("%s/%s_ta2.md" % (d, w))
@@ -69,7 +69,7 @@ def main():
             else:
                 e["bytes_per_launch"] = e["bytes_per_launch_fetch_x2"]
             if w.endswith("b"):
-                e["frames_per_launch"] = 30 if w == "c2b" else 8          # (tools/run_profiles.sh: c2b = the bench default's sets of 30, c5b = --batch 8)
+                e["frames_per_launch"] = 30 if w == "c2b" else 16         # (tools/run_profiles.sh: c2b = the bench default's sets of 30, c5b = --batch 16)
             if (k, "avg_us") in kt:
                 e["avg_us"] = kt[(k, "avg_us")]
                 e["GBps"] = e["bytes_per_launch"] / (e["avg_us"] * 1e-6) / 1e9
