@@ -141,6 +141,7 @@ SIGNATURES = {
     "rt_progressive_host_options": (_i, [_p, _pp]),
     "rt_progressive_host_set_flags": (_i, [_p, _i, _i]),
     "rt_image_write_pfm": (_i, [C.c_char_p, _p, _u32, _u32]),
+    "rt_image_write_exr": (_i, [C.c_char_p, _p, _u32, _u32]),
     "rt_image_write_png": (_i, [C.c_char_p, _p, _u32, _u32, _f, _f, _i]),
     "rt_progressive_host_reset": (_i, [_p]),
     "rt_progressive_host_save_state": (_i, [_p, _p, _sz, C.POINTER(_sz)]),
@@ -757,6 +758,13 @@ def write_pfm(path, image):
     """fp32 RGB portable float map of an (H, W, 4) float32 image."""
     img = np.ascontiguousarray(image, np.float32)
     _check(lib().rt_image_write_pfm(os.fsencode(path), _ptr(img), img.shape[1], img.shape[0]))
+
+
+def write_exr(path, image):
+    """(H, W, 4) float32 -> lossless OpenEXR (FLOAT channels A B G R, no compression)."""
+    img = np.ascontiguousarray(image, np.float32)
+    assert img.ndim == 3 and img.shape[2] == 4
+    _check(lib().rt_image_write_exr(os.fsencode(path), _ptr(img), img.shape[1], img.shape[0]))
 
 
 def write_png(path, image, exposure=1.0, gamma=2.2, tonemap=True):

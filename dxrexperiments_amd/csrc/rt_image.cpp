@@ -2,13 +2,16 @@
 //
 // The reference only ever shows its outputs in a window (CopyResource to the back buffer,
 // src/DXRExperimentsApp.cpp:213-214); a headless engine needs files.  Two formats, both
-// written without external libraries:
+// written without external libraries (round 3: three -- OpenEXR, the format every renderer-side tool reads):
+//   EXR  lossless fp32 RGBA: single-part scan-line OpenEXR 2.0, no compression, channels A B G R (the file format's
+//        alphabetical order), one scan line per chunk, rows top to bottom;
 //   PFM  lossless fp32 RGB, the accumulation image as it is (rows bottom to top, little endian);
 //   PNG  8-bit RGB for viewing: the DenoiseCompositor's display transform (exposure, optional
 //        Reinhard, gamma; DenoiseCommon.hlsli:29-41 in spirit -- host libm, not a parity path),
 //        zlib stream of stored blocks (no compression), CRC-32 / Adler-32 computed here.
 #include <math.h>
 #include <stdio.h>
+#include <string.h>
 
 #include <vector>
 
@@ -67,6 +70,49 @@ int rt_image_write_pfm(const char *path, const float *rgba32f, uint32_t width, u
         const float *src = rgba32f + (size_t)y * width * 4;
         for (uint32_t x = 0; x < width; x++) { row[3 * x] = src[4 * x]; row[3 * x + 1] = src[4 * x + 1]; row[3 * x + 2] = src[4 * x + 2]; }
         ok = fwrite(row.data(), sizeof(float), row.size(), f) == row.size();
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { rt_set_error("short write to %s", path); return RT_ERR_IO; }
+    return RT_OK;
+}
+
+int rt_image_write_exr(const char *path, const float *rgba32f, uint32_t width, uint32_t height)
+{
+    RT_REQUIRE(path && rgba32f, "null argument");
+    RT_REQUIRE(width > 0 && height > 0 && width < (1u << 30) && height < (1u << 30), "bad image size");
+    std::vector<uint8_t> h;
+    auto bytes = [&](const void *p, size_t n) { h.insert(h.end(), (const uint8_t *)p, (const uint8_t *)p + n); };
+    auto str = [&](const char *z) { bytes(z, strlen(z) + 1); };
+    auto i32 = [&](int32_t v) { bytes(&v, 4); };            // (little endian host, like everything else here)
+    auto f32 = [&](float v) { bytes(&v, 4); };
+    auto attr = [&](const char *name, const char *type, int32_t size) { str(name); str(type); i32(size); };
+    const uint8_t magic[8] = {0x76, 0x2f, 0x31, 0x01, 2, 0, 0, 0};        // 20000630, version 2, no flags: single-part scan-line file
+    bytes(magic, 8);
+    attr("channels", "chlist", 4 * 18 + 1);
+    for (const char *c : {"A", "B", "G", "R"}) { str(c); i32(2 /* FLOAT */); const uint8_t lin[4] = {0, 0, 0, 0}; bytes(lin, 4); i32(1); i32(1); }
+    h.push_back(0);
+    attr("compression", "compression", 1); h.push_back(0);                 // NO_COMPRESSION
+    attr("dataWindow", "box2i", 16); i32(0); i32(0); i32((int32_t)width - 1); i32((int32_t)height - 1);
+    attr("displayWindow", "box2i", 16); i32(0); i32(0); i32((int32_t)width - 1); i32((int32_t)height - 1);
+    attr("lineOrder", "lineOrder", 1); h.push_back(0);                     // INCREASING_Y
+    attr("pixelAspectRatio", "float", 4); f32(1.0f);
+    attr("screenWindowCenter", "v2f", 8); f32(0.0f); f32(0.0f);
+    attr("screenWindowWidth", "float", 4); f32(1.0f);
+    h.push_back(0);                                                         // end of header
+    const uint64_t line_bytes = (uint64_t)width * 16, chunk = 8 + line_bytes;
+    const uint64_t first = h.size() + (uint64_t)height * 8;
+    for (uint32_t y = 0; y < height; y++) { const uint64_t off = first + y * chunk; bytes(&off, 8); }
+    FILE *f = fopen(path, "wb");
+    if (!f) { rt_set_error("cannot create %s", path); return RT_ERR_IO; }
+    bool ok = fwrite(h.data(), 1, h.size(), f) == h.size();
+    std::vector<float> row((size_t)width * 4);
+    static const int channel_of[4] = {3, 2, 1, 0};                          // file order A B G R <- memory order R G B A
+    for (uint32_t y = 0; ok && y < height; y++) {
+        const float *src = rgba32f + (size_t)y * width * 4;
+        for (int c = 0; c < 4; c++)
+            for (uint32_t x = 0; x < width; x++) row[(size_t)c * width + x] = src[4 * (size_t)x + channel_of[c]];
+        const int32_t head[2] = {(int32_t)y, (int32_t)line_bytes};
+        ok = fwrite(head, 4, 2, f) == 2 && fwrite(row.data(), sizeof(float), row.size(), f) == row.size();
     }
     ok = (fclose(f) == 0) && ok;
     if (!ok) { rt_set_error("short write to %s", path); return RT_ERR_IO; }

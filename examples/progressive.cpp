@@ -16,7 +16,7 @@ using namespace DXRFramework;
 int main(int argc, char **argv)
 {
     if (argc < 6) {
-        std::fprintf(stderr, "usage: %s model.obj width height frames out.pfm|out.png [eye xyz at xyz]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s model.obj width height frames out.pfm|out.exr|out.png [eye xyz at xyz]\n", argv[0]);
         return 2;
     }
     const UINT width = std::atoi(argv[2]), height = std::atoi(argv[3]), frames = std::atoi(argv[4]);
@@ -70,11 +70,13 @@ int main(int argc, char **argv)
         std::printf("%s: %u frames, %.2f fps, ~%.2f Million Primary Rays/s, BVH build %.2f ms\n", pipeline->getName(), frames, frames / s,
                     double(width) * height * frames / s / 1e6, scene->getBuildMilliseconds());
 
-        // .png -> 8-bit view through the compositor's display transform, anything else -> lossless fp32 PFM
+        // .png -> 8-bit view through the compositor's display transform, .exr -> lossless fp32 RGBA OpenEXR, anything else -> lossless fp32 PFM
         const std::string out = argv[5];
         const bool png = out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0;
+        const bool exr = out.size() > 4 && out.compare(out.size() - 4, 4, ".exr") == 0;
         DXRFramework::ThrowIfFailed(png ? rt_image_write_png(out.c_str(), image.data(), width, height, 1.0f, 2.2f, 1)
-                                        : rt_image_write_pfm(out.c_str(), image.data(), width, height));
+                                    : exr ? rt_image_write_exr(out.c_str(), image.data(), width, height)
+                                          : rt_image_write_pfm(out.c_str(), image.data(), width, height));
     } catch (const std::exception &e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -329,6 +329,8 @@ int rt_dist_device_pci_bus_id(const rt_context *ctx, char *out, size_t capacity)
 
 /* ---- image files for host copies of the outputs (the reference only blits to its window,
  *      src/DXRExperimentsApp.cpp:213-214).  rgba32f = width*height float4, row 0 on top. ---------------- */
+/* lossless fp32 RGBA OpenEXR (single-part scan-line file, no compression, FLOAT channels A B G R) */
+int rt_image_write_exr(const char *path, const float *rgba32f, uint32_t width, uint32_t height);
 /* lossless fp32 RGB portable float map */
 int rt_image_write_pfm(const char *path, const float *rgba32f, uint32_t width, uint32_t height);
 /* 8-bit RGB PNG for viewing: v*exposure, optional Reinhard v/(1+v), v^(1/gamma) (the compositor's display

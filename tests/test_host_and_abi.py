@@ -134,7 +134,7 @@ def test_host_state_round_trip(capi):
 
 
 def test_image_writers(capi, tmp_path):
-    """PFM is lossless; the PNG decodes (zlib stream, CRCs) to the display transform of the image."""
+    """PFM and EXR are lossless; the PNG decodes (zlib stream, CRCs) to the display transform of the image."""
     import struct
     import zlib
     r = np.random.default_rng(8)
@@ -167,6 +167,37 @@ def test_image_writers(capi, tmp_path):
     assert np.abs(got - want).max() <= 0.51
     with pytest.raises(capi.RtError):
         capi.write_png(str(tmp_path / "no" / "dir.png"), img)
+    # OpenEXR: parsed here from the published file layout (magic, version, attribute list, offset table, one scan line per
+    # chunk, channels in alphabetical order) -- lossless, alpha included
+    exr = str(tmp_path / "a.exr")
+    capi.write_exr(exr, img)
+    raw = open(exr, "rb").read()
+    assert struct.unpack("<I", raw[:4])[0] == 20000630 and raw[4:8] == b"\x02\x00\x00\x00"
+    pos, attrs = 8, {}
+    while raw[pos] != 0:
+        e = raw.index(b"\0", pos); name = raw[pos:e].decode(); pos = e + 1
+        e = raw.index(b"\0", pos); typ = raw[pos:e].decode(); pos = e + 1
+        n = struct.unpack("<i", raw[pos:pos + 4])[0]
+        attrs[name] = (typ, raw[pos + 4:pos + 4 + n]); pos += 4 + n
+    pos += 1
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    assert struct.unpack("<4i", attrs["dataWindow"][1]) == (0, 0, 52, 36) and attrs["dataWindow"] == attrs["displayWindow"]
+    ch, names = attrs["channels"][1], []
+    q = 0
+    while ch[q] != 0:
+        e = ch.index(b"\0", q); names.append(ch[q:e].decode())
+        assert struct.unpack("<i4Bii", ch[e + 1:e + 17]) == (2, 0, 0, 0, 0, 1, 1)         # FLOAT, not perceptually linear, sampling 1 x 1
+        q = e + 17
+    assert names == ["A", "B", "G", "R"] and q + 1 == len(ch)
+    offsets = struct.unpack("<37Q", raw[pos:pos + 37 * 8])
+    back = np.empty((37, 53, 4), np.float32)
+    for y, off in enumerate(offsets):
+        yy, nbytes = struct.unpack("<ii", raw[off:off + 8])
+        assert yy == y and nbytes == 53 * 16
+        line = np.frombuffer(raw[off + 8:off + 8 + nbytes], "<f4").reshape(4, 53)
+        back[y] = line[::-1].T                       # file order A B G R -> R G B A
+    assert offsets[-1] + 8 + 53 * 16 == len(raw)
+    assert np.array_equal(back, img, equal_nan=True)
 
 
 def test_scene_generators_are_deterministic():
