@@ -105,6 +105,7 @@ SIGNATURES = {
     "rt_pipeline_clear_output": (_i, [_p]),
     "rt_pipeline_update": (_i, [_p, _p]),
     "rt_pipeline_render": (_i, [_p, _u32, _u32]),
+    "rt_pipeline_set_shadow_cache": (_i, [_p, _i]),
     "rt_pipeline_render_batch": (_i, [_p, _u32, _u32, _p, _u32]),
     "rt_pipeline_reserve_batch": (_i, [_p, _u32, _u32, _u32]),
     "rt_pipeline_render_tile": (_i, [_p, _u32, _u32, _u32, _u32, _u32, _u32]),
@@ -516,6 +517,10 @@ class Pipeline:
         buf = np.ascontiguousarray(np.stack([np.frombuffer(np.asarray(c).tobytes(), np.uint8) for c in constants]))
         assert buf.shape[1] == 188
         _check(lib().rt_pipeline_render_batch(self.h, self.width, self.height, _ptr(buf), buf.shape[0]))
+
+    def set_shadow_cache(self, cells_per_side):
+        """Light buffer of occluders for shadow rays (same image, less time): -1 automatic, 0 off, else cells per side."""
+        _check(lib().rt_pipeline_set_shadow_cache(self.h, int(cells_per_side)))
 
     def reserve_batch(self, frames):
         """Size the ray queues for sets of `frames` frames now (the first render_batch of that size then allocates nothing)."""

@@ -83,10 +83,11 @@ struct PrimarySink {
     }
 };
 
-// (see RT_LDS_STACK_ROWS_SETS: the single-level instantiations with that many stack rows are compiled for seven waves per SIMD;
+// (see RT_LDS_STACK_ROWS_SETS: the single-level instantiations with that many stack rows are compiled for seven waves per SIMD,
+// the 18-row ones for the six their LDS allows (the any-hit kernel with the shadow cache would take 81 registers otherwise);
 // every other instantiation is left to the compiler -- a floor of 1 constrains nothing)
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU __attribute__((amdgpu_waves_per_eu(STACK == RT_LDS_STACK_ROWS_SETS && !TWO_LEVEL ? 7 : 1)))
+#define RT_WAVES_PER_EU __attribute__((amdgpu_waves_per_eu(TWO_LEVEL ? 1 : STACK == RT_LDS_STACK_ROWS_SETS ? 7 : STACK == RT_LDS_STACK_ROWS ? 6 : 1)))
 #endif
 template <int STACK, bool TWO_LEVEL, bool BATCH>
 __global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_primary(PipeDev pd)
@@ -311,6 +312,7 @@ struct ShadowQueues {
     uint32_t *vis[MAXD + 1];
     int nq;
     const LightRays *frame_lights;      // device array [n_frames] (batches)
+    ShadowCacheDev cache;
 };
 template <bool BATCH>
 struct ShadowSrcN : ShadowQueues {
@@ -335,6 +337,44 @@ struct ShadowSrcN : ShadowQueues {
         }
         r.o = mk3(0.0f, 0.0f, 0.0f); r.d = r.o; r.tmin = 0.0f; r.tmax = -1.0f;
         return false;
+    }
+    // ---- the shadow cache (ShadowCacheDev): where this ray's entry lives, what it holds, what to put there ----
+    RT_DEV uint32_t cache_slot(const RayD &r) const
+    {
+        const uint32_t res = cache.res;
+        if (!(r.tmax < 1.0e37f)) {          // the directional light's rays run to RAY_MAX_T, the point light's to the light
+            float u = r.o.x * cache.ua[0] + r.o.y * cache.ua[1] + r.o.z * cache.ua[2] + cache.ua[3];
+            float v = r.o.x * cache.va[0] + r.o.y * cache.va[1] + r.o.z * cache.va[2] + cache.va[3];
+            u = fminf(fmaxf(u, 0.0f), cache.res_f - 1.0f);
+            v = fminf(fmaxf(v, 0.0f), cache.res_f - 1.0f);
+            return (uint32_t)u * res + (uint32_t)v;
+        }
+        const float mx = r.o.x - cache.lp[0], my = r.o.y - cache.lp[1], mz = r.o.z - cache.lp[2];      // from the light to the point
+        const float ax = fabsf(mx), ay = fabsf(my), az = fabsf(mz);
+        uint32_t face;
+        float ma, s, t;
+        if (ax >= ay && ax >= az) { face = mx < 0.0f ? 1u : 0u; ma = ax; s = my; t = mz; }
+        else if (ay >= az) { face = my < 0.0f ? 3u : 2u; ma = ay; s = mz; t = mx; }
+        else { face = mz < 0.0f ? 5u : 4u; ma = az; s = mx; t = my; }
+        const float inv = __builtin_amdgcn_rcpf(ma), half = 0.5f * cache.res_f;       // (where an entry lives need not be rounded correctly)
+        const float cs = fminf(fmaxf((s * inv * 0.5f + 0.5f) * half, 0.0f), half - 1.0f);
+        const float ct = fminf(fmaxf((t * inv * 0.5f + 0.5f) * half, 0.0f), half - 1.0f);
+        const uint32_t r2 = res >> 1;
+        return res * res + (face * r2 + (uint32_t)cs) * r2 + (uint32_t)ct;
+    }
+    // (the slot is computed once, when the ray is loaded; the walk keeps it in a spare row of the lane's LDS stack until a hit wants it)
+    RT_DEV uint32_t cached_leaf(const RayD &r, uint32_t &slot) const
+    {
+        slot = RT_NO_HIT;
+        if (!cache.table) return RT_NO_HIT;
+        slot = cache_slot(r);
+        return cache.table[slot];
+    }
+    RT_DEV void remember(uint32_t slot, uint32_t sorted_triangle) const
+    {
+        // (a slot that the stack has overwritten in the meantime is some other number: inside the table it only makes a stale entry)
+        const uint32_t entries = cache.res * cache.res + 6u * (cache.res >> 1) * (cache.res >> 1);
+        if (cache.table && slot < entries) cache.table[slot] = sorted_triangle;
     }
 };
 struct ShadowSinkN {      // ShadowMiss sets visibility 1 (ProgressiveRaytracing.hlsl:178-182)
@@ -554,6 +594,72 @@ __global__ void k_debug_cube(PipeDev pd, const float *__restrict__ dirs, float *
 
 namespace {
 
+// The shadow cache of the coming launches (ShadowCacheDev): single-level scenes only (an entry is an index into the one sorted
+// triangle array); the table is cleared when the scene has changed (an index must stay inside the array), its directional cells
+// span the bounding sphere of the model, its basis follows the frame's light (entries of another direction are merely stale).
+int prepare_shadow_cache(rt_pipeline *p, const rt_per_frame_constants &pfc, const LightRays &lr)
+{
+    p->shadow_cache_dev = ShadowCacheDev{};
+    const rt_scene *s = p->scene;
+    if (p->shadow_cache_res == 0 || s->two_level || s->inst.empty() || !s->inst[0].model || s->inst[0].model->n_tris >= (1u << 28)) return RT_OK;
+    int want = p->shadow_cache_res;
+    if (want < 0) {                         // not set through the API: the environment, else by the size of the triangles
+        const char *e = getenv("RT_SHADOW_CACHE_RES");
+        want = e ? atoi(e) : -1;
+        if (want == 0) return RT_OK;
+    }
+    if (want < 0) {
+        // cells well below the triangles' size: 8 per sqrt(triangle count) across the scene, a power of two in [1024, 8192]
+        // (bench scene, 262 k triangles: 1024 / 2048 / 4096 / 8192 cells -> 1.80 / 1.74 / 1.70 / 1.72 ms per frame, off 1.87;
+        //  10 M triangles: 2048 -> 11.9, 8192 -> 10.9 ms, off 12.0; profiles/r03/shadow_cache*.txt)
+        const double target = 8.0 * sqrt((double)s->inst[0].model->n_tris);
+        want = 1024;
+        while (want < 8192 && (double)want < target) want *= 2;
+    }
+    if (want > 8192) want = 8192;
+    if (want < 16) want = 16;
+    const uint32_t res = (uint32_t)want & ~1u;
+    const size_t entries = (size_t)res * res + 6u * (size_t)(res / 2) * (res / 2);
+    if (p->shadow_cache.bytes < entries * 4) { RT_TRY(p->shadow_cache.reserve(entries * 4)); p->shadow_cache_gen = 0xffffffffu; }
+    if (lr.on == 0xffffffffu) return RT_OK;            // (rt_pipeline_reserve_batch: the allocation only)
+    if (p->shadow_cache_gen != s->generation) {
+        HIP_TRY(hipMemsetAsync(p->shadow_cache.p, 0xff, entries * 4, p->ctx->stream));
+        const rt_model *m = s->inst[0].model;
+        float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        for (size_t i = 0; i < m->h_verts.size(); i++)
+            for (int c = 0; c < 3; c++) {
+                const float x = (&m->h_verts[i].position.x)[c];
+                if (i == 0 || x < lo[c]) lo[c] = x;
+                if (i == 0 || x > hi[c]) hi[c] = x;
+            }
+        float r2 = 0.0f;
+        for (int c = 0; c < 3; c++) { p->shadow_cache_centre[c] = 0.5f * (lo[c] + hi[c]); const float h = 0.5f * (hi[c] - lo[c]); r2 += h * h; }
+        p->shadow_cache_radius = r2 > 0.0f && r2 < 1e30f ? sqrtf(r2) : 1.0f;
+        p->shadow_cache_gen = s->generation;
+    }
+    ShadowCacheDev c = {};
+    c.table = p->shadow_cache.as<uint32_t>();
+    c.res = res; c.res_f = (float)res;
+    // two unit vectors across the direction to the light
+    const float d[3] = {lr.dir_to_light[0], lr.dir_to_light[1], lr.dir_to_light[2]};
+    const float ref[3] = {fabsf(d[1]) < 0.9f ? 0.0f : 1.0f, fabsf(d[1]) < 0.9f ? 1.0f : 0.0f, 0.0f};
+    float a[3] = {d[1] * ref[2] - d[2] * ref[1], d[2] * ref[0] - d[0] * ref[2], d[0] * ref[1] - d[1] * ref[0]};
+    const float al = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    if (!(al > 1e-6f)) { a[0] = 1.0f; a[1] = 0.0f; a[2] = 0.0f; } else { a[0] /= al; a[1] /= al; a[2] /= al; }
+    const float b[3] = {d[1] * a[2] - d[2] * a[1], d[2] * a[0] - d[0] * a[2], d[0] * a[1] - d[1] * a[0]};
+    const float k = 0.5f * (float)res / p->shadow_cache_radius;
+    c.ua[3] = 0.5f * (float)res; c.va[3] = 0.5f * (float)res;
+    for (int i = 0; i < 3; i++) {
+        c.ua[i] = a[i] * k; c.va[i] = b[i] * k;
+        c.ua[3] -= p->shadow_cache_centre[i] * c.ua[i];
+        c.va[3] -= p->shadow_cache_centre[i] * c.va[i];
+        c.lp[i] = lr.point_pos[i];
+    }
+    (void)pfc;
+    p->shadow_cache_dev = c;
+    return RT_OK;
+}
+
 int ensure_queues(rt_pipeline *p, uint32_t cap, uint32_t sh0_batches, uint32_t levels)
 {
     if (cap <= p->cap && sh0_batches <= p->sh0_batches && levels <= p->levels) return RT_OK;
@@ -608,6 +714,7 @@ hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots
     const LightRays lr = light_rays(pd), none = no_light_rays();
     const LightRays *fl = B ? pd.frame_lights : nullptr;
     shadows.frame_lights = fl;
+    shadows.cache = p->shadow_cache_dev;
     shadows.q[0] = QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, shadow_slots, any, lr};     // RaytracingCommon.hlsli:94
     shadows.vis[0] = pd.lv[0].vis;
     shadows.nq = 1;
@@ -756,6 +863,9 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     pd.n_frames = n_frames; pd.fcap = fcap;
     pd.pfcs = nullptr; pd.frame_lights = nullptr;
     pd.shadow_compact = ao_view ? 0u : 1u;          // the AO view's four rays have random directions
+    // (the light buffer is keyed by the two lights: the AO view's random rays do not use it)
+    if (ao_view) p->shadow_cache_dev = ShadowCacheDev{};
+    else RT_TRY(prepare_shadow_cache(p, frames[0], light_rays(1u, frames[0])));
     if (n_frames > 1) {
         // the batch's constants and light rays go to device memory: kernels index them by the frame of a slot
         const size_t cb = sizeof(rt_per_frame_constants) * RT_MAX_BATCH, lb = sizeof(LightRays) * RT_MAX_BATCH;
@@ -891,6 +1001,12 @@ int rt_pipeline_reserve_batch(rt_pipeline *p, uint32_t width, uint32_t height, u
     const bool ao_view = p->have_pfc && p->pfc.options.showAmbientOcclusionOnly != 0;
     RT_TRY(ensure_queues(p, fcap * frames, ao_view ? 4u : 2u, frame_levels(p)));
     if (frames > 1) RT_TRY(p->batch_consts.reserve((sizeof(rt_per_frame_constants) + sizeof(LightRays)) * RT_MAX_BATCH));
+    if (p->scene) {                                    // the shadow cache's table as well
+        LightRays only_allocate = no_light_rays();
+        only_allocate.on = 0xffffffffu;
+        RT_TRY(prepare_shadow_cache(p, p->pfc, only_allocate));
+        p->shadow_cache_dev = ShadowCacheDev{};
+    }
     return RT_OK;
 }
 

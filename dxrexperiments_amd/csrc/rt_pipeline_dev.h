@@ -59,6 +59,20 @@ struct LightRays {
     float point_pos[3];         // pointLight.worldPos
 };
 
+// The shadow cache (round 3): a light buffer of occluders.  An any-hit search only asks WHETHER something lies between a point and
+// a light, and in a progressive render the same question comes back frame after frame: the triangle that answered it last time
+// for rays in the same place in LIGHT space -- the 2-D cell of the origin projected along the directional light, the cube-map
+// texel of the direction from the point light -- is tested first (as a one-triangle leaf in front of the root on the ray's stack).
+// If it occludes, the search is over after one triangle test; if not, the walk starts as always.  Any triangle is a legal first
+// candidate, so entries may be stale or collide without touching the result; what the table holds only moves the time.
+struct ShadowCacheDev {
+    uint32_t *table;            // [res * res] directional cells, then [6 * (res / 2)^2] cube texels; nullptr: off.  0xFFFFFFFF: no entry
+    float ua[4], va[4];         // directional light: cell (u, v) = (dot(o, ua.xyz) + ua.w, dot(o, va.xyz) + va.w), in [0, res)
+    float lp[3];                // point light position
+    float res_f;
+    uint32_t res;
+};
+
 #define RT_MAX_BATCH 32u                // frames one set of launches renders (rt_pipeline_render_batch)
 
 struct PipeDev {
@@ -138,6 +152,12 @@ struct rt_pipeline {
     std::vector<uint8_t> ring_nframes; // frames each remembered entry covers (a batch is one entry)
     DevBuf batch_consts;               // per-frame constants and light rays of a batch (rt_pipeline_render_batch)
     int ring_frames = 0;               // 0 = timing off
+    // the shadow cache (ShadowCacheDev): table, the scene it was filled from, the bounds its directional cells span
+    DevBuf shadow_cache;
+    int shadow_cache_res = -1;         // rt_pipeline_set_shadow_cache: -1 automatic (env RT_SHADOW_CACHE_RES, else by triangle count), 0 off, n cells per side
+    uint32_t shadow_cache_gen = 0xffffffffu;
+    float shadow_cache_centre[3] = {0, 0, 0}, shadow_cache_radius = 1.0f;
+    ShadowCacheDev shadow_cache_dev = {};      // what the next shadow launches get (table == nullptr: off)
     // the shadow rays of the primary hits are traced beside the secondary rays (launch_frame): a second stream and the fork /
     // join events of that launch
     int overlap_shadow0 = -1;          // -1: not decided yet (RT_OVERLAP_SHADOW0)

@@ -186,6 +186,15 @@ int rt_pipeline_set_depth_limits(rt_pipeline *p, uint32_t max_radiance_depth, ui
     return RT_OK;
 }
 
+int rt_pipeline_set_shadow_cache(rt_pipeline *p, int cells_per_side)
+{
+    RT_REQUIRE(p, "null pipeline");
+    RT_REQUIRE(cells_per_side >= -1 && cells_per_side <= 8192, "shadow cache: cells per side in [16, 8192], 0 = off, -1 = automatic");
+    p->shadow_cache_res = cells_per_side;
+    p->shadow_cache_gen = 0xffffffffu;          // (a table of another size starts empty)
+    return RT_OK;
+}
+
 int rt_pipeline_set_skip_unlit_shadow_rays(rt_pipeline *p, int on)
 {
     RT_REQUIRE(p, "null pipeline");

@@ -394,6 +394,13 @@ RT_DEV uint32_t distinct_node_lines(int node, bool from_global)
 
 RT_DEV bool node_is_internal(int node) { return node >= 0 && node < RT_NODE_EMPTY; }
 
+// A ray source may keep a cache of first candidates for unordered any-hit searches of single-level scenes (the pipeline's shadow
+// cache): uint32_t cached_leaf(const RayD &, uint32_t &slot) -> index into the sorted triangle array or RT_NO_HIT, and where a better
+// answer would go; void remember(slot, index).  The walk parks the slot in the last LDS row of the lane's stack (a walk that ever
+// needs that row overwrites it: remember() then finds a number that is not a slot, or is somebody else's -- harmless either way).
+template <class S, class = void> struct src_has_cache { static constexpr bool value = false; };
+template <class S> struct src_has_cache<S, decltype((void)&S::cached_leaf)> { static constexpr bool value = true; };
+
 RT_DEV unsigned long long lanemask_lt()
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -565,6 +572,13 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 #ifdef RT_LDS_BLAS_TOPS
                         top_cur = topl;
 #endif
+                    }
+                    if constexpr (src_has_cache<Src>::value && ANYHIT && !TWO_LEVEL && !COUNT) {
+                        // the triangle that answered this question last time goes first: a one-triangle leaf in front of the root
+                        uint32_t slot;
+                        const uint32_t ct = src.cached_leaf(r, slot);
+                        st.lds[(STACK - 1) * BLOCK] = (int)slot;
+                        if (ct != RT_NO_HIT) { st.lds[0] = root0; sp = 1; node = ~(int)(ct << 3); }
                     }
                     alive = true;
                     started = true;
@@ -826,6 +840,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     const bool accepted = accept_candidate(*in, ii, prim, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), r, wri, cur, cull, found);
                     if (!ANYHIT) best = found;
                     if (accepted && first) {
+                        if constexpr (src_has_cache<Src>::value && ANYHIT && !TWO_LEVEL && !COUNT) src.remember((uint32_t)st.lds[(STACK - 1) * BLOCK], first_tri + k);
                         if (SPLIT && meta != 0u) meta |= (meta & META_THIEF) != 0u ? META_FOUND : META_FOUND | META_PARKED;
                         else sink.store(idx, found, true);
                         alive = false;

@@ -199,3 +199,34 @@ def test_reserve_batch(gpu, capi):
         p.reserve_batch(0)
     with pytest.raises(capi.RtError):
         p.reserve_batch(33)
+
+
+@pytest.mark.parametrize("case", ["default", "four_bounces", "moving_lights"])
+def test_shadow_cache_is_invisible(gpu, capi, case):
+    """rt_pipeline_set_shadow_cache: the light buffer of occluders changes which triangle a shadow ray meets first, never
+    whether it meets one -- the image and every ray count are the same with the cache off, automatic, with a table so coarse
+    that most entries are wrong (16 cells per side), and after the lights have moved under it; frame by frame and in sets."""
+    W, H = 192, 108
+    v, i = scenes.sponza_class(seed=42)
+    mat = T.default_material()
+    if case == "four_bounces":
+        mat["type"] = 2; mat["reflectivity"] = 0.6; mat["roughness"] = 0.3
+    cam = cam_array(scenes.sponza_camera(), W / H)
+    pfcs = frames_of(capi, cam, 9, W, H)
+    if case == "moving_lights":
+        for f, c in enumerate(pfcs):
+            c["directionalLight"]["forwardDir"] = (0.3 - 0.15 * f, -0.2 - 0.05 * f, -1.0 + 0.1 * f, 0.0)
+            c["pointLight"]["worldPos"] = (0.7 * f - 2.0, 1.0 + 0.2 * f, 2.0 - 0.5 * f, 1.0)
+    images, counts = [], []
+    for cells in (0, -1, 16, 512):
+        p = make_gpu_pipeline(capi, gpu, [(v, i)], [(0, None)], [mat], W, H, env=scenes.sky_cubemap(16))
+        if case == "four_bounces":
+            p.set_depth_limits(4, 3)
+        p.set_shadow_cache(cells)
+        images.append(both_ways(p, pfcs))          # (frame by frame == in one set, and the image of the second pass)
+        t = p.totals()
+        counts.append({k: t[k] for k in ("rays_primary", "rays_secondary", "rays_shadow", "primary_hits", "secondary_hits")})
+    for img, cnt in zip(images[1:], counts[1:]):
+        assert np.array_equal(img, images[0]) and cnt == counts[0]
+    with pytest.raises(capi.RtError):
+        p.set_shadow_cache(9000)
