@@ -651,6 +651,9 @@ def main():
                        "frames_per_gpu": K, "parallelism": "sample-sharded x%d, one RCCL all-reduce of the fp32 accumulation buffer" % world
                        if world > 1 else "single GPU", "accumulation": "sum+allreduce" if world > 1 else "running mean",
                        "frames_per_launch_set": S, "launch_sets": n_sets,
+                       # (rt_pipeline_set_shadow_cache, automatic: the occluder a shadow ray's light-space cell met last is tested first;
+                       #  every ray is still answered exactly and counted)
+                       "shadow_cache_cells_per_side": pipe.shadow_cache(),
                        "entry_point": "rt_pipeline_render_batch" if S > 1 else "rt_pipeline_update + rt_pipeline_render"},
             "primary_mrays_per_s": primary_all / elapsed / 1e6,
             "frames_per_s": K * world / elapsed,

@@ -106,6 +106,7 @@ SIGNATURES = {
     "rt_pipeline_update": (_i, [_p, _p]),
     "rt_pipeline_render": (_i, [_p, _u32, _u32]),
     "rt_pipeline_set_shadow_cache": (_i, [_p, _i]),
+    "rt_pipeline_get_shadow_cache": (_i, [_p, _p]),
     "rt_pipeline_render_batch": (_i, [_p, _u32, _u32, _p, _u32]),
     "rt_pipeline_reserve_batch": (_i, [_p, _u32, _u32, _u32]),
     "rt_pipeline_render_tile": (_i, [_p, _u32, _u32, _u32, _u32, _u32, _u32]),
@@ -521,6 +522,12 @@ class Pipeline:
     def set_shadow_cache(self, cells_per_side):
         """Light buffer of occluders for shadow rays (same image, less time): -1 automatic, 0 off, else cells per side."""
         _check(lib().rt_pipeline_set_shadow_cache(self.h, int(cells_per_side)))
+
+    def shadow_cache(self):
+        """cells per side of the shadow cache the last frame ran with (0: none)"""
+        n = C.c_int(0)
+        _check(lib().rt_pipeline_get_shadow_cache(self.h, C.byref(n)))
+        return n.value
 
     def reserve_batch(self, frames):
         """Size the ray queues for sets of `frames` frames now (the first render_batch of that size then allocates nothing)."""

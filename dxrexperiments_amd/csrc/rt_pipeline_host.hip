@@ -195,6 +195,13 @@ int rt_pipeline_set_shadow_cache(rt_pipeline *p, int cells_per_side)
     return RT_OK;
 }
 
+int rt_pipeline_get_shadow_cache(const rt_pipeline *p, int *cells_per_side)
+{
+    RT_REQUIRE(p && cells_per_side, "null argument");
+    *cells_per_side = p->shadow_cache_dev.table ? (int)p->shadow_cache_dev.res : 0;       // what the last frame ran with
+    return RT_OK;
+}
+
 int rt_pipeline_set_skip_unlit_shadow_rays(rt_pipeline *p, int on)
 {
     RT_REQUIRE(p, "null pipeline");

@@ -72,6 +72,9 @@ public:
         if (n) mConstants = constants[n - 1];
     }
 
+    // the light buffer of occluders shadow rays test first (-1 automatic, 0 off, else cells per side): same image, less time
+    void setShadowCache(int cellsPerSide) { DXRFramework::ThrowIfFailed(rt_pipeline_set_shadow_cache(mPipeline, cellsPerSide)); }
+
     // sizes the work memory of renderBatch calls of n frames ahead of time (optional)
     void reserveBatch(UINT n, UINT width, UINT height) { DXRFramework::ThrowIfFailed(rt_pipeline_reserve_batch(mPipeline, width, height, n)); }
 

@@ -199,6 +199,8 @@ int rt_pipeline_set_skip_unlit_shadow_rays(rt_pipeline *p, int on);
  * (bench scene: shadow stage -19 %).  cells_per_side: -1 automatic (by triangle count; env RT_SHADOW_CACHE_RES overrides),
  * 0 off, else 16..8192 (the table takes 10 * cells^2 bytes). */
 int rt_pipeline_set_shadow_cache(rt_pipeline *p, int cells_per_side);
+/* cells per side the last rendered frame used (0: it ran without the cache -- two-level scene, AO view, or switched off) */
+int rt_pipeline_get_shadow_cache(const rt_pipeline *p, int *cells_per_side);
 int rt_pipeline_clear_output(rt_pipeline *p);
 /* update(): the 188-byte constant buffer the reference fills each frame (.cpp:177-213) */
 int rt_pipeline_update(rt_pipeline *p, const rt_per_frame_constants *constants);
