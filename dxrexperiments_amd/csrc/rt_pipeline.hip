@@ -363,18 +363,26 @@ struct ShadowSrcN : ShadowQueues {
         return res * res + (face * r2 + (uint32_t)cs) * r2 + (uint32_t)ct;
     }
     // (the slot is computed once, when the ray is loaded; the walk keeps it in a spare row of the lane's LDS stack until a hit wants it)
-    RT_DEV uint32_t cached_leaf(const RayD &r, uint32_t &slot) const
+    RT_DEV uint32_t cached_leaf(uint32_t, const RayD &r, uint32_t &slot, uint32_t &instance) const
     {
         slot = RT_NO_HIT;
+        instance = 0u;
         if (!cache.table) return RT_NO_HIT;
         slot = cache_slot(r);
+        if (cache.two_level) {
+            const uint2 e = ((const uint2 *)cache.table)[slot];
+            instance = e.y;
+            return e.x;
+        }
         return cache.table[slot];
     }
-    RT_DEV void remember(uint32_t slot, uint32_t sorted_triangle) const
+    RT_DEV void remember(uint32_t slot, uint32_t sorted_triangle, uint32_t instance) const
     {
         // (a slot that the stack has overwritten in the meantime is some other number: inside the table it only makes a stale entry)
         const uint32_t entries = cache.res * cache.res + 6u * (cache.res >> 1) * (cache.res >> 1);
-        if (cache.table && slot < entries) cache.table[slot] = sorted_triangle;
+        if (!cache.table || slot >= entries) return;
+        if (cache.two_level) ((uint2 *)cache.table)[slot] = make_uint2(sorted_triangle, instance);
+        else cache.table[slot] = sorted_triangle;
     }
 };
 struct ShadowSinkN {      // ShadowMiss sets visibility 1 (ProgressiveRaytracing.hlsl:178-182)
@@ -601,7 +609,12 @@ int prepare_shadow_cache(rt_pipeline *p, const rt_per_frame_constants &pfc, cons
 {
     p->shadow_cache_dev = ShadowCacheDev{};
     const rt_scene *s = p->scene;
-    if (p->shadow_cache_res == 0 || s->two_level || s->inst.empty() || !s->inst[0].model || s->inst[0].model->n_tris >= (1u << 28)) return RT_OK;
+    if (p->shadow_cache_res == 0 || s->inst.empty()) return RT_OK;
+    size_t n_tris_all = 0;
+    for (const SceneInstance &si : s->inst) {
+        if (!si.model || si.model->n_tris >= (1u << 28)) return RT_OK;
+        n_tris_all += si.model->n_tris;
+    }
     int want = p->shadow_cache_res;
     if (want < 0) {                         // not set through the API: the environment, else by the size of the triangles
         const char *e = getenv("RT_SHADOW_CACHE_RES");
@@ -612,26 +625,45 @@ int prepare_shadow_cache(rt_pipeline *p, const rt_per_frame_constants &pfc, cons
         // cells well below the triangles' size: 8 per sqrt(triangle count) across the scene, a power of two in [1024, 8192]
         // (bench scene, 262 k triangles: 1024 / 2048 / 4096 / 8192 cells -> 1.80 / 1.74 / 1.70 / 1.72 ms per frame, off 1.87;
         //  10 M triangles: 2048 -> 11.9, 8192 -> 10.9 ms, off 12.0; profiles/r03/shadow_cache*.txt)
-        const double target = 8.0 * sqrt((double)s->inst[0].model->n_tris);
+        const double target = 8.0 * sqrt((double)n_tris_all);
         want = 1024;
         while (want < 8192 && (double)want < target) want *= 2;
     }
     if (want > 8192) want = 8192;
     if (want < 16) want = 16;
     const uint32_t res = (uint32_t)want & ~1u;
-    const size_t entries = (size_t)res * res + 6u * (size_t)(res / 2) * (res / 2);
-    if (p->shadow_cache.bytes < entries * 4) { RT_TRY(p->shadow_cache.reserve(entries * 4)); p->shadow_cache_gen = 0xffffffffu; }
+    const size_t entries = (size_t)res * res + 6u * (size_t)(res / 2) * (res / 2), entry_bytes = s->two_level ? 8 : 4;
+    if (p->shadow_cache.bytes < entries * entry_bytes) { RT_TRY(p->shadow_cache.reserve(entries * entry_bytes)); p->shadow_cache_gen = 0xffffffffu; }
     if (lr.on == 0xffffffffu) return RT_OK;            // (rt_pipeline_reserve_batch: the allocation only)
     if (p->shadow_cache_gen != s->generation) {
-        HIP_TRY(hipMemsetAsync(p->shadow_cache.p, 0xff, entries * 4, p->ctx->stream));
-        const rt_model *m = s->inst[0].model;
+        HIP_TRY(hipMemsetAsync(p->shadow_cache.p, 0xff, entries * entry_bytes, p->ctx->stream));
+        // the world bounds: every instance's model box (from the host copy of its vertices) through its transform
         float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-        for (size_t i = 0; i < m->h_verts.size(); i++)
-            for (int c = 0; c < 3; c++) {
-                const float x = (&m->h_verts[i].position.x)[c];
-                if (i == 0 || x < lo[c]) lo[c] = x;
-                if (i == 0 || x > hi[c]) hi[c] = x;
+        bool any = false;
+        const rt_model *boxed = nullptr;
+        float mlo[3] = {0, 0, 0}, mhi[3] = {0, 0, 0};
+        for (const SceneInstance &si : s->inst) {
+            const rt_model *m = si.model;
+            if (m != boxed) {
+                for (size_t i = 0; i < m->h_verts.size(); i++)
+                    for (int c = 0; c < 3; c++) {
+                        const float x = (&m->h_verts[i].position.x)[c];
+                        if (i == 0 || x < mlo[c]) mlo[c] = x;
+                        if (i == 0 || x > mhi[c]) mhi[c] = x;
+                    }
+                boxed = m;
             }
+            if (m->h_verts.empty()) continue;
+            for (int corner = 0; corner < 8; corner++) {
+                const float v[3] = {corner & 1 ? mhi[0] : mlo[0], corner & 2 ? mhi[1] : mlo[1], corner & 4 ? mhi[2] : mlo[2]};
+                for (int c = 0; c < 3; c++) {
+                    const float w = si.xform[4 * c] * v[0] + si.xform[4 * c + 1] * v[1] + si.xform[4 * c + 2] * v[2] + si.xform[4 * c + 3];
+                    if (!any || w < lo[c]) lo[c] = w;
+                    if (!any || w > hi[c]) hi[c] = w;
+                }
+                any = true;
+            }
+        }
         float r2 = 0.0f;
         for (int c = 0; c < 3; c++) { p->shadow_cache_centre[c] = 0.5f * (lo[c] + hi[c]); const float h = 0.5f * (hi[c] - lo[c]); r2 += h * h; }
         p->shadow_cache_radius = r2 > 0.0f && r2 < 1e30f ? sqrtf(r2) : 1.0f;
@@ -640,6 +672,7 @@ int prepare_shadow_cache(rt_pipeline *p, const rt_per_frame_constants &pfc, cons
     ShadowCacheDev c = {};
     c.table = p->shadow_cache.as<uint32_t>();
     c.res = res; c.res_f = (float)res;
+    c.two_level = s->two_level ? 1u : 0u;
     // two unit vectors across the direction to the light
     const float d[3] = {lr.dir_to_light[0], lr.dir_to_light[1], lr.dir_to_light[2]};
     const float ref[3] = {fabsf(d[1]) < 0.9f ? 0.0f : 1.0f, fabsf(d[1]) < 0.9f ? 1.0f : 0.0f, 0.0f};

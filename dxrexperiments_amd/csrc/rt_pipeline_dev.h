@@ -71,6 +71,7 @@ struct ShadowCacheDev {
     float lp[3];                // point light position
     float res_f;
     uint32_t res;
+    uint32_t two_level;         // entries are (triangle, instance) pairs of 8 B: the triangle index counts inside that instance's BLAS
 };
 
 #define RT_MAX_BATCH 32u                // frames one set of launches renders (rt_pipeline_render_batch)

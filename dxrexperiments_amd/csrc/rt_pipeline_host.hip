@@ -49,7 +49,7 @@ int rt_pipeline_destroy(rt_pipeline *p)
     if (!p) return RT_OK;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    DevBuf *all[] = {&p->d_mats, &p->d_env, &p->accum_own, &p->aov_own, &p->counters, &p->half_out, &p->totals, &p->work, &p->batch_consts};
+    DevBuf *all[] = {&p->d_mats, &p->d_env, &p->accum_own, &p->aov_own, &p->counters, &p->half_out, &p->totals, &p->work, &p->batch_consts, &p->shadow_cache};
     for (DevBuf *b : all) b->release();
     for (rt_pipeline::LevelBuf &l : p->lv) {
         DevBuf *lb[] = {&l.O, &l.D, &l.hit, &l.inst, &l.slot_j, &l.jlist, &l.pix, &l.shO, &l.shD, &l.vis, &l.color};

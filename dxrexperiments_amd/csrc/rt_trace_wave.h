@@ -395,8 +395,8 @@ RT_DEV uint32_t distinct_node_lines(int node, bool from_global)
 RT_DEV bool node_is_internal(int node) { return node >= 0 && node < RT_NODE_EMPTY; }
 
 // A ray source may keep a cache of first candidates for unordered any-hit searches of single-level scenes (the pipeline's shadow
-// cache): uint32_t cached_leaf(const RayD &, uint32_t &slot) -> index into the sorted triangle array or RT_NO_HIT, and where a better
-// answer would go; void remember(slot, index).  The walk parks the slot in the last LDS row of the lane's stack (a walk that ever
+// cache): uint32_t cached_leaf(ray index, const RayD &, uint32_t &slot, uint32_t &instance) -> index into the instance's sorted triangle
+// array or RT_NO_HIT, and where a better answer would go; void remember(slot, index, instance).  The walk parks the slot in the last LDS row of the lane's stack (a walk that ever
 // needs that row overwrites it: remember() then finds a number that is not a slot, or is somebody else's -- harmless either way).
 template <class S, class = void> struct src_has_cache { static constexpr bool value = false; };
 template <class S> struct src_has_cache<S, decltype((void)&S::cached_leaf)> { static constexpr bool value = true; };
@@ -573,12 +573,27 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                         top_cur = topl;
 #endif
                     }
-                    if constexpr (src_has_cache<Src>::value && ANYHIT && !TWO_LEVEL && !COUNT) {
+                    if constexpr (src_has_cache<Src>::value && ANYHIT && !COUNT) {
                         // the triangle that answered this question last time goes first: a one-triangle leaf in front of the root
-                        uint32_t slot;
-                        const uint32_t ct = src.cached_leaf(r, slot);
+                        uint32_t slot, ci;
+                        const uint32_t ct = src.cached_leaf(my, r, slot, ci);
                         st.lds[(STACK - 1) * BLOCK] = (int)slot;
-                        if (ct != RT_NO_HIT) { st.lds[0] = root0; sp = 1; node = ~(int)(ct << 3); }
+                        if (ct != RT_NO_HIT && (!TWO_LEVEL || ci < sc.n_inst)) {
+                            st.lds[0] = root0;
+                            sp = 1;
+                            if (TWO_LEVEL) {          // ... inside its instance: the leaf, then the sentinel that leads back out, then the TLAS root
+                                ii = ci;
+                                in = sc.inst + ii;
+                                cur = to_object(*in, r);
+                                nodes = in->wide;
+                                tris = in->tris;
+                                in_blas = true;
+                                top_lim = 0;
+                                st.lds[BLOCK] = RT_NODE_SENTINEL;
+                                sp = 2;
+                            }
+                            node = ~(int)(ct << 3);
+                        }
                     }
                     alive = true;
                     started = true;
@@ -840,7 +855,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     const bool accepted = accept_candidate(*in, ii, prim, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), r, wri, cur, cull, found);
                     if (!ANYHIT) best = found;
                     if (accepted && first) {
-                        if constexpr (src_has_cache<Src>::value && ANYHIT && !TWO_LEVEL && !COUNT) src.remember((uint32_t)st.lds[(STACK - 1) * BLOCK], first_tri + k);
+                        if constexpr (src_has_cache<Src>::value && ANYHIT && !COUNT) src.remember((uint32_t)st.lds[(STACK - 1) * BLOCK], first_tri + k, ii);
                         if (SPLIT && meta != 0u) meta |= (meta & META_THIEF) != 0u ? META_FOUND : META_FOUND | META_PARKED;
                         else sink.store(idx, found, true);
                         alive = false;

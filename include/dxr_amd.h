@@ -191,13 +191,13 @@ int rt_pipeline_set_accumulation_mode(rt_pipeline *p, uint32_t mode);        /* 
  * bit-identical either way.  Measured: a third of the shadow rays of the bench scene, but they end within a few steps inside
  * the closed geometry they start in, so the frame time does not move; -7 % on the single-sided 10 M-triangle terrain. */
 int rt_pipeline_set_skip_unlit_shadow_rays(rt_pipeline *p, int on);
-/* The shadow cache: a light buffer of occluders for the any-hit (shadow) searches of single-level scenes.  TraceRay with
+/* The shadow cache: a light buffer of occluders for the any-hit (shadow) searches.  TraceRay with
  * ACCEPT_FIRST_HIT_AND_END_SEARCH (assets/shaders/RaytracingCommon.hlsli:84-96) only asks whether ANY triangle lies between the
  * point and the light; the triangle that last answered that for rays at the same place in light space (the cell of the origin
  * projected along the directional light, the cube-map texel of the direction from the point light) is tested first, and the
  * walk only starts if it does not occlude.  The visibility -- and the image -- are the same bit for bit; the time is not
  * (bench scene: shadow stage -19 %).  cells_per_side: -1 automatic (by triangle count; env RT_SHADOW_CACHE_RES overrides),
- * 0 off, else 16..8192 (the table takes 10 * cells^2 bytes). */
+ * 0 off, else 16..8192 (the table takes 10 * cells^2 bytes, 20 * cells^2 for scenes of several instances). */
 int rt_pipeline_set_shadow_cache(rt_pipeline *p, int cells_per_side);
 /* cells per side the last rendered frame used (0: it ran without the cache -- two-level scene, AO view, or switched off) */
 int rt_pipeline_get_shadow_cache(const rt_pipeline *p, int *cells_per_side);

@@ -201,6 +201,27 @@ def test_reserve_batch(gpu, capi):
         p.reserve_batch(33)
 
 
+def test_shadow_cache_is_invisible_in_instanced_scenes(gpu, capi):
+    """the same for two-level walks: an entry is a (triangle, instance) pair and the ray starts inside that instance"""
+    W, H = 96, 64
+    blob = scenes.blob_mesh(level=2)
+    soup = triangle_soup(400, seed=4, extent=2.0, size=0.5)
+    xf = random_xforms(24, seed=11, spread=6.0)
+    mats = [T.default_material() for _ in range(24)]
+    cam = np.array([0, 2, 16, 0, 0, 0, 0, 1, 0, 0.8, W / H], np.float32)
+    pfcs = frames_of(capi, cam, 8, W, H)
+    images, counts = [], []
+    for cells in (0, -1, 16, 256):
+        p = make_gpu_pipeline(capi, gpu, [blob, soup], [(k % 2, xf[k]) for k in range(24)], mats, W, H, env=scenes.sky_cubemap(16))
+        p.set_shadow_cache(cells)
+        images.append(both_ways(p, pfcs))
+        assert (p.shadow_cache() != 0) == (cells != 0)
+        t = p.totals()
+        counts.append({k: t[k] for k in ("rays_primary", "rays_secondary", "rays_shadow", "primary_hits", "secondary_hits")})
+    for img, cnt in zip(images[1:], counts[1:]):
+        assert np.array_equal(img, images[0]) and cnt == counts[0]
+
+
 @pytest.mark.parametrize("case", ["default", "four_bounces", "moving_lights"])
 def test_shadow_cache_is_invisible(gpu, capi, case):
     """rt_pipeline_set_shadow_cache: the light buffer of occluders changes which triangle a shadow ray meets first, never
