@@ -81,6 +81,7 @@ int rt_pipeline_set_scene(rt_pipeline *p, rt_scene *s)
     if (p->scene) rt_scene_destroy(p->scene);
     p->scene = s;
     p->rendered = false;        // last_pd holds device pointers of the previous scene
+    p->shadow_cache_gen = 0xffffffffu;      // ... and the shadow cache triangle indices of its arrays (another scene may carry the same generation number)
     return RT_OK;
 }
 
