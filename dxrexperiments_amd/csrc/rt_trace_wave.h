@@ -578,7 +578,9 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                         uint32_t slot, ci;
                         const uint32_t ct = src.cached_leaf(my, r, slot, ci);
                         st.lds[(STACK - 1) * BLOCK] = (int)slot;
-                        if (ct != RT_NO_HIT && (!TWO_LEVEL || ci < sc.n_inst)) {
+                        // (an entry is only ever tested if it names a triangle that exists: the table is emptied with the scene, but a pair
+                        // torn between two writers, or a table handed over by mistake, must not read past an array)
+                        if (ct != RT_NO_HIT && (TWO_LEVEL ? ci < sc.n_inst && ct < sc.inst[ci].n_prims : ct < in0->n_prims)) {
                             st.lds[0] = root0;
                             sp = 1;
                             if (TWO_LEVEL) {          // ... inside its instance: the leaf, then the sentinel that leads back out, then the TLAS root
