@@ -363,25 +363,29 @@ struct ShadowSrcN : ShadowQueues {
         return res * res + (face * r2 + (uint32_t)cs) * r2 + (uint32_t)ct;
     }
     // (the slot is computed once, when the ray is loaded; the walk keeps it in a spare row of the lane's LDS stack until a hit wants it)
+    static constexpr bool has_first_candidates = true;
+    template <bool TWO_LEVEL>
     RT_DEV uint32_t cached_leaf(uint32_t, const RayD &r, uint32_t &slot, uint32_t &instance) const
     {
         slot = RT_NO_HIT;
         instance = 0u;
         if (!cache.table) return RT_NO_HIT;
         slot = cache_slot(r);
-        if (cache.two_level) {
+        if (TWO_LEVEL) {
             const uint2 e = ((const uint2 *)cache.table)[slot];
             instance = e.y;
-            return e.x;
+            return e.x;                                  // (checked against its instance's triangle count by the walk)
         }
-        return cache.table[slot];
+        const uint32_t t = cache.table[slot];
+        return t < cache.n_tris ? t : RT_NO_HIT;         // (an entry is only ever tested if it names a triangle that exists)
     }
+    template <bool TWO_LEVEL>
     RT_DEV void remember(uint32_t slot, uint32_t sorted_triangle, uint32_t instance) const
     {
         // (a slot that the stack has overwritten in the meantime is some other number: inside the table it only makes a stale entry)
         const uint32_t entries = cache.res * cache.res + 6u * (cache.res >> 1) * (cache.res >> 1);
         if (!cache.table || slot >= entries) return;
-        if (cache.two_level) ((uint2 *)cache.table)[slot] = make_uint2(sorted_triangle, instance);
+        if (TWO_LEVEL) ((uint2 *)cache.table)[slot] = make_uint2(sorted_triangle, instance);
         else cache.table[slot] = sorted_triangle;
     }
 };
@@ -673,6 +677,7 @@ int prepare_shadow_cache(rt_pipeline *p, const rt_per_frame_constants &pfc, cons
     c.table = p->shadow_cache.as<uint32_t>();
     c.res = res; c.res_f = (float)res;
     c.two_level = s->two_level ? 1u : 0u;
+    c.n_tris = s->two_level ? 0u : s->inst[0].model->n_tris;
     // two unit vectors across the direction to the light
     const float d[3] = {lr.dir_to_light[0], lr.dir_to_light[1], lr.dir_to_light[2]};
     const float ref[3] = {fabsf(d[1]) < 0.9f ? 0.0f : 1.0f, fabsf(d[1]) < 0.9f ? 1.0f : 0.0f, 0.0f};

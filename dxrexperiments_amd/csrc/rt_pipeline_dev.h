@@ -72,6 +72,7 @@ struct ShadowCacheDev {
     float res_f;
     uint32_t res;
     uint32_t two_level;         // entries are (triangle, instance) pairs of 8 B: the triangle index counts inside that instance's BLAS
+    uint32_t n_tris;            // single level: triangles of the one model (an entry at or above it is not tested)
 };
 
 #define RT_MAX_BATCH 32u                // frames one set of launches renders (rt_pipeline_render_batch)

@@ -399,7 +399,7 @@ RT_DEV bool node_is_internal(int node) { return node >= 0 && node < RT_NODE_EMPT
 // array or RT_NO_HIT, and where a better answer would go; void remember(slot, index, instance).  The walk parks the slot in the last LDS row of the lane's stack (a walk that ever
 // needs that row overwrites it: remember() then finds a number that is not a slot, or is somebody else's -- harmless either way).
 template <class S, class = void> struct src_has_cache { static constexpr bool value = false; };
-template <class S> struct src_has_cache<S, decltype((void)&S::cached_leaf)> { static constexpr bool value = true; };
+template <class S> struct src_has_cache<S, decltype((void)&S::has_first_candidates)> { static constexpr bool value = true; };
 
 RT_DEV unsigned long long lanemask_lt()
 {
@@ -576,11 +576,11 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     if constexpr (src_has_cache<Src>::value && ANYHIT && !COUNT) {
                         // the triangle that answered this question last time goes first: a one-triangle leaf in front of the root
                         uint32_t slot, ci;
-                        const uint32_t ct = src.cached_leaf(my, r, slot, ci);
+                        const uint32_t ct = src.template cached_leaf<TWO_LEVEL>(my, r, slot, ci);
                         st.lds[(STACK - 1) * BLOCK] = (int)slot;
                         // (an entry is only ever tested if it names a triangle that exists: the table is emptied with the scene, but a pair
                         // torn between two writers, or a table handed over by mistake, must not read past an array)
-                        if (ct != RT_NO_HIT && (TWO_LEVEL ? ci < sc.n_inst && ct < sc.inst[ci].n_prims : ct < in0->n_prims)) {
+                        if (ct != RT_NO_HIT && (!TWO_LEVEL || (ci < sc.n_inst && ct < sc.inst[ci].n_prims))) {      // (single level: the source checks against its own count)
                             st.lds[0] = root0;
                             sp = 1;
                             if (TWO_LEVEL) {          // ... inside its instance: the leaf, then the sentinel that leads back out, then the TLAS root
@@ -857,7 +857,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     const bool accepted = accept_candidate(*in, ii, prim, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), r, wri, cur, cull, found);
                     if (!ANYHIT) best = found;
                     if (accepted && first) {
-                        if constexpr (src_has_cache<Src>::value && ANYHIT && !COUNT) src.remember((uint32_t)st.lds[(STACK - 1) * BLOCK], first_tri + k, ii);
+                        if constexpr (src_has_cache<Src>::value && ANYHIT && !COUNT) src.template remember<TWO_LEVEL>((uint32_t)st.lds[(STACK - 1) * BLOCK], first_tri + k, ii);
                         if (SPLIT && meta != 0u) meta |= (meta & META_THIEF) != 0u ? META_FOUND : META_FOUND | META_PARKED;
                         else sink.store(idx, found, true);
                         alive = false;
