@@ -29,7 +29,9 @@
 // rt_pipeline_host.hip: creation, setters, outputs, checkpoints, timing and statistics.
 #include <hip/hip_fp16.h>
 
+#include <array>
 #include <new>
+#include <utility>
 
 #include "rt_shade.h"
 
@@ -644,20 +646,23 @@ int prepare_shadow_cache(rt_pipeline *p, const rt_per_frame_constants &pfc, cons
         // the world bounds: every instance's model box (from the host copy of its vertices) through its transform
         float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
         bool any = false;
-        const rt_model *boxed = nullptr;
-        float mlo[3] = {0, 0, 0}, mhi[3] = {0, 0, 0};
+        std::vector<std::pair<const rt_model *, std::array<float, 6>>> boxes;        // (a scene has few distinct models)
         for (const SceneInstance &si : s->inst) {
             const rt_model *m = si.model;
-            if (m != boxed) {
+            if (m->h_verts.empty()) continue;
+            size_t at = 0;
+            while (at < boxes.size() && boxes[at].first != m) at++;
+            if (at == boxes.size()) {
+                std::array<float, 6> b = {0, 0, 0, 0, 0, 0};
                 for (size_t i = 0; i < m->h_verts.size(); i++)
                     for (int c = 0; c < 3; c++) {
                         const float x = (&m->h_verts[i].position.x)[c];
-                        if (i == 0 || x < mlo[c]) mlo[c] = x;
-                        if (i == 0 || x > mhi[c]) mhi[c] = x;
+                        if (i == 0 || x < b[c]) b[c] = x;
+                        if (i == 0 || x > b[3 + c]) b[3 + c] = x;
                     }
-                boxed = m;
+                boxes.push_back({m, b});
             }
-            if (m->h_verts.empty()) continue;
+            const float *mlo = boxes[at].second.data(), *mhi = mlo + 3;
             for (int corner = 0; corner < 8; corner++) {
                 const float v[3] = {corner & 1 ? mhi[0] : mlo[0], corner & 2 ? mhi[1] : mlo[1], corner & 4 ? mhi[2] : mlo[2]};
                 for (int c = 0; c < 3; c++) {
