@@ -387,6 +387,9 @@ struct ShadowSrcN : ShadowQueues {
         // (a slot that the stack has overwritten in the meantime is some other number: inside the table it only makes a stale entry)
         const uint32_t entries = cache.res * cache.res + 6u * (cache.res >> 1) * (cache.res >> 1);
         if (!cache.table || slot >= entries) return;
+#ifdef RT_TRACE_STATS     /* instrumentation build (tools/trace_stats.py): occluded rays answered by their cell's entry / by the walk */
+        atomicAdd(&rtd::g_trace_sp_hist[cache.table[TWO_LEVEL ? 2u * slot : slot] == sorted_triangle ? 60 : 61], 1ull);
+#endif
         if (TWO_LEVEL) ((uint2 *)cache.table)[slot] = make_uint2(sorted_triangle, instance);
         else cache.table[slot] = sorted_triangle;
     }

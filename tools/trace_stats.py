@@ -57,7 +57,7 @@ def main():
         w, l = out[2 * k], out[2 * k + 1]
         print("%-20s wave-level %12d  lane-level %14d  lanes active %.1f %%  per ray %.1f" % (n, w, l, 100.0 * l / (64.0 * w) if w else 0.0, l / rays))
     hist = np.array(out[8:68], dtype=np.uint64)
-    print("drain compaction: waves that joined %d, rays they deposited %d, adopting waves %d, outer iterations spent waiting on a tall stack %d" % tuple(out[68:72]))
+    print("shadow cache: occluded shadow rays whose occluder was their cell's entry %d, found by the walk %d (of %d shadow rays)" % (out[68], out[69], st["rays_shadow"]))
     tot = float(hist.sum())
     top = int(np.nonzero(hist)[0].max())
     cum = np.cumsum(hist) / tot
