@@ -64,8 +64,9 @@ struct PrimarySrcT {
         uint32_t px, py;
         if (BATCH && pd.n_frames > 1u) {         // (a kernel argument: the branch is uniform)
             // 64 consecutive slots = one tile = one chunk of a wave: the frame is the same for every lane that loads here
-            const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)(q / pd.fcap));
-            const bool valid = pix_xy(pd, q - f * pd.fcap, px, py);
+            uint32_t ql;
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_frame(pd, q, ql));
+            const bool valid = pix_xy(pd, ql, px, py);
             r = primary_ray(pd, pd.pfcs[f].cameraParams, px, py);
             return valid;
         }
@@ -75,7 +76,8 @@ struct PrimarySrcT {
     }
 };
 typedef PrimarySrcT<true> PrimarySrc;        // (the counting kernels)
-struct PrimarySink {
+template <bool BATCH>
+struct PrimarySinkT {
     const PipeDev &pd;
     RT_DEV void store(uint32_t q, const HitD &h, bool) const
     {
@@ -100,7 +102,7 @@ __global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_primary(PipeDev pd)
     if (blockIdx.x == 0)
         for (uint32_t i = threadIdx.x; i < (uint32_t)(POOL_OFFSET_WORDS + POOL_BYTES / 4); i += PBLOCK) pd.counters[i] = 0u;
     PrimarySrcT<BATCH> src = {pd};
-    PrimarySink sink = {pd};
+    PrimarySinkT<BATCH> sink = {pd};
     trace_wave<STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, nullptr, smem, nullptr);   // one 8x8 tile per wave, dealt by the hardware dispatcher
 }
 
@@ -506,7 +508,7 @@ __global__ void __launch_bounds__(PBLOCK) k_resolve(PipeDev pd_arg)
     // frames would have left (each frame with its own accumCount)
     for (uint32_t f = 0; f < (BATCH ? pd.n_frames : 1u); f++) {
         if (BATCH) pd.pfc = pd.pfcs[f];
-        const uint32_t q = f * pd.fcap + ql;
+        const uint32_t q = frame_slot(pd, f, ql);
         const RayD r = primary_ray(pd, px, py);
         const float4 h = pd.lv[0].hit[q];
         Shaded sh;

@@ -125,13 +125,21 @@ RT_DEV RayD primary_ray(const PipeDev &pd, const rt_camera_params &cp, uint32_t 
 }
 RT_DEV RayD primary_ray(const PipeDev &pd, uint32_t px, uint32_t py) { return primary_ray(pd, pd.pfc.cameraParams, px, py); }
 
-// The frame a pixel slot belongs to, and the slot inside that frame (single frames: 0 and q itself)
+// The frame a pixel slot belongs to, and the slot inside that frame (single frames: 0 and q itself).  The slots of a set of n
+// frames are TILE major: the 64 slots of tile t of frame f are chunk t * n + f, so that the same 8x8 pixels of consecutive frames --
+// rays that differ by a sub-pixel jitter -- sit next to each other in the primary launch and, since every queue is compacted in slot
+// order, in every queue after it (frame-major order put them a whole frame apart: the waves that walk them found none of the other's
+// nodes in the caches).
 RT_DEV uint32_t slot_frame(const PipeDev &pd, uint32_t q, uint32_t &q_in_frame)
 {
     if (pd.n_frames <= 1u) { q_in_frame = q; return 0u; }
-    const uint32_t f = q / pd.fcap;
-    q_in_frame = q - f * pd.fcap;
+    const uint32_t c = q >> 6, tile = c / pd.n_frames, f = c - tile * pd.n_frames;
+    q_in_frame = (tile << 6) | (q & 63u);
     return f;
+}
+RT_DEV uint32_t frame_slot(const PipeDev &pd, uint32_t frame, uint32_t q_in_frame)
+{
+    return pd.n_frames <= 1u ? q_in_frame : ((((q_in_frame >> 6) * pd.n_frames + frame) << 6) | (q_in_frame & 63u));
 }
 
 // ---- interpolateVertexAttributes (RaytracingCommon.hlsli:53-82), normal only
