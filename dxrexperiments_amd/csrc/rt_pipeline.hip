@@ -208,20 +208,21 @@ __global__ void __launch_bounds__(PBLOCK) k_shade_emit(PipeDev pd, int level, ui
 // expressions of evaluateDirectionalLight / evaluatePointLight (RaytracingCommon.hlsli:126-147; directional_light /
 // point_light above): 16 B written and read per hit instead of 128 B.  The four rays of the ambient-occlusion view have
 // random directions and keep the explicit origin / direction form.
-struct QueueSrc {
+// (RayQueue: the queue itself; QueueSrc: a queue with the frame's light rays, a ray source of its own.  The launch of all shadow
+// queues holds ONE copy of the lights beside its queues -- five copies in the kernel argument cost the two-level any-hit kernel
+// the scalar registers it spills into vector ones.)
+struct RayQueue {
     const float4 *O, *D;
     const uint32_t *count_ptr;
     uint32_t stride, batches, fl;
-    LightRays lights;
     RT_DEV uint32_t n() const { return *count_ptr; }
     RT_DEV uint32_t count() const { return n() * batches; }
     RT_DEV uint32_t flags() const { return fl; }
     RT_DEV size_t slot(uint32_t i) const { const uint32_t c = n(); return (size_t)(i / c) * stride + i % c; }
-    RT_DEV bool load(uint32_t i, RayD &r) const { return load_lit(i, r, nullptr); }
     // per_frame: a batch of frames -- the lights of frame f (bits 8.. of the hit's word).  The single-frame kernels call this
     // with a literal nullptr: the branch folds away and their code is what it was before batches existed (with the branch
     // compiled in, the five inlined copies of this loader cost the any-hit kernel 30 VGPRs and 128 B of scratch).
-    RT_DEV bool load_lit(uint32_t i, RayD &r, const LightRays *per_frame) const
+    RT_DEV bool load_lit(uint32_t i, RayD &r, const LightRays &lights, const LightRays *per_frame) const
     {
         if (lights.on) {
             const uint32_t c = n(), b = i / c;
@@ -242,7 +243,7 @@ struct QueueSrc {
                     const f3 path = l - r.o;
                     const float dist = length(path);
                     r.d = normalize(path);
-                    r.tmax = dist - RAY_EPSILON;
+                    r.tmax = dist - fmaxf(RAY_EPSILON, fl[3]);       // (fl[3]: point_free of that frame's lights)
                 }
                 return r.tmax > r.tmin;
             }
@@ -253,7 +254,7 @@ struct QueueSrc {
                 const f3 path = mk3(lights.point_pos[0], lights.point_pos[1], lights.point_pos[2]) - r.o;
                 const float dist = length(path);
                 r.d = normalize(path);
-                r.tmax = dist - RAY_EPSILON;
+                r.tmax = dist - fmaxf(RAY_EPSILON, lights.point_free);
             }
             return r.tmax > r.tmin;
         }
@@ -263,6 +264,11 @@ struct QueueSrc {
         r.d = mk3(b.x, b.y, b.z); r.tmax = b.w;
         return r.tmax > r.tmin;
     }
+};
+struct QueueSrc : RayQueue {
+    LightRays lights;
+    RT_DEV bool load(uint32_t i, RayD &r) const { return RayQueue::load_lit(i, r, lights, nullptr); }
+    RT_DEV bool load_lit(uint32_t i, RayD &r, const LightRays *per_frame) const { return RayQueue::load_lit(i, r, lights, per_frame); }
 };
 static inline LightRays light_rays(uint32_t shadow_compact, const rt_per_frame_constants &pfc)
 {
@@ -276,9 +282,10 @@ static inline LightRays light_rays(uint32_t shadow_compact, const rt_per_frame_c
     const float inv = 1.0f / sqrtf(d);
     l.dir_to_light[0] = x * inv; l.dir_to_light[1] = y * inv; l.dir_to_light[2] = z * inv;
     l.point_pos[0] = w.x; l.point_pos[1] = w.y; l.point_pos[2] = w.z;
+    l.point_free = 0.0f;
     return l;
 }
-static inline LightRays light_rays(const PipeDev &pd) { return light_rays(pd.shadow_compact, pd.pfc); }
+static inline LightRays light_rays(const PipeDev &pd) { LightRays l = light_rays(pd.shadow_compact, pd.pfc); l.point_free = pd.point_free; return l; }
 static inline LightRays no_light_rays()
 {
     LightRays l;
@@ -312,7 +319,8 @@ struct SecondarySink {
 // every shadow ray of the frame in ONE launch: the shadow queues of all shaded levels, back to back
 // BATCH: the launch covers several frames, a ray takes the light rays of its hit's frame
 struct ShadowQueues {
-    QueueSrc q[MAXD + 1];
+    RayQueue q[MAXD + 1];
+    LightRays lights;                   // the frame's light rays, for all the queues
     uint32_t *vis[MAXD + 1];
     int nq;
     const LightRays *frame_lights;      // device array [n_frames] (batches)
@@ -335,7 +343,7 @@ struct ShadowSrcN : ShadowQueues {
         for (int k = 0; k <= MAXD; k++) {
             if (k < nq) {
                 const uint32_t c = q[k].count();
-                if (i < c) return q[k].load_lit(i, r, BATCH ? frame_lights : nullptr);
+                if (i < c) return q[k].load_lit(i, r, lights, BATCH ? frame_lights : nullptr);
                 i -= c;
             }
         }
@@ -613,6 +621,119 @@ __global__ void k_debug_cube(PipeDev pd, const float *__restrict__ dirs, float *
 
 namespace {
 
+// How far from a point light the scene certainly is empty: its shadow rays may stop that far short of the light (QueueSrc::load_lit) --
+// nothing can occlude them inside that sphere, and all of them would otherwise walk the nodes around the light, where they converge.
+// A lower bound is enough: the distance from the light to the nearest occupied cell of a 64^3 grid over the scene's bounds, in which
+// every triangle (single-level scenes; the world box of every instance otherwise) has marked the cells its bounding box touches;
+// times 0.99, minus RAY_EPSILON.  Host arithmetic, once per scene and per light position; bench scene: 3.3 of a 32 x 11 x 14 atrium,
+// shadow stage -3 % (profiles/r03/free_radius.txt).
+float free_radius(rt_pipeline *p, const float lp[3])
+{
+    rt_pipeline::FreeGrid &g = p->free_grid;
+    const rt_scene *s = p->scene;
+    const int N = 64;
+    if (!(lp[0] == lp[0] && lp[1] == lp[1] && lp[2] == lp[2])) return 0.0f;
+    if (g.gen != s->generation) {
+        g.gen = s->generation;
+        g.radius = -1.0f;
+        g.occ.assign((size_t)N * N * N, 0);
+        // world boxes: of every triangle (one identity instance) or of every instance
+        std::vector<std::array<float, 6>> boxes;
+        bool hopeless = s->inst.empty();
+        for (const SceneInstance &si : s->inst) {
+            const rt_model *m = si.model;
+            if (!m || m->h_verts.empty() || m->h_idx.size() < 3) continue;
+            if (!s->two_level) {
+                boxes.reserve(m->h_idx.size() / 3);
+                for (size_t t = 0; t + 2 < m->h_idx.size(); t += 3) {
+                    std::array<float, 6> b;
+                    bool finite = true;
+                    for (int c = 0; c < 3; c++) {
+                        const float x0 = (&m->h_verts[m->h_idx[t]].position.x)[c], x1 = (&m->h_verts[m->h_idx[t + 1]].position.x)[c], x2 = (&m->h_verts[m->h_idx[t + 2]].position.x)[c];
+                        b[c] = fminf(x0, fminf(x1, x2)); b[3 + c] = fmaxf(x0, fmaxf(x1, x2));
+                        finite = finite && x0 == x0 && x1 == x1 && x2 == x2;
+                    }
+                    if (finite) boxes.push_back(b);          // (a triangle with a NaN corner meets no ray)
+                }
+            } else {
+                float mlo[3] = {0, 0, 0}, mhi[3] = {0, 0, 0};
+                for (size_t i = 0; i < m->h_verts.size(); i++)
+                    for (int c = 0; c < 3; c++) {
+                        const float x = (&m->h_verts[i].position.x)[c];
+                        if (!(x == x)) { hopeless = true; continue; }
+                        if (i == 0 || x < mlo[c]) mlo[c] = x;
+                        if (i == 0 || x > mhi[c]) mhi[c] = x;
+                    }
+                std::array<float, 6> b = {0, 0, 0, 0, 0, 0};
+                for (int corner = 0; corner < 8; corner++) {
+                    const float v[3] = {corner & 1 ? mhi[0] : mlo[0], corner & 2 ? mhi[1] : mlo[1], corner & 4 ? mhi[2] : mlo[2]};
+                    for (int c = 0; c < 3; c++) {
+                        const float w = si.xform[4 * c] * v[0] + si.xform[4 * c + 1] * v[1] + si.xform[4 * c + 2] * v[2] + si.xform[4 * c + 3];
+                        if (!(w == w)) hopeless = true;
+                        if (corner == 0 || w < b[c]) b[c] = w;
+                        if (corner == 0 || w > b[3 + c]) b[3 + c] = w;
+                    }
+                }
+                // (a transformed box: a little slack for the roundings of the instance's own transform of its vertices)
+                for (int c = 0; c < 3; c++) { const float e = 1e-4f * (fabsf(b[c]) + fabsf(b[3 + c]) + 1.0f); b[c] -= e; b[3 + c] += e; }
+                boxes.push_back(b);
+            }
+        }
+        float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        for (size_t i = 0; i < boxes.size(); i++)
+            for (int c = 0; c < 3; c++) {
+                if (i == 0 || boxes[i][c] < lo[c]) lo[c] = boxes[i][c];
+                if (i == 0 || boxes[i][3 + c] > hi[c]) hi[c] = boxes[i][3 + c];
+            }
+        for (int c = 0; c < 3; c++) {
+            if (!(lo[c] > -1e30f && hi[c] < 1e30f)) hopeless = true;
+            g.lo[c] = lo[c];
+            g.cell[c] = (hi[c] - lo[c]) / (float)N;
+            if (!(g.cell[c] > 0.0f)) g.cell[c] = 1e-30f;
+        }
+        if (hopeless || boxes.empty()) g.occ.assign(g.occ.size(), 1);       // (nothing known: every cell counts as occupied)
+        else
+            for (const std::array<float, 6> &b : boxes) {
+                int a[3], z[3];
+                for (int c = 0; c < 3; c++) {
+                    // (one cell of slack on both sides: the cell index of a coordinate is computed in floating point)
+                    const float fa = (b[c] - g.lo[c]) / g.cell[c] - 1.0f, fz = (b[3 + c] - g.lo[c]) / g.cell[c] + 1.0f;
+                    a[c] = fa < 0.0f ? 0 : fa > (float)(N - 1) ? N - 1 : (int)fa;
+                    z[c] = fz < 0.0f ? 0 : fz > (float)(N - 1) ? N - 1 : (int)fz;
+                }
+                for (int x = a[0]; x <= z[0]; x++)
+                    for (int y = a[1]; y <= z[1]; y++)
+                        memset(&g.occ[((size_t)x * N + y) * N + a[2]], 1, (size_t)(z[2] - a[2] + 1));
+            }
+    }
+    if (g.radius >= 0.0f && g.lp[0] == lp[0] && g.lp[1] == lp[1] && g.lp[2] == lp[2]) return g.radius;
+    double best = 1e300;
+    for (int x = 0; x < N; x++) {
+        const double bx0 = (double)g.lo[0] + (double)g.cell[0] * x, bx1 = bx0 + (double)g.cell[0];
+        const double dx = lp[0] < bx0 ? bx0 - lp[0] : lp[0] > bx1 ? lp[0] - bx1 : 0.0;
+        if (dx * dx >= best) continue;
+        for (int y = 0; y < N; y++) {
+            const double by0 = (double)g.lo[1] + (double)g.cell[1] * y, by1 = by0 + (double)g.cell[1];
+            const double dy = lp[1] < by0 ? by0 - lp[1] : lp[1] > by1 ? lp[1] - by1 : 0.0;
+            if (dx * dx + dy * dy >= best) continue;
+            const unsigned char *row = &g.occ[((size_t)x * N + y) * N];
+            for (int z = 0; z < N; z++) {
+                if (!row[z]) continue;
+                const double bz0 = (double)g.lo[2] + (double)g.cell[2] * z, bz1 = bz0 + (double)g.cell[2];
+                const double dz = lp[2] < bz0 ? bz0 - lp[2] : lp[2] > bz1 ? lp[2] - bz1 : 0.0;
+                const double d2 = dx * dx + dy * dy + dz * dz;
+                if (d2 < best) best = d2;
+            }
+        }
+    }
+    // (the cells' own bounds were computed in float: one more cell of slack on the answer)
+    double r = sqrt(best) - sqrt((double)g.cell[0] * g.cell[0] + (double)g.cell[1] * g.cell[1] + (double)g.cell[2] * g.cell[2]);
+    r = r * 0.99 - (double)RAY_EPSILON;
+    g.lp[0] = lp[0]; g.lp[1] = lp[1]; g.lp[2] = lp[2];
+    g.radius = r > 0.0 && r < 1e30 ? (float)r : 0.0f;
+    return g.radius;
+}
+
 // The shadow cache of the coming launches (ShadowCacheDev): single-level scenes only (an entry is an index into the one sorted
 // triangle array); the table is cleared when the scene has changed (an index must stay inside the array), its directional cells
 // span the bounding sphere of the model, its basis follows the frame's light (entries of another direction are merely stale).
@@ -763,7 +884,8 @@ hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots
     const LightRays *fl = B ? pd.frame_lights : nullptr;
     shadows.frame_lights = fl;
     shadows.cache = p->shadow_cache_dev;
-    shadows.q[0] = QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, shadow_slots, any, lr};     // RaytracingCommon.hlsli:94
+    shadows.lights = lr;
+    shadows.q[0] = RayQueue{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, shadow_slots, any};     // RaytracingCommon.hlsli:94
     shadows.vis[0] = pd.lv[0].vis;
     shadows.nq = 1;
     size_t shadow_max = (size_t)cap * shadow_slots;
@@ -789,7 +911,7 @@ hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots
     }
     for (uint32_t l = 1; l <= levels; l++) {
         // level 1: the diffuse and the specular batch of the primary hits; deeper: one ray per hit of level l-1
-        const QueueSrc rays = {pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE, none};   // ProgressiveRaytracing.hlsl:53
+        const QueueSrc rays = {{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE}, none};   // ProgressiveRaytracing.hlsl:53
         k_trace_secondary<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_secondary<STACK, TWO_LEVEL>, PBLOCK, (size_t)cap * 2), PBLOCK, 0, st>>>(
             pd.sc, rays, pd.lv[l].hit, pd.lv[l].inst, pd.pools + (size_t)l * RT_POOL_GROUPS * RT_POOL_STRIDE, &pd.counters[C_SECONDARY]);
         k_compact_level<<<(2 * cap + CTILES * CBLOCK - 1) / (CTILES * CBLOCK), CBLOCK, 0, st>>>(pd, (int)l);
@@ -801,7 +923,7 @@ hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots
         }
         if (T) record(ev[4 + 2 * (l - 1)], st);
         if (casts_shadows) {
-            shadows.q[shadows.nq] = QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any, lr};
+            shadows.q[shadows.nq] = RayQueue{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any};
             shadows.vis[shadows.nq] = pd.lv[l].vis;
             shadows.nq++;
             shadow_max += (size_t)cap * 4;
@@ -845,13 +967,13 @@ static int count_walk_launch(rt_pipeline *p, unsigned long long *w)
     const unsigned gs = rt_persistent_grid(ctx, k_walk_shadow<TWO_LEVEL>, PBLOCK, (size_t)cap * 2);
     const LightRays lr = light_rays(pd), none = no_light_rays();
     const LightRays *fl = pd.n_frames > 1u ? pd.frame_lights : nullptr;
-    k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any, lr}, fl}, w + 7 * RT_STAGE_SHADOW0);
+    k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any}, lr}, fl}, w + 7 * RT_STAGE_SHADOW0);
     const uint32_t levels = pd.max_rad < (uint32_t)MAXD ? pd.max_rad : (uint32_t)MAXD;
     for (uint32_t l = 1; l <= levels; l++) {
-        k_walk_queue<TWO_LEVEL><<<gq, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE, none},
+        k_walk_queue<TWO_LEVEL><<<gq, PBLOCK, 0, st>>>(pd.sc, QueueSrc{{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE}, none},
                                                        w + 7 * RT_STAGE_SECONDARY);
         if (l < pd.max_shadow)
-            k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any, lr}, fl}, w + 7 * RT_STAGE_SHADOW1);
+            k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any}, lr}, fl}, w + 7 * RT_STAGE_SHADOW1);
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -912,6 +1034,11 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     pd.pfcs = nullptr; pd.frame_lights = nullptr;
     pd.shadow_compact = ao_view ? 0u : 1u;          // the AO view's four rays have random directions
     // (the light buffer is keyed by the two lights: the AO view's random rays do not use it)
+    const bool free_on = !(getenv("RT_FREE_RADIUS") && atoi(getenv("RT_FREE_RADIUS")) == 0);
+    {
+        const float lp0[3] = {frames[0].pointLight.worldPos.x, frames[0].pointLight.worldPos.y, frames[0].pointLight.worldPos.z};
+        pd.point_free = free_on ? free_radius(p, lp0) : 0.0f;
+    }
     if (ao_view) p->shadow_cache_dev = ShadowCacheDev{};
     else RT_TRY(prepare_shadow_cache(p, frames[0], light_rays(1u, frames[0])));
     if (n_frames > 1) {
@@ -921,7 +1048,8 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
         std::vector<unsigned char> stage(cb + lb, 0);
         for (uint32_t f = 0; f < n_frames; f++) {
             memcpy(&stage[sizeof(rt_per_frame_constants) * f], &frames[f], sizeof(rt_per_frame_constants));
-            const LightRays lr = light_rays(pd.shadow_compact, frames[f]);
+            LightRays lr = light_rays(pd.shadow_compact, frames[f]);
+            lr.point_free = free_on ? free_radius(p, lr.point_pos) : 0.0f;
             memcpy(&stage[cb + sizeof(LightRays) * f], &lr, sizeof lr);
         }
         HIP_TRY(hipMemcpyAsync(p->batch_consts.p, stage.data(), cb + lb, hipMemcpyHostToDevice, st));     // (pageable source: staged before the call returns)
@@ -1073,16 +1201,16 @@ int rt_pipeline_count_work(rt_pipeline *p, rt_stage_work *out)
     k_count_primary<<<blocks(cap), PBLOCK, 0, st>>>(pd, w + 3 * RT_STAGE_PRIMARY);
     const LightRays lr = light_rays(pd), none = no_light_rays();
     const LightRays *fl = pd.n_frames > 1u ? pd.frame_lights : nullptr;
-    k_count_queue<<<(blocks(cap) + 1) * ss, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any, lr}, fl},
+    k_count_queue<<<(blocks(cap) + 1) * ss, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any}, lr}, fl},
                                                              w + 3 * RT_STAGE_SHADOW0);
     const uint32_t levels = pd.max_rad < (uint32_t)MAXD ? pd.max_rad : (uint32_t)MAXD;
     for (uint32_t l = 1; l <= levels; l++) {        // every secondary level adds into the same two rows
         const uint32_t batches = l == 1 ? 2u : 1u;
         k_count_queue<<<(blocks((size_t)cap * 2) + 1) * batches, PBLOCK, 0, st>>>(
-            pd.sc, LitQueueSrc{QueueSrc{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, batches, RT_RAY_FLAG_NONE, none}, nullptr}, w + 3 * RT_STAGE_SECONDARY);
+            pd.sc, LitQueueSrc{QueueSrc{{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, batches, RT_RAY_FLAG_NONE}, none}, nullptr}, w + 3 * RT_STAGE_SECONDARY);
         if (l < pd.max_shadow)
             k_count_queue<<<(blocks((size_t)cap * 2) + 1) * 2, PBLOCK, 0, st>>>(
-                pd.sc, LitQueueSrc{QueueSrc{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2 * cap, 2, any, lr}, fl}, w + 3 * RT_STAGE_SHADOW1);
+                pd.sc, LitQueueSrc{QueueSrc{{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2 * cap, 2, any}, lr}, fl}, w + 3 * RT_STAGE_SHADOW1);
     }
     HIP_TRY(hipGetLastError());
     unsigned long long h[RT_STAGE_COUNT * 3];

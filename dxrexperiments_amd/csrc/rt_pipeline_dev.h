@@ -57,6 +57,8 @@ struct LightRays {
     float dir_to_light[3];      // normalize(-directionalLight.forwardDir), computed once per frame on the host with the
                                 //   device's expression (IEEE sqrt and division, left-to-right sums, no contraction)
     float point_pos[3];         // pointLight.worldPos
+    float point_free;           // no geometry lies nearer to the point light than this (0: unknown): its shadow rays end there
+                                //   (rt_pipeline::free_radius: a lower bound from a coarse occupancy grid of the scene)
 };
 
 // The shadow cache (round 3): a light buffer of occluders.  An any-hit search only asks WHETHER something lies between a point and
@@ -105,6 +107,7 @@ struct PipeDev {
     float4 *aov_direct, *aov_indirect;  // realtime pipeline outputs (RealtimeRaytracing.hlsl:3-4)
     uint32_t *counters;
     unsigned long long *totals;         // running sums over frames (rt_pipeline_get_totals); updated by the frame's last kernel
+    float point_free;           // LightRays::point_free of pfc's point light
     uint32_t *pools;            // chunk counters of the persistent launches: [2 + MAXD][RT_POOL_GROUPS], 128 B apart
     LevelDev lv[MAXD + 1];
 };
@@ -160,6 +163,9 @@ struct rt_pipeline {
     uint32_t shadow_cache_gen = 0xffffffffu;
     float shadow_cache_centre[3] = {0, 0, 0}, shadow_cache_radius = 1.0f;
     ShadowCacheDev shadow_cache_dev = {};      // what the next shadow launches get (table == nullptr: off)
+    // the free sphere around the point light (LightRays::point_free): a 64^3 occupancy grid of the scene's triangles (instances: of
+    // their world boxes), built on the host once per scene; the last light position asked and its answer
+    struct FreeGrid { uint32_t gen = 0xffffffffu; float lo[3] = {0, 0, 0}, cell[3] = {1, 1, 1}; std::vector<unsigned char> occ; float lp[3] = {0, 0, 0}, radius = -1.0f; } free_grid;
     // the shadow rays of the primary hits are traced beside the secondary rays (launch_frame): a second stream and the fork /
     // join events of that launch
     int overlap_shadow0 = -1;          // -1: not decided yet (RT_OVERLAP_SHADOW0)
