@@ -82,6 +82,7 @@ int rt_pipeline_set_scene(rt_pipeline *p, rt_scene *s)
     p->scene = s;
     p->rendered = false;        // last_pd holds device pointers of the previous scene
     p->shadow_cache_gen = 0xffffffffu;      // ... and the shadow cache triangle indices of its arrays (another scene may carry the same generation number)
+    p->free_grid.gen = 0xffffffffu;         // ... and the occupancy grid its geometry
     return RT_OK;
 }
 
