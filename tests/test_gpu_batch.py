@@ -251,3 +251,28 @@ def test_shadow_cache_is_invisible(gpu, capi, case):
         assert np.array_equal(img, images[0]) and cnt == counts[0]
     with pytest.raises(capi.RtError):
         p.set_shadow_cache(9000)
+
+
+def test_another_scene_on_the_same_pipeline(gpu, capi):
+    """What a pipeline remembers about a scene -- shadow-cache entries (indices into its triangle array), the occupancy grid behind
+    the point light's free sphere -- goes when it is given another scene, also one whose generation counter reads the same: the
+    small scene rendered after the large one equals the small scene rendered by a fresh pipeline."""
+    W, H = 96, 64
+    big = scenes.sponza_class(seed=42)
+    small = triangle_soup(300, seed=3, extent=3.0, size=1.2)
+    cam_big = cam_array(scenes.sponza_camera(), W / H)
+    cam_small = np.array([0, 0, 9, 0, 0, 0, 0, 1, 0, 0.8, W / H], np.float32)
+
+    def scene_of(mesh):
+        sc = capi.Scene(gpu)
+        sc.add_model(capi.Model(gpu, *mesh))
+        sc.build()
+        return sc
+    fresh = make_gpu_pipeline(capi, gpu, [small], [(0, None)], [T.default_material()], W, H, env=scenes.sky_cubemap(16))
+    want = both_ways(fresh, frames_of(capi, cam_small, 6, W, H))
+    p = make_gpu_pipeline(capi, gpu, [big], [(0, None)], [T.default_material()], W, H, env=scenes.sky_cubemap(16))
+    both_ways(p, frames_of(capi, cam_big, 6, W, H))            # fills the cache with indices up to 262 k
+    p.set_scene(scene_of(small))
+    p.build_acceleration_structures()
+    got = both_ways(p, frames_of(capi, cam_small, 6, W, H))
+    assert np.array_equal(got, want)
