@@ -623,115 +623,74 @@ namespace {
 
 // How far from a point light the scene certainly is empty: its shadow rays may stop that far short of the light (QueueSrc::load_lit) --
 // nothing can occlude them inside that sphere, and all of them would otherwise walk the nodes around the light, where they converge.
-// A lower bound is enough: the distance from the light to the nearest occupied cell of a 64^3 grid over the scene's bounds, in which
-// every triangle (single-level scenes; the world box of every instance otherwise) has marked the cells its bounding box touches;
-// times 0.99, minus RAY_EPSILON.  Host arithmetic, once per scene and per light position; bench scene: 3.3 of a 32 x 11 x 14 atrium,
-// shadow stage -3 % (profiles/r03/free_radius.txt).
-float free_radius(rt_pipeline *p, const float lp[3])
+// A lower bound is enough: the least distance from the light to the bounding box of any triangle (single-level scenes; to the world box
+// of any instance otherwise), times 0.99, minus RAY_EPSILON.  One device pass over the triangle records per (scene, light position),
+// queued behind the frame that first sees the pair and read back through page-locked memory: the frames until it has landed run
+// with no sphere (a scene that changes every frame never gets one, and never waits for one).  Bench scene: 3.3 of a 32 x 11 x 14
+// atrium, shadow stage -3 % (profiles/r03/free_radius.txt).
+__global__ void __launch_bounds__(PBLOCK) k_free_sphere(SceneDev sc, uint32_t two_level, uint32_t n, float lx, float ly, float lz, uint32_t *out_bits)
 {
-    rt_pipeline::FreeGrid &g = p->free_grid;
-    const rt_scene *s = p->scene;
-    const int N = 64;
-    if (!(lp[0] == lp[0] && lp[1] == lp[1] && lp[2] == lp[2])) return 0.0f;
-    if (g.gen != s->generation) {
-        g.gen = s->generation;
-        g.radius = -1.0f;
-        g.occ.assign((size_t)N * N * N, 0);
-        // world boxes: of every triangle (one identity instance) or of every instance
-        std::vector<std::array<float, 6>> boxes;
-        bool hopeless = s->inst.empty();
-        for (const SceneInstance &si : s->inst) {
-            const rt_model *m = si.model;
-            if (!m || m->h_verts.empty() || m->h_idx.size() < 3) continue;
-            if (!s->two_level) {
-                boxes.reserve(m->h_idx.size() / 3);
-                for (size_t t = 0; t + 2 < m->h_idx.size(); t += 3) {
-                    std::array<float, 6> b;
-                    bool finite = true;
-                    for (int c = 0; c < 3; c++) {
-                        const float x0 = (&m->h_verts[m->h_idx[t]].position.x)[c], x1 = (&m->h_verts[m->h_idx[t + 1]].position.x)[c], x2 = (&m->h_verts[m->h_idx[t + 2]].position.x)[c];
-                        b[c] = fminf(x0, fminf(x1, x2)); b[3 + c] = fmaxf(x0, fmaxf(x1, x2));
-                        finite = finite && x0 == x0 && x1 == x1 && x2 == x2;
-                    }
-                    if (finite) boxes.push_back(b);          // (a triangle with a NaN corner meets no ray)
-                }
-            } else {
-                float mlo[3] = {0, 0, 0}, mhi[3] = {0, 0, 0};
-                for (size_t i = 0; i < m->h_verts.size(); i++)
-                    for (int c = 0; c < 3; c++) {
-                        const float x = (&m->h_verts[i].position.x)[c];
-                        if (!(x == x)) { hopeless = true; continue; }
-                        if (i == 0 || x < mlo[c]) mlo[c] = x;
-                        if (i == 0 || x > mhi[c]) mhi[c] = x;
-                    }
-                std::array<float, 6> b = {0, 0, 0, 0, 0, 0};
-                for (int corner = 0; corner < 8; corner++) {
-                    const float v[3] = {corner & 1 ? mhi[0] : mlo[0], corner & 2 ? mhi[1] : mlo[1], corner & 4 ? mhi[2] : mlo[2]};
-                    for (int c = 0; c < 3; c++) {
-                        const float w = si.xform[4 * c] * v[0] + si.xform[4 * c + 1] * v[1] + si.xform[4 * c + 2] * v[2] + si.xform[4 * c + 3];
-                        if (!(w == w)) hopeless = true;
-                        if (corner == 0 || w < b[c]) b[c] = w;
-                        if (corner == 0 || w > b[3 + c]) b[3 + c] = w;
-                    }
-                }
-                // (a transformed box: a little slack for the roundings of the instance's own transform of its vertices)
-                for (int c = 0; c < 3; c++) { const float e = 1e-4f * (fabsf(b[c]) + fabsf(b[3 + c]) + 1.0f); b[c] -= e; b[3 + c] += e; }
-                boxes.push_back(b);
-            }
+    const uint32_t i = blockIdx.x * PBLOCK + threadIdx.x;
+    float d2 = __uint_as_float(0x7f800000u);
+    if (i < n) {
+        float lo[3], hi[3];
+        if (two_level) {
+            const InstanceRec &in = sc.inst[i];
+            for (int c = 0; c < 3; c++) { lo[c] = in.wlo[c]; hi[c] = in.whi[c]; }
+        } else {
+            const TriRec t = sc.inst[0].tris[i];
+            const float vx[3] = {t.a.x, t.a.w, t.b.z}, vy[3] = {t.a.y, t.b.x, t.b.w}, vz[3] = {t.a.z, t.b.y, t.c.x};
+            lo[0] = fminf(vx[0], fminf(vx[1], vx[2])); hi[0] = fmaxf(vx[0], fmaxf(vx[1], vx[2]));
+            lo[1] = fminf(vy[0], fminf(vy[1], vy[2])); hi[1] = fmaxf(vy[0], fmaxf(vy[1], vy[2]));
+            lo[2] = fminf(vz[0], fminf(vz[1], vz[2])); hi[2] = fmaxf(vz[0], fmaxf(vz[1], vz[2]));
         }
-        float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-        for (size_t i = 0; i < boxes.size(); i++)
-            for (int c = 0; c < 3; c++) {
-                if (i == 0 || boxes[i][c] < lo[c]) lo[c] = boxes[i][c];
-                if (i == 0 || boxes[i][3 + c] > hi[c]) hi[c] = boxes[i][3 + c];
-            }
+        const float l[3] = {lx, ly, lz};
+        float s = 0.0f;
+        bool known = true;
         for (int c = 0; c < 3; c++) {
-            if (!(lo[c] > -1e30f && hi[c] < 1e30f)) hopeless = true;
-            g.lo[c] = lo[c];
-            g.cell[c] = (hi[c] - lo[c]) / (float)N;
-            if (!(g.cell[c] > 0.0f)) g.cell[c] = 1e-30f;
+            const float d = l[c] < lo[c] ? lo[c] - l[c] : l[c] > hi[c] ? l[c] - hi[c] : 0.0f;
+            known = known && lo[c] == lo[c] && hi[c] == hi[c];
+            s += d * d;
         }
-        if (hopeless || boxes.empty()) g.occ.assign(g.occ.size(), 1);       // (nothing known: every cell counts as occupied)
-        else
-            for (const std::array<float, 6> &b : boxes) {
-                int a[3], z[3];
-                for (int c = 0; c < 3; c++) {
-                    // (one cell of slack on both sides: the cell index of a coordinate is computed in floating point)
-                    const float fa = (b[c] - g.lo[c]) / g.cell[c] - 1.0f, fz = (b[3 + c] - g.lo[c]) / g.cell[c] + 1.0f;
-                    a[c] = fa < 0.0f ? 0 : fa > (float)(N - 1) ? N - 1 : (int)fa;
-                    z[c] = fz < 0.0f ? 0 : fz > (float)(N - 1) ? N - 1 : (int)fz;
-                }
-                for (int x = a[0]; x <= z[0]; x++)
-                    for (int y = a[1]; y <= z[1]; y++)
-                        memset(&g.occ[((size_t)x * N + y) * N + a[2]], 1, (size_t)(z[2] - a[2] + 1));
-            }
+        // (a box with a NaN in it says nothing about where its triangle is: the sphere has no room then.  A triangle with a NaN
+        // CORNER meets no ray, but fminf / fmaxf may have hidden the NaN: not worth telling apart)
+        d2 = known ? s : 0.0f;
     }
-    if (g.radius >= 0.0f && g.lp[0] == lp[0] && g.lp[1] == lp[1] && g.lp[2] == lp[2]) return g.radius;
-    double best = 1e300;
-    for (int x = 0; x < N; x++) {
-        const double bx0 = (double)g.lo[0] + (double)g.cell[0] * x, bx1 = bx0 + (double)g.cell[0];
-        const double dx = lp[0] < bx0 ? bx0 - lp[0] : lp[0] > bx1 ? lp[0] - bx1 : 0.0;
-        if (dx * dx >= best) continue;
-        for (int y = 0; y < N; y++) {
-            const double by0 = (double)g.lo[1] + (double)g.cell[1] * y, by1 = by0 + (double)g.cell[1];
-            const double dy = lp[1] < by0 ? by0 - lp[1] : lp[1] > by1 ? lp[1] - by1 : 0.0;
-            if (dx * dx + dy * dy >= best) continue;
-            const unsigned char *row = &g.occ[((size_t)x * N + y) * N];
-            for (int z = 0; z < N; z++) {
-                if (!row[z]) continue;
-                const double bz0 = (double)g.lo[2] + (double)g.cell[2] * z, bz1 = bz0 + (double)g.cell[2];
-                const double dz = lp[2] < bz0 ? bz0 - lp[2] : lp[2] > bz1 ? lp[2] - bz1 : 0.0;
-                const double d2 = dx * dx + dy * dy + dz * dz;
-                if (d2 < best) best = d2;
-            }
-        }
+    for (int o = 32; o > 0; o >>= 1) d2 = fminf(d2, __shfl_xor(d2, o, 64));
+    if ((threadIdx.x & 63u) == 0u) atomicMin(out_bits, __float_as_uint(d2));          // (non-negative floats order like their bits)
+}
+
+float free_radius(rt_pipeline *p, const PipeDev &pd, const float lp[3])
+{
+    rt_pipeline::FreeSphere &f = p->free_sphere;
+    const rt_scene *s = p->scene;
+    hipStream_t st = p->ctx->stream;
+    if (!(lp[0] == lp[0] && lp[1] == lp[1] && lp[2] == lp[2])) return 0.0f;
+    if (!f.h_min) {
+        if (hipHostMalloc((void **)&f.h_min, 64, hipHostMallocDefault) != hipSuccess) { f.h_min = nullptr; return 0.0f; }
+        if (hipEventCreateWithFlags(&f.landed, hipEventDisableTiming) != hipSuccess || f.d_min.reserve(64) != RT_OK) return 0.0f;
     }
-    // (the cells' own bounds were computed in float: one more cell of slack on the answer)
-    double r = sqrt(best) - sqrt((double)g.cell[0] * g.cell[0] + (double)g.cell[1] * g.cell[1] + (double)g.cell[2] * g.cell[2]);
-    r = r * 0.99 - (double)RAY_EPSILON;
-    g.lp[0] = lp[0]; g.lp[1] = lp[1]; g.lp[2] = lp[2];
-    g.radius = r > 0.0 && r < 1e30 ? (float)r : 0.0f;
-    return g.radius;
+    if (f.in_flight && hipEventQuery(f.landed) == hipSuccess) {
+        f.in_flight = false;
+        f.known_gen = f.asked_gen;
+        memcpy(f.known_lp, f.asked_lp, sizeof f.known_lp);
+        const double r = sqrt((double)*f.h_min) * 0.99 - (double)RAY_EPSILON;
+        f.known_radius = r > 0.0 && r < 1e30 ? (float)r : 0.0f;
+    }
+    const bool known = f.known_gen == s->generation && memcmp(f.known_lp, lp, sizeof f.known_lp) == 0;
+    const bool asked = f.in_flight && f.asked_gen == s->generation && memcmp(f.asked_lp, lp, sizeof f.asked_lp) == 0;
+    if (!known && !asked && !f.in_flight) {
+        const uint32_t n = s->two_level ? (uint32_t)s->inst.size() : (s->inst.empty() || !s->inst[0].model ? 0u : s->inst[0].model->n_tris);
+        if (n == 0u || !f.landed) return 0.0f;
+        const uint32_t inf_bits = 0x7f800000u;
+        if (hipMemcpyAsync(f.d_min.p, &inf_bits, 4, hipMemcpyHostToDevice, st) != hipSuccess) return 0.0f;
+        k_free_sphere<<<(n + PBLOCK - 1) / PBLOCK, PBLOCK, 0, st>>>(pd.sc, s->two_level ? 1u : 0u, n, lp[0], lp[1], lp[2], f.d_min.as<uint32_t>());
+        if (hipMemcpyAsync(f.h_min, f.d_min.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(f.landed, st) != hipSuccess) return 0.0f;
+        f.in_flight = true;
+        f.asked_gen = s->generation;
+        memcpy(f.asked_lp, lp, sizeof f.asked_lp);
+    }
+    return known ? f.known_radius : 0.0f;
 }
 
 // The shadow cache of the coming launches (ShadowCacheDev): single-level scenes only (an entry is an index into the one sorted
@@ -769,35 +728,12 @@ int prepare_shadow_cache(rt_pipeline *p, const rt_per_frame_constants &pfc, cons
     if (lr.on == 0xffffffffu) return RT_OK;            // (rt_pipeline_reserve_batch: the allocation only)
     if (p->shadow_cache_gen != s->generation) {
         HIP_TRY(hipMemsetAsync(p->shadow_cache.p, 0xff, entries * entry_bytes, p->ctx->stream));
-        // the world bounds: every instance's model box (from the host copy of its vertices) through its transform
-        float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-        bool any = false;
-        std::vector<std::pair<const rt_model *, std::array<float, 6>>> boxes;        // (a scene has few distinct models)
-        for (const SceneInstance &si : s->inst) {
-            const rt_model *m = si.model;
-            if (m->h_verts.empty()) continue;
-            size_t at = 0;
-            while (at < boxes.size() && boxes[at].first != m) at++;
-            if (at == boxes.size()) {
-                std::array<float, 6> b = {0, 0, 0, 0, 0, 0};
-                for (size_t i = 0; i < m->h_verts.size(); i++)
-                    for (int c = 0; c < 3; c++) {
-                        const float x = (&m->h_verts[i].position.x)[c];
-                        if (i == 0 || x < b[c]) b[c] = x;
-                        if (i == 0 || x > b[3 + c]) b[3 + c] = x;
-                    }
-                boxes.push_back({m, b});
-            }
-            const float *mlo = boxes[at].second.data(), *mhi = mlo + 3;
-            for (int corner = 0; corner < 8; corner++) {
-                const float v[3] = {corner & 1 ? mhi[0] : mlo[0], corner & 2 ? mhi[1] : mlo[1], corner & 4 ? mhi[2] : mlo[2]};
-                for (int c = 0; c < 3; c++) {
-                    const float w = si.xform[4 * c] * v[0] + si.xform[4 * c + 1] * v[1] + si.xform[4 * c + 2] * v[2] + si.xform[4 * c + 3];
-                    if (!any || w < lo[c]) lo[c] = w;
-                    if (!any || w > hi[c]) hi[c] = w;
-                }
-                any = true;
-            }
+        // the world bounds: what the builds brought back (the model's own box for one identity instance, the TLAS's otherwise)
+        const float *bb = s->two_level ? s->tlas.bounds : s->inst[0].model->blas.bounds;
+        float lo[3], hi[3];
+        for (int c = 0; c < 3; c++) {
+            lo[c] = bb[c]; hi[c] = bb[3 + c];
+            if (!(lo[c] > -1e30f && hi[c] < 1e30f && lo[c] <= hi[c])) { lo[c] = -1.0f; hi[c] = 1.0f; }      // (any cell size is legal)
         }
         float r2 = 0.0f;
         for (int c = 0; c < 3; c++) { p->shadow_cache_centre[c] = 0.5f * (lo[c] + hi[c]); const float h = 0.5f * (hi[c] - lo[c]); r2 += h * h; }
@@ -1037,7 +973,7 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     const bool free_on = !(getenv("RT_FREE_RADIUS") && atoi(getenv("RT_FREE_RADIUS")) == 0);
     {
         const float lp0[3] = {frames[0].pointLight.worldPos.x, frames[0].pointLight.worldPos.y, frames[0].pointLight.worldPos.z};
-        pd.point_free = free_on ? free_radius(p, lp0) : 0.0f;
+        pd.point_free = free_on ? free_radius(p, pd, lp0) : 0.0f;
     }
     if (ao_view) p->shadow_cache_dev = ShadowCacheDev{};
     else RT_TRY(prepare_shadow_cache(p, frames[0], light_rays(1u, frames[0])));
@@ -1049,7 +985,8 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
         for (uint32_t f = 0; f < n_frames; f++) {
             memcpy(&stage[sizeof(rt_per_frame_constants) * f], &frames[f], sizeof(rt_per_frame_constants));
             LightRays lr = light_rays(pd.shadow_compact, frames[f]);
-            lr.point_free = free_on ? free_radius(p, lr.point_pos) : 0.0f;
+            // (frames whose point light is where the first frame's is share its sphere; a frame with another light gets none)
+            lr.point_free = free_on && memcmp(lr.point_pos, &frames[0].pointLight.worldPos, 3 * sizeof(float)) == 0 ? pd.point_free : 0.0f;
             memcpy(&stage[cb + sizeof(LightRays) * f], &lr, sizeof lr);
         }
         HIP_TRY(hipMemcpyAsync(p->batch_consts.p, stage.data(), cb + lb, hipMemcpyHostToDevice, st));     // (pageable source: staged before the call returns)

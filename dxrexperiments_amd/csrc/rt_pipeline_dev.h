@@ -163,9 +163,17 @@ struct rt_pipeline {
     uint32_t shadow_cache_gen = 0xffffffffu;
     float shadow_cache_centre[3] = {0, 0, 0}, shadow_cache_radius = 1.0f;
     ShadowCacheDev shadow_cache_dev = {};      // what the next shadow launches get (table == nullptr: off)
-    // the free sphere around the point light (LightRays::point_free): a 64^3 occupancy grid of the scene's triangles (instances: of
-    // their world boxes), built on the host once per scene; the last light position asked and its answer
-    struct FreeGrid { uint32_t gen = 0xffffffffu; float lo[3] = {0, 0, 0}, cell[3] = {1, 1, 1}; std::vector<unsigned char> occ; float lp[3] = {0, 0, 0}, radius = -1.0f; } free_grid;
+    // the free sphere around the point light (LightRays::point_free): the least distance from the light to the box of any triangle
+    // (instances: to any instance's world box), found by a device pass over them when the scene or the light has changed and read
+    // back without a host round trip: page-locked word + event, used from the first render call that finds the event complete
+    struct FreeSphere {
+        DevBuf d_min;                      // one float (bits): running minimum of the pass in flight
+        float *h_min = nullptr;            // page-locked landing place
+        hipEvent_t landed = nullptr;
+        uint32_t asked_gen = 0xffffffffu, known_gen = 0xffffffffu;
+        float asked_lp[3] = {0, 0, 0}, known_lp[3] = {0, 0, 0}, known_radius = 0.0f;
+        bool in_flight = false;
+    } free_sphere;
     // the shadow rays of the primary hits are traced beside the secondary rays (launch_frame): a second stream and the fork /
     // join events of that launch
     int overlap_shadow0 = -1;          // -1: not decided yet (RT_OVERLAP_SHADOW0)

@@ -60,6 +60,9 @@ int rt_pipeline_destroy(rt_pipeline *p)
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     if (p->side) (void)hipStreamDestroy(p->side);
     p->ev_fork = p->ev_join = nullptr; p->side = nullptr;
+    if (p->free_sphere.landed) (void)hipEventDestroy(p->free_sphere.landed);
+    if (p->free_sphere.h_min) (void)hipHostFree(p->free_sphere.h_min);
+    p->free_sphere.d_min.release();
     if (p->scene) rt_scene_destroy(p->scene);
     rt_context *ctx = p->ctx;
     delete p;
@@ -82,7 +85,7 @@ int rt_pipeline_set_scene(rt_pipeline *p, rt_scene *s)
     p->scene = s;
     p->rendered = false;        // last_pd holds device pointers of the previous scene
     p->shadow_cache_gen = 0xffffffffu;      // ... and the shadow cache triangle indices of its arrays (another scene may carry the same generation number)
-    p->free_grid.gen = 0xffffffffu;         // ... and the occupancy grid its geometry
+    p->free_sphere.known_gen = p->free_sphere.asked_gen = 0xffffffffu;      // ... and the free sphere its geometry (a pass in flight lands unused)
     return RT_OK;
 }
 
