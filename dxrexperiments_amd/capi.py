@@ -107,6 +107,7 @@ SIGNATURES = {
     "rt_pipeline_render": (_i, [_p, _u32, _u32]),
     "rt_pipeline_set_shadow_cache": (_i, [_p, _i]),
     "rt_pipeline_get_shadow_cache": (_i, [_p, _p]),
+    "rt_pipeline_get_free_sphere": (_i, [_p, _p]),
     "rt_pipeline_render_batch": (_i, [_p, _u32, _u32, _p, _u32]),
     "rt_pipeline_reserve_batch": (_i, [_p, _u32, _u32, _u32]),
     "rt_pipeline_render_tile": (_i, [_p, _u32, _u32, _u32, _u32, _u32, _u32]),
@@ -528,6 +529,12 @@ class Pipeline:
         n = C.c_int(0)
         _check(lib().rt_pipeline_get_shadow_cache(self.h, C.byref(n)))
         return n.value
+
+    def free_sphere(self):
+        """radius of the empty sphere around the point light of the last update() that its shadow rays stop at (0: not known yet)"""
+        r = C.c_float(0.0)
+        _check(lib().rt_pipeline_get_free_sphere(self.h, C.byref(r)))
+        return r.value
 
     def reserve_batch(self, frames):
         """Size the ray queues for sets of `frames` frames now (the first render_batch of that size then allocates nothing)."""

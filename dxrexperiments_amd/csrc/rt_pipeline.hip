@@ -660,6 +660,22 @@ __global__ void __launch_bounds__(PBLOCK) k_free_sphere(SceneDev sc, uint32_t tw
     if ((threadIdx.x & 63u) == 0u) atomicMin(out_bits, __float_as_uint(d2));          // (non-negative floats order like their bits)
 }
 
+// a pass that has landed becomes what is known
+void free_sphere_poll(rt_pipeline::FreeSphere &f)
+{
+    if (f.in_flight && hipEventQuery(f.landed) == hipSuccess) {
+        f.in_flight = false;
+        f.known_gen = f.asked_gen;
+        memcpy(f.known_lp, f.asked_lp, sizeof f.known_lp);
+        // (0.99 and the term in the coordinates' size -- 32 units in the last place of the largest one -- cover the rounding of
+        // the rays' own arithmetic: a ray's parameter at a triangle is exact to a few ulps of the coordinates, not of the radius)
+        double size = 0.0;
+        for (int c = 0; c < 3; c++) size = fmax(size, fmax(fabs((double)f.asked_lp[c]), (double)f.asked_size));
+        const double r = sqrt((double)*f.h_min) * 0.99 - (double)RAY_EPSILON - size * 4e-6;
+        f.known_radius = r > 0.0 && r < 1e30 ? (float)r : 0.0f;
+    }
+}
+
 float free_radius(rt_pipeline *p, const PipeDev &pd, const float lp[3])
 {
     rt_pipeline::FreeSphere &f = p->free_sphere;
@@ -670,13 +686,7 @@ float free_radius(rt_pipeline *p, const PipeDev &pd, const float lp[3])
         if (hipHostMalloc((void **)&f.h_min, 64, hipHostMallocDefault) != hipSuccess) { f.h_min = nullptr; return 0.0f; }
         if (hipEventCreateWithFlags(&f.landed, hipEventDisableTiming) != hipSuccess || f.d_min.reserve(64) != RT_OK) return 0.0f;
     }
-    if (f.in_flight && hipEventQuery(f.landed) == hipSuccess) {
-        f.in_flight = false;
-        f.known_gen = f.asked_gen;
-        memcpy(f.known_lp, f.asked_lp, sizeof f.known_lp);
-        const double r = sqrt((double)*f.h_min) * 0.99 - (double)RAY_EPSILON;
-        f.known_radius = r > 0.0 && r < 1e30 ? (float)r : 0.0f;
-    }
+    free_sphere_poll(f);
     const bool known = f.known_gen == s->generation && memcmp(f.known_lp, lp, sizeof f.known_lp) == 0;
     const bool asked = f.in_flight && f.asked_gen == s->generation && memcmp(f.asked_lp, lp, sizeof f.asked_lp) == 0;
     if (!known && !asked && !f.in_flight) {
@@ -688,6 +698,9 @@ float free_radius(rt_pipeline *p, const PipeDev &pd, const float lp[3])
         if (hipMemcpyAsync(f.h_min, f.d_min.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(f.landed, st) != hipSuccess) return 0.0f;
         f.in_flight = true;
         f.asked_gen = s->generation;
+        const float *bb = s->two_level ? s->tlas.bounds : s->inst[0].model->blas.bounds;
+        f.asked_size = 0.0f;
+        for (int c = 0; c < 6; c++) f.asked_size = bb[c] == bb[c] ? fmaxf(f.asked_size, fabsf(bb[c])) : __builtin_inff();
         memcpy(f.asked_lp, lp, sizeof f.asked_lp);
     }
     return known ? f.known_radius : 0.0f;
@@ -1120,6 +1133,19 @@ int rt_pipeline_reserve_batch(rt_pipeline *p, uint32_t width, uint32_t height, u
         RT_TRY(prepare_shadow_cache(p, p->pfc, only_allocate));
         p->shadow_cache_dev = ShadowCacheDev{};
     }
+    return RT_OK;
+}
+
+int rt_pipeline_get_free_sphere(rt_pipeline *p, float *radius)
+{
+    RT_REQUIRE(p && radius, "get_free_sphere: null argument");
+    *radius = 0.0f;
+    rt_pipeline::FreeSphere &f = p->free_sphere;
+    if (!p->scene || !p->have_pfc || !f.landed) return RT_OK;
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    free_sphere_poll(f);
+    const float *lp = &p->pfc.pointLight.worldPos.x;
+    if (f.known_gen == p->scene->generation && memcmp(f.known_lp, lp, sizeof f.known_lp) == 0) *radius = f.known_radius;
     return RT_OK;
 }
 

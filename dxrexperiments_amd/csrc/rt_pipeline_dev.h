@@ -58,7 +58,7 @@ struct LightRays {
                                 //   device's expression (IEEE sqrt and division, left-to-right sums, no contraction)
     float point_pos[3];         // pointLight.worldPos
     float point_free;           // no geometry lies nearer to the point light than this (0: unknown): its shadow rays end there
-                                //   (rt_pipeline::free_radius: a lower bound from a coarse occupancy grid of the scene)
+                                //   (free_radius(): a lower bound found by a device pass over the triangles' boxes)
 };
 
 // The shadow cache (round 3): a light buffer of occluders.  An any-hit search only asks WHETHER something lies between a point and
@@ -172,6 +172,7 @@ struct rt_pipeline {
         hipEvent_t landed = nullptr;
         uint32_t asked_gen = 0xffffffffu, known_gen = 0xffffffffu;
         float asked_lp[3] = {0, 0, 0}, known_lp[3] = {0, 0, 0}, known_radius = 0.0f;
+        float asked_size = 0.0f;           // the largest coordinate of the scene's bounds when the pass was queued
         bool in_flight = false;
     } free_sphere;
     // the shadow rays of the primary hits are traced beside the secondary rays (launch_frame): a second stream and the fork /

@@ -75,6 +75,9 @@ public:
     // the light buffer of occluders shadow rays test first (-1 automatic, 0 off, else cells per side): same image, less time
     void setShadowCache(int cellsPerSide) { DXRFramework::ThrowIfFailed(rt_pipeline_set_shadow_cache(mPipeline, cellsPerSide)); }
 
+    // radius of the empty sphere around the point light that its shadow rays stop at (0: not known yet / none)
+    float getFreeSphere() { float r = 0.0f; DXRFramework::ThrowIfFailed(rt_pipeline_get_free_sphere(mPipeline, &r)); return r; }
+
     // sizes the work memory of renderBatch calls of n frames ahead of time (optional)
     void reserveBatch(UINT n, UINT width, UINT height) { DXRFramework::ThrowIfFailed(rt_pipeline_reserve_batch(mPipeline, width, height, n)); }
 

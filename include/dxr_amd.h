@@ -199,8 +199,14 @@ int rt_pipeline_set_skip_unlit_shadow_rays(rt_pipeline *p, int on);
  * (bench scene: shadow stage -19 %).  cells_per_side: -1 automatic (by triangle count; env RT_SHADOW_CACHE_RES overrides),
  * 0 off, else 16..8192 (the table takes 10 * cells^2 bytes, 20 * cells^2 for scenes of several instances). */
 int rt_pipeline_set_shadow_cache(rt_pipeline *p, int cells_per_side);
-/* cells per side the last rendered frame used (0: it ran without the cache -- two-level scene, AO view, or switched off) */
+/* cells per side the last rendered frame used (0: it ran without the cache -- AO view, or switched off) */
 int rt_pipeline_get_shadow_cache(const rt_pipeline *p, int *cells_per_side);
+/* The free sphere around the point light: shootShadowRay towards it (RaytracingCommon.hlsli:84-96, :133-147) ends where no
+ * geometry can lie any more -- a lower bound of the light's distance from the nearest triangle, found by a device pass the first
+ * frame with a new (scene, light position) queues behind itself and later frames pick up when it has landed; the visibility is
+ * the same bit for bit.  Returns the radius in use for the light position of the last update() (0: none known yet, or none
+ * possible: the light touches geometry).  Never waits.  Env RT_FREE_RADIUS=0 switches the sphere off. */
+int rt_pipeline_get_free_sphere(rt_pipeline *p, float *radius);
 int rt_pipeline_clear_output(rt_pipeline *p);
 /* update(): the 188-byte constant buffer the reference fills each frame (.cpp:177-213) */
 int rt_pipeline_update(rt_pipeline *p, const rt_per_frame_constants *constants);

@@ -95,12 +95,27 @@ def run(iters, seed, ctx, verbose=True):
                 host.options[f] = int(r.random() < 0.25)
             host.options["debug"] = int(r.integers(0, 3))
             host.options["environmentStrength"] = float(r.uniform(0.0, 2.0))
+        # lights anywhere -- also inside the geometry -- or the reference's (the shadow cache is keyed by the light, the point
+        # light's shadow rays end at its free sphere); in a set they may move from frame to frame
+        lights = r.random() < 0.6
+        moving = lights and r.random() < 0.4
+
+        def relight(pfc):
+            if lights:
+                pfc["directionalLight"]["forwardDir"][:3] = r.normal(0, 1, 3)
+                pfc["pointLight"]["worldPos"][:3] = r.uniform(-5, 5, 3)
+            return pfc
+        desc["lights"] = "moving" if moving else "random" if lights else "reference"
         eye = r.uniform(-6, 6, 3) + np.array([0, 2, 8.0])
         cam = cam_array(dict(eye=tuple(eye), at=tuple(r.uniform(-1, 1, 3)), up=(0, 1, 0), fov=float(r.uniform(0.4, 1.2))), W / H)
         omats = np.stack(mats)
         acc = np.zeros((H, W, 4), np.float32)
         for f in range(2):
             pfc = host.update_realtime(cam, 0.0, f + 1, W, H) if realtime else host.update(cam, 0.0, f + 1, W, H)
+            if f == 0 or moving:
+                lit = relight(pfc.copy())
+            pfc["directionalLight"] = lit["directionalLight"]
+            pfc["pointLight"] = lit["pointLight"]
             p.update(pfc)
             p.render()
             if realtime:
@@ -116,6 +131,11 @@ def run(iters, seed, ctx, verbose=True):
                 return "MISMATCH %r frame %d image equal: %s gpu %r oracle %r" % (desc, f, ok, {k: gst[k] for k in ost if k in gst}, ost)
         if not realtime:               # the same accumulation continued by a batch of frames in one set of launches
             more = [host.update(cam, 0.0, 3 + k, W, H) for k in range(int(r.integers(1, 6)))]
+            for pfc in more:
+                if moving:
+                    lit = relight(pfc.copy())
+                pfc["directionalLight"] = lit["directionalLight"]
+                pfc["pointLight"] = lit["pointLight"]
             p.render_batch(more)
             for pfc in more:
                 acc, ost = osc.render(omats, pfc, W, H, accum=acc, env_faces=env, max_radiance_depth=depth[0], max_shadow_depth=depth[1], nthreads=8)

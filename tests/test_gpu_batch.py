@@ -254,7 +254,7 @@ def test_shadow_cache_is_invisible(gpu, capi, case):
 
 
 def test_another_scene_on_the_same_pipeline(gpu, capi):
-    """What a pipeline remembers about a scene -- shadow-cache entries (indices into its triangle array), the occupancy grid behind
+    """What a pipeline remembers about a scene -- shadow-cache entries (indices into its triangle array), the distance behind
     the point light's free sphere -- goes when it is given another scene, also one whose generation counter reads the same: the
     small scene rendered after the large one equals the small scene rendered by a fresh pipeline."""
     W, H = 96, 64
@@ -276,3 +276,59 @@ def test_another_scene_on_the_same_pipeline(gpu, capi):
     p.build_acceleration_structures()
     got = both_ways(p, frames_of(capi, cam_small, 6, W, H))
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("scene", ["atrium", "instances"])
+def test_free_sphere_against_the_oracle(gpu, oracle, capi, scene):
+    """rt_pipeline_get_free_sphere: the point light's shadow rays stop at a sphere no triangle reaches into.  The radius arrives
+    behind the first frame (a device pass, never waited for), is a lower bound of the light's distance from every vertex, is none
+    when the light touches geometry, follows the light -- and the image stays the oracle's bit for bit, frame by frame and in sets."""
+    from test_gpu_pipeline import make_oracle_scene
+    W, H = 64, 40
+    if scene == "atrium":
+        models = [scenes.sponza_class(seed=42)]
+        inst = [(0, None)]
+        cam = cam_array(scenes.sponza_camera(), W / H)
+        world = models[0][0]["position"]
+    else:
+        models = [scenes.blob_mesh(level=2), triangle_soup(300, seed=4, extent=2.0, size=0.5)]
+        xf = random_xforms(12, seed=11, spread=6.0)
+        inst = [(k % 2, xf[k]) for k in range(12)]
+        cam = np.array([0, 2, 16, 0, 0, 0, 0, 1, 0, 0.8, W / H], np.float32)
+        world = np.concatenate([models[mi][0]["position"] @ np.asarray(x, np.float64).reshape(3, 4)[:, :3].T + np.asarray(x, np.float64).reshape(3, 4)[:, 3]
+                                for mi, x in inst])
+    mats = [T.default_material() for _ in inst]
+    env = scenes.sky_cubemap(8)
+    p = make_gpu_pipeline(capi, gpu, models, inst, mats, W, H, env=env)
+    osc = make_oracle_scene(oracle, models, inst)
+    omats = np.stack(mats)
+    pfcs = frames_of(capi, cam, 9, W, H)
+    lights = [tuple(pfcs[0]["pointLight"]["worldPos"][:3]),              # the reference's
+              tuple(np.float32(world[len(world) // 3])),                # on a vertex: no room for a sphere
+              (60.0, 45.0, -30.0)]                                      # far outside the scene
+    acc = np.zeros((H, W, 4), np.float32)
+    f = 0
+    for k, lp in enumerate(lights):
+        for c in pfcs[3 * k:3 * k + 3]:
+            c["pointLight"]["worldPos"][:3] = lp
+        p.update(pfcs[f]); p.render()                   # the first frame with this light: queues the pass behind itself
+        acc, _ = osc.render(omats, pfcs[f], W, H, accum=acc, env_faces=env, nthreads=8)
+        assert np.array_equal(p.read_output(), acc)     # (read_output waits for the stream: the pass has landed)
+        r = p.free_sphere()
+        nearest = float(np.sqrt(((world.astype(np.float64) - np.array(lp, np.float64)) ** 2).sum(axis=1).min()))
+        assert 0.0 <= r <= nearest
+        if k == 1:
+            assert r == 0.0
+        elif k == 2:
+            assert r > 0.8 * nearest - 6.0              # (instances: the bound is to their boxes)
+        elif scene == "atrium":
+            assert r > 1.0
+        if k == 1:
+            p.update(pfcs[f + 1]); p.render(); p.update(pfcs[f + 2]); p.render()
+        else:
+            p.render_batch(pfcs[f + 1:f + 3])           # these run with the sphere
+        for c in pfcs[f + 1:f + 3]:
+            acc, _ = osc.render(omats, c, W, H, accum=acc, env_faces=env, nthreads=8)
+        assert np.array_equal(p.read_output(), acc)
+        assert p.free_sphere() == r
+        f += 3
