@@ -478,27 +478,19 @@ RT_DEV void add_totals(const uint32_t *__restrict__ counters, unsigned long long
 
 // what the frame's last kernel does with the colour of pixel slot q (RayGen's tail, ProgressiveRaytracing.hlsl:36-38 /
 // RealtimeRaytracing.hlsl:44-45)
-RT_DEV void write_pixel(const PipeDev &pd, uint32_t px, uint32_t py, const Shaded &sh)
+RT_DEV float4 accumulate(const PipeDev &pd, const float4 prev, const Shaded &sh)
 {
-    const size_t pixel = (size_t)py * pd.width + px;
-    if (pd.kind == RT_PIPELINE_REALTIME) {                  // two AOVs, no accumulation
-        pd.aov_direct[pixel] = make_float4(fmax2(sh.aov_direct.x, 0.0f), fmax2(sh.aov_direct.y, 0.0f), fmax2(sh.aov_direct.z, 0.0f), 1.0f);
-        pd.aov_indirect[pixel] = make_float4(fmax2(sh.aov_indirect.x, 0.0f), fmax2(sh.aov_indirect.y, 0.0f), fmax2(sh.aov_indirect.z, 0.0f), 1.0f);
-        return;
-    }
     const f3 c = sh.color;
     const float4 cur = make_float4(fmax2(c.x, 0.0f), fmax2(c.y, 0.0f), fmax2(c.z, 0.0f), 1.0f);
-    float4 *dst = pd.accum + pixel;
-    const float4 prev = *dst;
-    float4 o;
-    if (pd.accum_mode == RT_ACCUM_SUM) {
-        o = make_float4(prev.x + cur.x, prev.y + cur.y, prev.z + cur.z, prev.w + cur.w);
-    } else {
-        const float n = (float)pd.pfc.cameraParams.accumCount;
-        const float n1 = (float)(pd.pfc.cameraParams.accumCount + 1u);
-        o = make_float4((n * prev.x + cur.x) / n1, (n * prev.y + cur.y) / n1, (n * prev.z + cur.z) / n1, (n * prev.w + cur.w) / n1);
-    }
-    *dst = o;
+    if (pd.accum_mode == RT_ACCUM_SUM) return make_float4(prev.x + cur.x, prev.y + cur.y, prev.z + cur.z, prev.w + cur.w);
+    const float n = (float)pd.pfc.cameraParams.accumCount;
+    const float n1 = (float)(pd.pfc.cameraParams.accumCount + 1u);
+    return make_float4((n * prev.x + cur.x) / n1, (n * prev.y + cur.y) / n1, (n * prev.z + cur.z) / n1, (n * prev.w + cur.w) / n1);
+}
+RT_DEV void write_aovs(const PipeDev &pd, size_t pixel, const Shaded &sh)          // two AOVs, no accumulation
+{
+    pd.aov_direct[pixel] = make_float4(fmax2(sh.aov_direct.x, 0.0f), fmax2(sh.aov_direct.y, 0.0f), fmax2(sh.aov_direct.z, 0.0f), 1.0f);
+    pd.aov_indirect[pixel] = make_float4(fmax2(sh.aov_indirect.x, 0.0f), fmax2(sh.aov_indirect.y, 0.0f), fmax2(sh.aov_indirect.z, 0.0f), 1.0f);
 }
 
 // FLAT = false: one bounce at most, the secondary hits are shaded inline (ResolveIO<0, 1>); FLAT = true: their colours
@@ -514,6 +506,15 @@ __global__ void __launch_bounds__(PBLOCK) k_resolve(PipeDev pd_arg)
     if (!pix_xy(pd, ql, px, py)) return;
     // a batch: the frames of a pixel one after the other, in frame order, so that the running mean is the one S single
     // frames would have left (each frame with its own accumCount)
+    // (one bounce: the pixel's running value stays in registers from the first frame of the set to the last, resolve -4 %; the
+    //  level-by-level form would pay for the four registers with its fifth wave: profiles/r03/resolve_registers.txt)
+    const size_t pixel = (size_t)py * pd.width + px;
+    const bool progressive = pd.kind != RT_PIPELINE_REALTIME;
+#ifndef RT_RESOLVE_REG_ACC
+#define RT_RESOLVE_REG_ACC 1
+#endif
+    constexpr bool KEEP = BATCH && !FLAT && RT_RESOLVE_REG_ACC;
+    float4 acc = KEEP && progressive ? pd.accum[pixel] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (uint32_t f = 0; f < (BATCH ? pd.n_frames : 1u); f++) {
         if (BATCH) pd.pfc = pd.pfcs[f];
         const uint32_t q = frame_slot(pd, f, ql);
@@ -531,8 +532,10 @@ __global__ void __launch_bounds__(PBLOCK) k_resolve(PipeDev pd_arg)
             ResolveIO<0, 1> io(pd, pd.lv[0].slot_j[q], px + py * pd.width);
             sh = closest_hit_aov(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.lv[0].inst[q], 0u, px + py * pd.width);
         }
-        write_pixel(pd, px, py, sh);
+        if (progressive) { acc = accumulate(pd, KEEP ? acc : pd.accum[pixel], sh); if (!KEEP) pd.accum[pixel] = acc; }
+        else write_aovs(pd, pixel, sh);
     }
+    if (KEEP && progressive) pd.accum[pixel] = acc;
 }
 
 // deep paths: the colour of every hit of level L >= 1 (its shadow rays are traced, the hits of level L + 1 already shaded)
