@@ -695,8 +695,7 @@ float free_radius(rt_pipeline *p, const PipeDev &pd, const float lp[3])
     if (!known && !asked && !f.in_flight) {
         const uint32_t n = s->two_level ? (uint32_t)s->inst.size() : (s->inst.empty() || !s->inst[0].model ? 0u : s->inst[0].model->n_tris);
         if (n == 0u || !f.landed) return 0.0f;
-        const uint32_t inf_bits = 0x7f800000u;
-        if (hipMemcpyAsync(f.d_min.p, &inf_bits, 4, hipMemcpyHostToDevice, st) != hipSuccess) return 0.0f;
+        if (hipMemsetD32Async((hipDeviceptr_t)f.d_min.p, 0x7f800000, 1, st) != hipSuccess) return 0.0f;      // +inf
         k_free_sphere<<<(n + PBLOCK - 1) / PBLOCK, PBLOCK, 0, st>>>(pd.sc, s->two_level ? 1u : 0u, n, lp[0], lp[1], lp[2], f.d_min.as<uint32_t>());
         if (hipMemcpyAsync(f.h_min, f.d_min.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(f.landed, st) != hipSuccess) return 0.0f;
         f.in_flight = true;
