@@ -601,6 +601,15 @@ def main():
 
     if S > 1:
         pipe.reserve_batch(S)           # the work memory of a set of S frames: sized outside the timed region, like the output
+    if os.environ.get("DXR_BENCH_PREROLL"):       # experiment (profiles/r03/shadow_cache_coarse_level.txt): frames on ANOTHER pipeline first
+        other = capi.Pipeline(ctx)
+        other.set_scene(scene); other.add_material(mat); other.set_environment_cube(env)
+        other.create_output(W, H)
+        n_pre = int(os.environ["DXR_BENCH_PREROLL"])
+        for f0 in range(0, n_pre, 20):
+            other.render_batch([host.update(cam11, 0.0, 10000 + f, W, H) for f in range(f0, min(f0 + 20, n_pre))])
+        torch.cuda.synchronize()
+        other.close()
     steps(0, Wu)
     if world > 1:                       # warm the collective too
         dist.all_reduce(torch.zeros_like(acc))
