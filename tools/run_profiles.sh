@@ -3,7 +3,7 @@
 # a kernel-trace pass and separate PMC passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950; SQ and TCC
 # sets in passes of their own), each around the same bench command.
 # usage: tools/run_profiles.sh <tag> [workloads...]    -> gpurun_out/<tag>/<workload>_<pass>.md (+ .log)
-# workloads: c2h (THE bench default: `python3 bench.py`, whatever it runs), c2 (the bench scene frame by frame), c5 (10 M triangles 4K), c4 (4096 instances 4K realtime + denoiser: tools/profile_c4.py),
+# workloads: c2h (THE bench default: `python3 bench.py`, whatever it runs), c2d (the driver's form: --gpus 1 --steps 20 --warmup 5), c2 (the bench scene frame by frame), c5 (10 M triangles 4K), c4 (4096 instances 4K realtime + denoiser: tools/profile_c4.py),
 #            c2b / c5b (the same two with 8 frames per set of launches, rt_pipeline_render_batch); PASSES="kt ea write" limits the passes
 TAG=${1:-r02}; shift
 WL=${@:-c2 c5}
@@ -14,6 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 for w in $WL; do
   PROG=$R/bench.py
   if [ $w = c2h ]; then ARGS="--cpu-seconds 0 --no-live-pmc";
+  elif [ $w = c2d ]; then ARGS="--gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --no-live-pmc";       # the driver's form of the command
   elif [ $w = c2 ]; then ARGS="--steps 8 --warmup 2 --batch 1 --cpu-seconds 0 --hbm-frames 0 --no-live-pmc";
   elif [ $w = c2b ]; then ARGS="--steps 60 --warmup 30 --cpu-seconds 0 --hbm-frames 0 --no-live-pmc --no-frame-by-frame --no-roofline";       # the headline launches only: sets of 30 frames
   elif [ $w = c5 ]; then ARGS="--workload c5 --hbm-frames 4 --no-live-pmc";
