@@ -38,7 +38,8 @@ class StageWork(C.Structure):
 
 class StageWalk(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_global", C.c_uint64), ("nodes_lds", C.c_uint64), ("tris", C.c_uint64),
-                ("instance_entries", C.c_uint64), ("lines", C.c_uint64), ("longest_walk", C.c_uint64), ("longest_walk_ray", C.c_uint64)]
+                ("instance_entries", C.c_uint64), ("lines", C.c_uint64), ("longest_walk", C.c_uint64), ("longest_walk_ray", C.c_uint64),
+                ("wave_node_steps", C.c_uint64), ("wave_leaf_phases", C.c_uint64), ("wave_tri_steps", C.c_uint64)]
 
 
 STAGES = ("primary", "secondary", "shadow0", "shadow1")

@@ -497,30 +497,6 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
     s->h_inst.assign(n, InstanceRec());
     std::vector<Box6> hb(n);
     uint32_t deepest = 0;
-    // the two models most instances use get LDS room for the top of their BLAS in the two-level kernels (rt_trace_wave.h)
-    {
-        std::vector<std::pair<rt_model *, uint32_t>> use;
-        for (uint32_t i = 0; i < n; i++) {
-            rt_model *m = s->inst[i].model;
-            size_t k = 0;
-            while (k < use.size() && use[k].first != m) k++;
-            if (k == use.size()) { if (use.size() < 4096) use.push_back(std::make_pair(m, 0u)); else continue; }
-            use[k].second++;
-        }
-        s->lds_blas[0] = s->lds_blas[1] = nullptr;
-        // (only a library built with -DRT_LDS_BLAS_TOPS uses this: round 3's experiment, rt_trace_wave.h)
-#ifdef RT_LDS_BLAS_TOPS
-        const bool on = true;
-#else
-        const bool on = false;
-#endif
-        for (int slot = 0; slot < 2 && on; slot++) {
-            size_t best = use.size();
-            for (size_t k = 0; k < use.size(); k++)
-                if (use[k].first != s->lds_blas[0] && use[k].first->blas.wide_n > 0 && (best == use.size() || use[k].second > use[best].second)) best = k;
-            if (best < use.size()) s->lds_blas[slot] = use[best].first;
-        }
-    }
     for (uint32_t i = 0; i < n; i++) {
         rt_model *m = s->inst[i].model;
         InstanceRec &r = s->h_inst[i];
@@ -550,7 +526,7 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
             }
         }
         r.root_code = m->blas.root_code;
-        r.flags = (identity ? RT_INST_IDENTITY : 0u) | (m == s->lds_blas[0] ? 1u << 8 : m == s->lds_blas[1] ? 2u << 8 : 0u);
+        r.flags = identity ? RT_INST_IDENTITY : 0u;
         r.wide = m->blas.wide.as<WNode>();
         r.tris = m->tris.as<TriRec>();
         r.cnodes = m->blas.nodes.as<rt_bvh_node>();

@@ -139,8 +139,6 @@ struct SceneDev {
     int *deep_stack;             // global stack rows beyond the LDS rows (rt_trace_wave.h); nullptr: never needed
     uint32_t top_n;              // nodes 0..top_n-1 of the structure a ray starts in (single-level: the BLAS, two-level: the
                                  //   TLAS) are copied into LDS by every traversal workgroup
-    const WNode *blas_top[2];    // two-level: the node arrays of the two BLASes most instances use (their instances carry
-    uint32_t blas_top_n[2];      //   slot 1 / 2 in InstanceRec::flags bits 8-9) and how many of their first nodes go to LDS
 };
 
 #ifndef RT_TOP_NODES
@@ -151,10 +149,6 @@ struct SceneDev {
 #define RT_TOP_NODES  128             // 8 KiB (with four-wide nodes the size hardly matters: 32 .. 192 nodes all within 1 %)
 #endif
 #endif
-// a library built with -DRT_LDS_BLAS_TOPS: in two-level scenes the table holds the top of the TLAS and the tops of the two
-// most-instanced BLASes (rt_trace_wave.h); otherwise the TLAS has all of it
-#define RT_TOP_TLAS (RT_TOP_NODES / 2)
-#define RT_TOP_BLAS (RT_TOP_NODES / 4)
 #define RT_TOP_ROWS(BLOCK) ((RT_TOP_NODES * RT_TOP_WORDS + (BLOCK) - 1) / (BLOCK))      // LDS rows (of BLOCK ints) the top table takes
 
 
@@ -234,7 +228,6 @@ struct rt_scene {
     float build_ms = 0.0f;
     uint32_t stack_need = 0;     // traversal stack entries a ray can hold at once
     bool two_level = true;       // false: one identity instance, rays walk its BLAS directly
-    rt_model *lds_blas[2] = {nullptr, nullptr};      // the two models most instances use: the tops of their BLASes are LDS resident
     SceneDev dev() const
     {
         SceneDev s;
@@ -245,8 +238,6 @@ struct rt_scene {
         s.tlas_root_code = tlas.root_code;
         s.deep_stack = nullptr;
         s.top_n = 0;
-        s.blas_top[0] = s.blas_top[1] = nullptr;
-        s.blas_top_n[0] = s.blas_top_n[1] = 0;
         return s;
     }
 };
@@ -314,15 +305,7 @@ static inline int rt_scene_dev_for_launch(rt_context *ctx, const rt_scene *s, ui
     *out = s->dev();
     if (ctx->lds_top) {          // one identity instance: rays walk its BLAS directly; otherwise the top of the TLAS
         const BvhDev &bv = s->two_level ? s->tlas : s->inst[0].model->blas;
-        const uint32_t room = s->two_level && (s->lds_blas[0] || s->lds_blas[1]) ? RT_TOP_TLAS : RT_TOP_NODES;
-        out->top_n = bv.wide_n < room ? bv.wide_n : room;
-        if (s->two_level)
-            for (int k = 0; k < 2; k++)
-                if (s->lds_blas[k]) {
-                    const BvhDev &b = s->lds_blas[k]->blas;
-                    out->blas_top[k] = b.wide.as<WNode>();
-                    out->blas_top_n[k] = b.wide_n < RT_TOP_BLAS ? b.wide_n : RT_TOP_BLAS;
-                }
+        out->top_n = bv.wide_n < RT_TOP_NODES ? bv.wide_n : RT_TOP_NODES;
     }
     const uint32_t bound = s->stack_need + 2;
     if (bound <= lds_rows) return RT_OK;

@@ -397,9 +397,6 @@ struct ShadowSrcN : ShadowQueues {
         // (a slot that the stack has overwritten in the meantime is some other number: inside the table it only makes a stale entry)
         const uint32_t entries = cache.res * cache.res + 6u * (cache.res >> 1) * (cache.res >> 1);
         if (!cache.table || slot >= entries) return;
-#ifdef RT_TRACE_STATS     /* instrumentation build (tools/trace_stats.py): occluded rays answered by their cell's entry / by the walk */
-        atomicAdd(&rtd::g_trace_sp_hist[cache.table[TWO_LEVEL ? 2u * slot : slot] == sorted_triangle ? 60 : 61], 1ull);
-#endif
         if (TWO_LEVEL) ((uint2 *)cache.table)[slot] = make_uint2(sorted_triangle, instance);
         else cache.table[slot] = sorted_triangle;
     }
@@ -913,18 +910,18 @@ static int count_walk_launch(rt_pipeline *p, unsigned long long *w)
     const PipeDev &pd = p->last_pd;
     const uint32_t cap = pd.cap, ss = p->last_shadow_slots;
     const uint32_t any = RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH | RT_RAY_FLAG_SKIP_CLOSEST_HIT_SHADER;
-    k_walk_primary<TWO_LEVEL><<<rt_persistent_grid(ctx, k_walk_primary<TWO_LEVEL>, PBLOCK, cap), PBLOCK, 0, st>>>(pd, w + 7 * RT_STAGE_PRIMARY);
+    k_walk_primary<TWO_LEVEL><<<rt_persistent_grid(ctx, k_walk_primary<TWO_LEVEL>, PBLOCK, cap), PBLOCK, 0, st>>>(pd, w + RT_WALK_WORDS * RT_STAGE_PRIMARY);
     const unsigned gq = rt_persistent_grid(ctx, k_walk_queue<TWO_LEVEL>, PBLOCK, (size_t)cap * 2);
     const unsigned gs = rt_persistent_grid(ctx, k_walk_shadow<TWO_LEVEL>, PBLOCK, (size_t)cap * 2);
     const LightRays lr = light_rays(pd), none = no_light_rays();
     const LightRays *fl = pd.n_frames > 1u ? pd.frame_lights : nullptr;
-    k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any}, lr}, fl}, w + 7 * RT_STAGE_SHADOW0);
+    k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any}, lr}, fl}, w + RT_WALK_WORDS * RT_STAGE_SHADOW0);
     const uint32_t levels = pd.max_rad < (uint32_t)MAXD ? pd.max_rad : (uint32_t)MAXD;
     for (uint32_t l = 1; l <= levels; l++) {
         k_walk_queue<TWO_LEVEL><<<gq, PBLOCK, 0, st>>>(pd.sc, QueueSrc{{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE}, none},
-                                                       w + 7 * RT_STAGE_SECONDARY);
+                                                       w + RT_WALK_WORDS * RT_STAGE_SECONDARY);
         if (l < pd.max_shadow)
-            k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any}, lr}, fl}, w + 7 * RT_STAGE_SHADOW1);
+            k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any}, lr}, fl}, w + RT_WALK_WORDS * RT_STAGE_SHADOW1);
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -1157,7 +1154,7 @@ int rt_pipeline_count_work(rt_pipeline *p, rt_stage_work *out)
     if (!p->rendered || !p->scene->built || p->scene->generation != p->last_scene_gen) { rt_set_error("count_work: nothing rendered since the last change of scene, materials or output"); return RT_ERR_STATE; }
     HIP_TRY(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->stream;
-    RT_TRY(p->work.reserve(RT_STAGE_COUNT * 7 * sizeof(unsigned long long)));
+    RT_TRY(p->work.reserve(RT_STAGE_COUNT * RT_WALK_WORDS * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(p->work.p, 0, RT_STAGE_COUNT * 3 * sizeof(unsigned long long), st));
     unsigned long long *w = p->work.as<unsigned long long>();
     const PipeDev &pd = p->last_pd;
@@ -1191,20 +1188,22 @@ int rt_pipeline_count_walk(rt_pipeline *p, rt_stage_walk *out)
     if (!p->rendered || !p->scene->built || p->scene->generation != p->last_scene_gen) { rt_set_error("count_walk: nothing rendered since the last change of scene, materials or output"); return RT_ERR_STATE; }
     HIP_TRY(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->stream;
-    const size_t bytes = RT_STAGE_COUNT * 7 * sizeof(unsigned long long);
+    const size_t bytes = RT_STAGE_COUNT * RT_WALK_WORDS * sizeof(unsigned long long);
     RT_TRY(p->work.reserve(bytes));
     HIP_TRY(hipMemsetAsync(p->work.p, 0, bytes, st));
     unsigned long long *w = p->work.as<unsigned long long>();
     if (p->scene->two_level) RT_TRY(count_walk_launch<true>(p, w));
     else RT_TRY(count_walk_launch<false>(p, w));
-    unsigned long long h[RT_STAGE_COUNT * 7];
+    unsigned long long h[RT_STAGE_COUNT * RT_WALK_WORDS];
     HIP_TRY(hipMemcpyAsync(h, w, sizeof h, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (int k = 0; k < RT_STAGE_COUNT; k++) {
-        out[k].rays = h[7 * k]; out[k].nodes_global = h[7 * k + 1]; out[k].nodes_lds = h[7 * k + 2];
-        out[k].tris = h[7 * k + 3]; out[k].instance_entries = h[7 * k + 4]; out[k].lines = h[7 * k + 5];
-        out[k].longest_walk = h[7 * k + 6] >> 32;
-        out[k].longest_walk_ray = (uint32_t)h[7 * k + 6];
+        const unsigned long long *hk = h + RT_WALK_WORDS * k;
+        out[k].rays = hk[0]; out[k].nodes_global = hk[1]; out[k].nodes_lds = hk[2];
+        out[k].tris = hk[3]; out[k].instance_entries = hk[4]; out[k].lines = hk[5];
+        out[k].longest_walk = hk[6] >> 32;
+        out[k].longest_walk_ray = (uint32_t)hk[6];
+        out[k].wave_node_steps = hk[7]; out[k].wave_leaf_phases = hk[8]; out[k].wave_tri_steps = hk[9];
     }
     return RT_OK;
 }
@@ -1248,33 +1247,6 @@ int rt_pipeline_read_primary_hits(rt_pipeline *p, float *t, uint32_t *prim, uint
     }
     return RT_OK;
 }
-
-#ifdef RT_TRACE_STATS
-// instrumentation build only: wave / lane counters of the pipeline's traversal kernels since the last call
-int rt_debug_trace_stats(unsigned long long out[8 + 64])
-{
-    unsigned long long zero[64];
-    memset(zero, 0, sizeof zero);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rtd::g_trace_stats), 8 * sizeof zero[0]));
-    HIP_TRY(hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(rtd::g_trace_sp_hist), sizeof zero));
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rtd::g_trace_stats), zero, 8 * sizeof zero[0]));
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rtd::g_trace_sp_hist), zero, sizeof zero));
-    return RT_OK;
-}
-#endif
-
-#ifdef RT_TRACE_TIMES
-// instrumentation build only: select the launches whose waves record their times (0 closest-hit queues, 1 any-hit queues) /
-// read the 4 x 8192 records of the last such launch
-int rt_debug_wave_times(int select, unsigned long long *out)
-{
-    HIP_TRY(hipDeviceSynchronize());
-    if (out) HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rtd::g_trace_wave_t), 4 * 8192 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rtd::g_trace_sel), &select, sizeof select));
-    return RT_OK;
-}
-#endif
 
 int rt_debug_sample_cube(rt_context *ctx, const float *faces, uint32_t size, uint32_t filter, const float *dirs, float *out, size_t n)
 {

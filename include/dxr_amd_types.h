@@ -169,6 +169,11 @@ typedef struct rt_stage_walk {
                                     the one or two lines each triangle record spans                                   */
     uint64_t longest_walk;       /* node steps of the stage's longest single ray (persistent kernels end with their slowest lane) */
     uint64_t longest_walk_ray;   /* ... and that ray's index in its queue (last launch of the stage) */
+    /* what the WAVES of the walk did (round 4): with the per-lane tallies above, the lane utilisation of the walk's two halves,
+     * (nodes_global + nodes_lds) / (64 * wave_node_steps) and tris / (64 * wave_tri_steps)                             */
+    uint64_t wave_node_steps;    /* node steps issued: one per wave per pass of the node loop                        */
+    uint64_t wave_leaf_phases;   /* leaf phases (triangles, instance entry / exit, ray end) entered by a wave         */
+    uint64_t wave_tri_steps;     /* triangle-test iterations issued by the waves' leaf phases                         */
 } rt_stage_walk;
 
 /* Status codes returned by every export. */

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """When do the waves of a persistent traversal launch run out of queue, and when do they leave?  (instrumentation build)
 
+  (the wave clocks live in dxrexperiments_amd/csrc/experiments/r03_traversal_experiments.patch since round 4: apply it first)
   tools/build_variant.sh times -DRT_TRACE_TIMES
   DXR_AMD_LIB=$PWD/dxrexperiments_amd/lib/variants/libtimes.so python tools/drain_timeline.py
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """SIMD utilisation of the traversal engine on the bench workload (instrumentation build only).
 
+  (the counters live in dxrexperiments_amd/csrc/experiments/r03_traversal_experiments.patch since round 4: apply it first)
   tools/build_variant.sh stats -DRT_TRACE_STATS [other -D flags]
   DXR_AMD_LIB=$PWD/dxrexperiments_amd/lib/variants/libstats.so python tools/trace_stats.py [instances]
 
