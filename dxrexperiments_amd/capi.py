@@ -39,7 +39,8 @@ class StageWork(C.Structure):
 class StageWalk(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_global", C.c_uint64), ("nodes_lds", C.c_uint64), ("tris", C.c_uint64),
                 ("instance_entries", C.c_uint64), ("lines", C.c_uint64), ("longest_walk", C.c_uint64), ("longest_walk_ray", C.c_uint64),
-                ("wave_node_steps", C.c_uint64), ("wave_leaf_phases", C.c_uint64), ("wave_tri_steps", C.c_uint64)]
+                ("wave_node_steps", C.c_uint64), ("wave_leaf_phases", C.c_uint64), ("wave_tri_steps", C.c_uint64),
+                ("node_lines", C.c_uint64)]
 
 
 STAGES = ("primary", "secondary", "shadow0", "shadow1")
@@ -137,6 +138,13 @@ SIGNATURES = {
     "rt_pipeline_count_work": (_i, [_p, C.POINTER(StageWork)]),
     "rt_pipeline_count_walk": (_i, [_p, C.POINTER(StageWalk)]),
     "rt_pipeline_render_bands": (_i, [_p, _u32, _u32, _u32, _u32, _u32]),
+    "rt_pipeline_render_bands_batch": (_i, [_p, _u32, _u32, _u32, _u32, _u32, _p, _u32]),
+    "rt_pipeline_set_deferred": (_i, [_p, _u32]),
+    "rt_pipeline_get_deferred": (_i, [_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rt_pipeline_flush": (_i, [_p]),
+    "rt_pipeline_set_queue_budget": (_i, [_p, _sz]),
+    "rt_pipeline_get_queue_memory": (_i, [_p, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]),
+    "rt_debug_set_alloc_limit": (_i, [_sz]),
     "rt_debug_read_secondary_ray": (_i, [_p, _u32, _p, _p]),
     "rt_camera_look": (_i, [_p, _p, _p, _p, _p]),
     "rt_camera_basis": (_i, [_p, _p, _f, _f, _p, _p, _p]),
@@ -389,6 +397,12 @@ class Scene:
         _check(lib().rt_scene_wide_read(self.h, which, _ptr(nodes), _ptr(recs)))
         return nodes, root.value, recs
 
+    def wide_counts(self, which=0):
+        """(nodes, records) of the production traversal layout: which = -1 the TLAS, k >= 0 the BLAS of instance k's model"""
+        n, root, m = C.c_uint32(), C.c_int32(), C.c_uint32()
+        _check(lib().rt_scene_wide_info(self.h, which, C.byref(n), C.byref(root), C.byref(m)))
+        return n.value, m.value
+
     def wide_write(self, nodes, which=0):
         nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
         _check(lib().rt_debug_wide_write(self.h, which, _ptr(nodes), nodes.shape[0]))
@@ -545,6 +559,37 @@ class Pipeline:
         """One frame over this rank's interleaved row bands (tile-partitioned multi-GPU runs)."""
         _check(lib().rt_pipeline_render_bands(self.h, self.width, self.height, band_rows, rank, world))
 
+    def render_bands_batch(self, band_rows, rank, world, constants):
+        """len(constants) frames over this rank's interleaved row bands through shared sets of launches: render_batch for a
+        tile-partitioned run (bit for bit the same rows of the whole frames)."""
+        buf = np.ascontiguousarray(np.stack([np.frombuffer(np.asarray(c).tobytes(), np.uint8) for c in constants]))
+        assert buf.shape[1] == 188
+        _check(lib().rt_pipeline_render_bands_batch(self.h, self.width, self.height, band_rows, rank, world, _ptr(buf), buf.shape[0]))
+
+    def set_deferred(self, max_frames):
+        """Sets of frames behind update() + render(): render() only records the frame; the recorded frames go through ONE set
+        of launches when max_frames (<= 32) have gathered or when anything reads or changes what they produce.  0 / 1: off."""
+        _check(lib().rt_pipeline_set_deferred(self.h, int(max_frames)))
+
+    def deferred(self):
+        """(max frames per set, frames recorded and not rendered yet)"""
+        m, n = C.c_uint32(0), C.c_uint32(0)
+        _check(lib().rt_pipeline_get_deferred(self.h, C.byref(m), C.byref(n)))
+        return m.value, n.value
+
+    def flush(self):
+        _check(lib().rt_pipeline_flush(self.h))
+
+    def set_queue_budget(self, nbytes):
+        """Worst-case queue bytes a set of launches may reserve up front; above it the levels are sized by count (0: default)."""
+        _check(lib().rt_pipeline_set_queue_budget(self.h, int(nbytes)))
+
+    def queue_memory(self):
+        """(bytes of ray / hit / shadow queues reserved, whether the last set sized its levels by count)"""
+        b, c = C.c_size_t(0), C.c_uint32(0)
+        _check(lib().rt_pipeline_get_queue_memory(self.h, C.byref(b), C.byref(c)))
+        return b.value, bool(c.value)
+
     @property
     def num_outputs(self):
         n = C.c_int()
@@ -600,7 +645,8 @@ class Pipeline:
 
     def count_walk(self):
         """What the PRODUCTION traversal fetched for the last frame per stage:
-        {stage: dict(rays, nodes_global, nodes_lds, tris, instance_entries, lines, longest_walk, longest_walk_ray)}."""
+        {stage: dict(rays, nodes_global, nodes_lds, tris, instance_entries, lines, longest_walk, longest_walk_ray,
+        wave_node_steps, wave_leaf_phases, wave_tri_steps)}."""
         w = (StageWalk * len(STAGES))()
         _check(lib().rt_pipeline_count_walk(self.h, w))
         return {n: {f: int(getattr(w[i], f)) for f, _ in StageWalk._fields_} for i, n in enumerate(STAGES)}

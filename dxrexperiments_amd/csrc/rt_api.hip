@@ -16,6 +16,18 @@ void rt_set_error(const char *fmt, ...)
     g_last_error = buf;
 }
 
+size_t &rt_alloc_limit_ref()
+{
+    static size_t limit = ~(size_t)0;
+    return limit;
+}
+
+extern "C" int rt_debug_set_alloc_limit(size_t bytes)
+{
+    rt_alloc_limit_ref() = bytes ? bytes : ~(size_t)0;
+    return RT_OK;
+}
+
 namespace {
 
 using namespace rtd;
@@ -191,6 +203,7 @@ int rt_context_synchronize(rt_context *ctx)
 {
     RT_REQUIRE(ctx, "null context");
     RT_TRY(use_device(ctx));
+    RT_TRY(rt_context_flush_deferred(ctx));          // frames a deferred pipeline still holds are part of "everything submitted"
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
@@ -364,6 +377,7 @@ int rt_scene_add_model(rt_scene *s, rt_model *m, const float transform3x4[12])
 {
     RT_REQUIRE(s && m && transform3x4, "null argument");
     RT_REQUIRE(m->ctx == s->ctx, "model and scene belong to different contexts");
+    RT_TRY(rt_context_flush_deferred(s->ctx));       // frames accepted before this change see the scene as it was
     SceneInstance in;
     in.model = m;
     memcpy(in.xform, transform3x4, sizeof in.xform);
@@ -388,6 +402,7 @@ int rt_scene_build(rt_scene *s, uint32_t hit_group_count)
     RT_REQUIRE(!s->inst.empty(), "scene has no instances");
     rt_context *ctx = s->ctx;
     RT_TRY(use_device(ctx));
+    RT_TRY(rt_context_flush_deferred(ctx));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(hipEventCreate(&e0));
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); rt_set_error("rt_scene_build: hipEventCreate failed"); return RT_ERR_HIP; }

@@ -346,8 +346,10 @@ int lbvh_from_boxes(rt_context *ctx, BvhDev &bv, const Box6 *boxes, uint32_t n, 
 {
     hipStream_t st = ctx->stream;
     const unsigned B = 256;
-    // the traversal addresses a 128-B node as base + (index << 7) with a 32-bit byte offset (rt_trace_wave.h)
-    if (n > (1u << 25)) { rt_set_error("acceleration structure over %u primitives: the limit is 2^25 (33,554,432)", n); return RT_ERR_UNSUPPORTED; }
+    // the traversal addresses a node as base + (index << RT_NODE_SHIFT) with a 32-bit byte offset (rt_trace_wave.h): 64-B nodes
+    // leave room for 2^26 of them
+    constexpr uint32_t kMaxPrims = 1u << (32 - RT_NODE_SHIFT);
+    if (n > kMaxPrims) { rt_set_error("acceleration structure over %u primitives: the limit is 2^%d (%u)", n, 32 - RT_NODE_SHIFT, kMaxPrims); return RT_ERR_UNSUPPORTED; }
     bv.n = n;
     RT_TRY(bv.nodes.reserve(sizeof(rt_bvh_node) * (2 * (size_t)n - 1)));
     RT_TRY(bv.keys.reserve(sizeof(uint64_t) * n));

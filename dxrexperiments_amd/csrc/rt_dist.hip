@@ -16,6 +16,7 @@
 // first); never re-exec a process that has initialised HIP.
 #include <dirent.h>
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
@@ -117,33 +118,47 @@ std::string rendezvous_path(const void *id128, int rank)
 
 int check_one_device_per_rank(const rt_context *ctx, int rank, int world, const void *id128, std::string *mine)
 {
-    double limit = 20.0;
+    // how long a rank waits for the others' entries: ranks of one launcher arrive within milliseconds of each other, a rank on
+    // another node never does -- so a few seconds by default (RT_DIST_CHECK_SECONDS; a rank that is not seen in time is simply
+    // not checked), and no wait at all beyond the ranks the launcher says are local (LOCAL_WORLD_SIZE)
+    double limit = 5.0;
     if (const char *e = getenv("RT_DIST_CHECK_SECONDS")) limit = atof(e);
     if (world < 2 || !(limit > 0.0)) return RT_OK;
     char bus[64] = {0};
     if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, ctx->device) != hipSuccess) return RT_OK;       // nothing to compare
-    {   // entries a failed create left behind (see below) are swept once they are ten minutes old
+    {   // entries a failed create of THIS user left behind (see below) are swept once they are ten minutes old
         if (DIR *dir = opendir("/dev/shm")) {
             const time_t now = time(nullptr);
+            const uid_t me = geteuid();
             while (struct dirent *e = readdir(dir)) {
                 if (strncmp(e->d_name, "dxr_amd_", 8) != 0) continue;
                 const std::string old = std::string("/dev/shm/") + e->d_name;
                 struct stat sb;
-                if (stat(old.c_str(), &sb) == 0 && now - sb.st_mtime > 600) unlink(old.c_str());
+                if (lstat(old.c_str(), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_uid == me && now - sb.st_mtime > 600) unlink(old.c_str());
             }
             closedir(dir);
         }
     }
     const std::string path = rendezvous_path(id128, rank), tmp = path + ".tmp";
-    FILE *f = fopen(tmp.c_str(), "w");
-    if (!f) return RT_OK;                                                                          // no /dev/shm: skip
-    fprintf(f, "%s\n", bus);
-    fclose(f);
-    if (rename(tmp.c_str(), path.c_str()) != 0) { unlink(tmp.c_str()); return RT_OK; }
+    // (a world-writable directory: the entry is created exclusively, never through a link somebody else has put there, and
+    // readable by its owner only -- the ranks of one job run as one user)
+    (void)unlink(tmp.c_str());
+    const int fd = open(tmp.c_str(), O_CREAT | O_EXCL | O_NOFOLLOW | O_WRONLY | O_CLOEXEC, 0600);
+    if (fd < 0) return RT_OK;                                                                      // no /dev/shm: skip
+    const size_t len = strlen(bus);
+    const bool wrote = write(fd, bus, len) == (ssize_t)len && write(fd, "\n", 1) == 1;
+    close(fd);
+    if (!wrote || rename(tmp.c_str(), path.c_str()) != 0) { unlink(tmp.c_str()); return RT_OK; }
     *mine = path;
     struct timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (int r = 0; r < world; r++) {
+    // the ranks of this node, if the launcher says which (torchrun: LOCAL_WORLD_SIZE consecutive ranks per node)
+    int first = 0, last = world;
+    if (const char *e = getenv("LOCAL_WORLD_SIZE")) {
+        const int lw = atoi(e);
+        if (lw >= 1 && lw <= world) { first = rank / lw * lw; last = first + lw < world ? first + lw : world; }
+    }
+    for (int r = first; r < last; r++) {
         if (r == rank) continue;
         const std::string other = rendezvous_path(id128, r);
         for (;;) {

@@ -36,6 +36,11 @@ void rt_set_error(const char *fmt, ...);
         }                                            \
     } while (0)
 
+// Test hook (rt_debug_set_alloc_limit): device allocations above this many bytes fail with RT_ERR_OOM as if the device were
+// full, so that the out-of-memory paths can be exercised on a 288 GB part.  Default: no limit.
+size_t &rt_alloc_limit_ref();
+static inline size_t rt_alloc_limit() { return rt_alloc_limit_ref(); }
+
 // Owning device allocation; grows on demand, never shrinks.
 struct DevBuf {
     void *p = nullptr;
@@ -43,18 +48,30 @@ struct DevBuf {
     bool borrowed = false;       // p points into somebody else's allocation (adopt): never freed here
     // use a slice of another allocation; a later reserve() beyond it falls back to an allocation of its own
     void adopt(void *ptr, size_t n) { release(); p = ptr; bytes = n; borrowed = ptr != nullptr; }
+    // Grows to at least n bytes (contents are NOT kept).  The new block is allocated BEFORE the old one is freed, so a
+    // growth that fails leaves the buffer as it was; only when old + new do not fit together is the old block given up
+    // first -- and then a second failure leaves an EMPTY buffer (p = nullptr, bytes = 0), never a stale pointer.  Callers
+    // keep no capacities of their own: what a buffer can hold is `bytes`.
     int reserve(size_t n)
     {
         if (n <= bytes) return RT_OK;
-        if (p && !borrowed) (void)hipFree(p);
-        p = nullptr; bytes = 0; borrowed = false;
-        hipError_t e = hipMalloc(&p, n ? n : 16);
+        const size_t want = n ? n : 16;
+        void *q = nullptr;
+        hipError_t e = want > rt_alloc_limit() ? hipErrorOutOfMemory : hipMalloc(&q, want);
+        if (e == hipErrorOutOfMemory && p && !borrowed && want <= rt_alloc_limit()) {
+            (void)hipGetLastError();
+            (void)hipFree(p);
+            p = nullptr; bytes = 0;
+            q = nullptr;
+            e = hipMalloc(&q, want);
+        }
         if (e != hipSuccess) {
+            (void)hipGetLastError();
             rt_set_error("hipMalloc(%zu): %s", n, hipGetErrorString(e));
-            p = nullptr;
             return e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP;
         }
-        bytes = n ? n : 16;
+        if (p && !borrowed) (void)hipFree(p);
+        p = q; bytes = want; borrowed = false;
         return RT_OK;
     }
     void release()
@@ -169,6 +186,7 @@ struct rt_context {
                                  //   (measured, profiles/r03/wide8_experiment.md: no faster on either layout)
     float sah_node = 1.0f, sah_prim = 0.5f;     // cost of one wide-node step / one triangle test (RT_SAH_NODE, RT_SAH_PRIM)
     uint32_t cu_count = 256;     // compute units of the device
+    size_t device_mem_total = 0; // bytes of device memory (asked once, when a pipeline first sizes its queues)
     uint32_t blocks_per_cu_override = 0;    // RT_PERSISTENT_BLOCKS_PER_CU: 0 = ask the occupancy API per kernel
     bool lds_top = true;                    // RT_LDS_TOP=0: every node comes from global memory
     uint32_t lds_stack_rows = 0;            // RT_LDS_STACK_ROWS=6: the small-stack instantiation (tests of the deep-stack path)
@@ -181,6 +199,8 @@ struct rt_context {
     DevBuf build_arena;          // temporaries of the acceleration-structure builds: one allocation, sliced (hipMalloc
                                  // and hipFree synchronise the device and cost more than the kernels of a small build)
     DevBuf scratch[8];           // staging for host-pointer batch calls
+    std::vector<struct rt_pipeline *> deferred;      // pipelines holding frames that render() has accepted and not rendered yet
+                                 //   (rt_pipeline_set_deferred): whatever changes what those frames would see flushes them first
 };
 
 struct BvhDev {
@@ -320,6 +340,9 @@ static inline uint32_t rt_lds_stack_rows(const rt_context *ctx)
 
 // rt_bvh_ploc.hip
 size_t rt_ploc_temp_bytes(uint32_t n);
+
+// rt_pipeline.hip: renders the frames every deferred pipeline of the context still holds (rt_pipeline_set_deferred)
+int rt_context_flush_deferred(rt_context *ctx);
 
 // rt_api.hip
 void rt_context_retain(rt_context *ctx);

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(CBLOCK) k_compact_level(PipeDev pd, int L)
     const uint32_t first = blockIdx.x * (uint32_t)(CTILES * CBLOCK);
     if (first >= total_items) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    auto slot_of = [&](uint32_t idx) -> size_t { return L == 1 ? (size_t)(idx / n) * pd.cap + idx % n : (size_t)idx; };
+    auto slot_of = [&](uint32_t idx) -> size_t { return L == 1 ? (size_t)(idx / n) * pd.lv[1].rstride + idx % n : (size_t)idx; };
     uint32_t flags = 0, mine = 0;
 #pragma unroll 4
     for (int t = 0; t < CTILES; t++) {
@@ -187,7 +187,7 @@ RT_DEV void shade_emit_body(const PipeDev &pd_arg, int level, uint32_t shadow_sl
     if (emit_next) {
         if (L == 0) {
             for (uint32_t w = 0; w < 2; w++)
-                if (!(io.sec_mask & (1u << w))) store_invalid(pd.lv[1].O, pd.lv[1].D, (size_t)w * pd.cap + idx);
+                if (!(io.sec_mask & (1u << w))) store_invalid(pd.lv[1].O, pd.lv[1].D, (size_t)w * pd.lv[1].rstride + idx);
         } else if (L < MAXD && !io.sec_mask) store_invalid(pd.lv[L < MAXD ? L + 1 : MAXD].O, pd.lv[L < MAXD ? L + 1 : MAXD].D, idx);
     }
 }
@@ -777,34 +777,95 @@ int prepare_shadow_cache(rt_pipeline *p, const rt_per_frame_constants &pfc, cons
     return RT_OK;
 }
 
-int ensure_queues(rt_pipeline *p, uint32_t cap, uint32_t sh0_batches, uint32_t levels)
+// ---- queue memory ------------------------------------------------------------------------------------------------------
+// Level l keeps, per RAY slot (l = 0: per pixel slot; no ray is stored there), the ray (32 B + 4 B pixel slot), its hit record
+// (16 + 4 B) and the two compaction maps (4 + 4 B); per HIT of the level its shadow rays -- compact form: ONE float4 per hit +
+// 4 B of visibility per shadow ray; explicit form (the ambient-occlusion view): 32 B per shadow ray -- and, for paths of more
+// than one bounce, 16 B of colour per ray slot.  How many slots a level needs is only known once the level before has been
+// compacted: the worst case is 2 rays per pixel at level 1 and as many rays as slots at every deeper level, 228 B per pixel and
+// frame for the reference's depth limits and 884 B with four bounces -- times up to 32 frames per set of launches.  So:
+//   * when the worst case of the whole set fits the budget (a quarter of the device's memory by default) everything is
+//     reserved up front and a set is enqueued without the host ever looking at the device (single frames always go this way);
+//   * above it the levels are sized BY COUNT: after the compaction of level l the host reads that one counter (a stream
+//     synchronisation: ~20 us against the tens of milliseconds of a set) and sizes the shadow queue of level l and the ray
+//     queue of level l + 1 for what is really there.  A 4K four-bounce frame of the 10 M-triangle scene needs 2.7 instead of
+//     7.3 GB that way, and sets of 32 fit.
+// Buffers only grow (with an eighth to spare, so that the next set's slightly different counts do not reallocate).
+inline size_t round64(size_t n) { return (n + 63u) & ~(size_t)63u; }
+int grow(DevBuf &b, size_t bytes)
 {
-    if (cap <= p->cap && sh0_batches <= p->sh0_batches && levels <= p->levels) return RT_OK;
-    const size_t c = cap > p->cap ? cap : p->cap;
-    const size_t sb = sh0_batches > p->sh0_batches ? sh0_batches : p->sh0_batches;
-    const uint32_t nl = levels > p->levels ? levels : p->levels;
-    RT_TRY(p->counters.reserve(POOL_OFFSET_WORDS * 4 + POOL_BYTES));
-    for (uint32_t l = 0; l <= nl; l++) {
-        rt_pipeline::LevelBuf &b = p->lv[l];
-        const size_t slots = l == 0 ? c : 2 * c, shadow = l == 0 ? sb * c : 4 * c;
-        if (l > 0) { RT_TRY(b.O.reserve(slots * 16)); RT_TRY(b.D.reserve(slots * 16)); RT_TRY(b.pix.reserve(slots * 4)); }
-        RT_TRY(b.hit.reserve(slots * 16)); RT_TRY(b.inst.reserve(slots * 4));
-        RT_TRY(b.slot_j.reserve(slots * 4)); RT_TRY(b.jlist.reserve(slots * 4));
-        RT_TRY(b.shO.reserve(shadow * 16)); RT_TRY(b.shD.reserve(shadow * 16)); RT_TRY(b.vis.reserve(shadow * 4));
-        if (l > 0 && nl > 1) RT_TRY(b.color.reserve(slots * 16));          // deep paths only (k_shade_level)
-    }
-    p->cap = (uint32_t)c;
-    p->sh0_batches = (uint32_t)sb;
-    p->levels = nl;
+    if (bytes <= b.bytes) return RT_OK;
+    return b.reserve(bytes + bytes / 8);
+}
+// ray queue + hit records of level l for `slots` ray slots (level 0: pixel slots)
+int reserve_level_rays(rt_pipeline *p, uint32_t l, size_t slots, bool deep)
+{
+    rt_pipeline::LevelBuf &b = p->lv[l];
+    if (l > 0) { RT_TRY(grow(b.O, slots * 16)); RT_TRY(grow(b.D, slots * 16)); RT_TRY(grow(b.pix, slots * 4)); }
+    RT_TRY(grow(b.hit, slots * 16)); RT_TRY(grow(b.inst, slots * 4));
+    RT_TRY(grow(b.slot_j, slots * 4)); RT_TRY(grow(b.jlist, slots * 4));
+    if (l > 0 && deep) RT_TRY(grow(b.color, slots * 16));          // deep paths only (k_shade_level)
     return RT_OK;
+}
+// shadow queue of level l for `hits` hits with `shadow_slots` rays each
+int reserve_level_shadows(rt_pipeline *p, uint32_t l, size_t hits, uint32_t shadow_slots, bool compact)
+{
+    rt_pipeline::LevelBuf &b = p->lv[l];
+    if (compact) RT_TRY(grow(b.shO, hits * 16));
+    else { RT_TRY(grow(b.shO, hits * shadow_slots * 16)); RT_TRY(grow(b.shD, hits * shadow_slots * 16)); }
+    return grow(b.vis, hits * shadow_slots * 4);
+}
+inline size_t level_ray_bytes(uint32_t l, bool deep) { return (l > 0 ? 36u : 0u) + 28u + (l > 0 && deep ? 16u : 0u); }
+inline size_t level_shadow_bytes(uint32_t shadow_slots, bool compact) { return compact ? 16u + 4u * shadow_slots : 36u * shadow_slots; }
+size_t worst_case_queue_bytes(size_t cap, uint32_t levels, uint32_t max_shadow, uint32_t shadow_slots0, bool compact)
+{
+    const bool deep = levels > 1;
+    size_t total = cap * (level_ray_bytes(0, deep) + level_shadow_bytes(shadow_slots0, compact));
+    for (uint32_t l = 1; l <= levels; l++)
+        total += 2 * cap * (level_ray_bytes(l, deep) + (l < max_shadow ? level_shadow_bytes(2, compact) : 0));
+    return total;
+}
+size_t queue_budget(rt_pipeline *p)
+{
+    if (p->queue_budget) return p->queue_budget;
+    static const char *const env = getenv("RT_QUEUE_BUDGET_MB");
+    if (env) { const long long mb = atoll(env); if (mb > 0) return (size_t)mb << 20; }
+    if (p->ctx->device_mem_total == 0) {         // asked once per context: hipMemGetInfo is a driver round trip, this runs per frame
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) { (void)hipGetLastError(); total_b = (size_t)64 << 30; }
+        p->ctx->device_mem_total = total_b;
+    }
+    return p->ctx->device_mem_total / 4;
+}
+// everything a set of `cap` pixel slots can need at most, reserved now; the strides that go with it
+int reserve_worst_case(rt_pipeline *p, size_t cap, uint32_t levels, uint32_t max_shadow, uint32_t shadow_slots0, bool compact)
+{
+    const bool deep = levels > 1;
+    RT_TRY(reserve_level_rays(p, 0, cap, deep));
+    RT_TRY(reserve_level_shadows(p, 0, cap, shadow_slots0, compact));
+    for (uint32_t l = 1; l <= levels; l++) {
+        RT_TRY(reserve_level_rays(p, l, 2 * cap, deep));
+        if (l < max_shadow) RT_TRY(reserve_level_shadows(p, l, 2 * cap, 2, compact));
+    }
+    return RT_OK;
+}
+void bind_level(const rt_pipeline *p, PipeDev &pd, int l)
+{
+    const rt_pipeline::LevelBuf &b = p->lv[l];
+    LevelDev &d = pd.lv[l];
+    d.O = b.O.as<float4>(); d.D = b.D.as<float4>(); d.hit = b.hit.as<float4>(); d.inst = b.inst.as<uint32_t>();
+    d.slot_j = b.slot_j.as<uint32_t>(); d.jlist = b.jlist.as<uint32_t>(); d.pix = b.pix.as<uint32_t>();
+    d.shO = b.shO.as<float4>(); d.shD = b.shD.as<float4>(); d.vis = b.vis.as<uint32_t>(); d.color = b.color.as<float4>();
 }
 
 // radiance levels a frame traces: level l exists when hits of depth l-1 may spawn rays
 inline uint32_t frame_levels(const rt_pipeline *p) { return p->max_rad < (uint32_t)MAXD ? p->max_rad : (uint32_t)MAXD; }
 
-// returns the first error of an event record (kernel launch errors surface in hipGetLastError at the call site)
+// The launches of one frame, or of one set of frames.  `counted`: the levels beyond the pixel slots are sized by what the
+// compaction before them has counted (see "queue memory" above); otherwise the caller has reserved the worst case and set the
+// strides.  pd is updated as the levels are bound and is what the counting re-walks replay (rt_pipeline::last_pd).
 template <int STACK, bool TWO_LEVEL>
-hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
+int launch_frame(rt_pipeline *p, PipeDev &pd, uint32_t shadow_slots, bool counted)
 {
     hipError_t first_error = hipSuccess;
     auto record = [&](hipEvent_t e, hipStream_t s) { const hipError_t rc = hipEventRecord(e, s); if (first_error == hipSuccess) first_error = rc; };
@@ -813,18 +874,42 @@ hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots
     const size_t ring_slot = T ? (size_t)(p->ring_pos % (uint64_t)p->ring_frames) : 0;
     hipEvent_t *ev = T ? &p->ring[ring_slot * EV_COUNT] : nullptr;
     const uint32_t cap = pd.cap;
-    const rt_context *ctx = p->ctx;
+    rt_context *ctx = p->ctx;
     const uint32_t levels = frame_levels(p);
+    const bool deep = levels > 1, compact = pd.shadow_compact != 0;
     const uint32_t any = RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH | RT_RAY_FLAG_SKIP_CLOSEST_HIT_SHADER;
+    // counted queues: the hits the compaction of level l has just produced -> the shadow queue of level l and the ray queue of
+    // level l + 1 get their sizes; `slots` = ray slots of the level whose launches come next (level 1: two batches)
+    size_t hits_l = cap, slots = cap;
+    auto size_next = [&](uint32_t l, bool casts_shadows, bool spawns) -> int {
+        if (counted) {
+            HIP_TRY(hipMemcpyAsync(ctx->pinned, &pd.counters[C_NHIT + l], 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            hits_l = round64((size_t)ctx->pinned[0]);
+            if (hits_l == 0) hits_l = 64;
+        } else hits_l = l == 0 ? (size_t)cap : 2 * (size_t)cap;
+        if (hits_l > 0xffffffc0ull / 2) { rt_set_error("render: more than 2^31 hits at radiance level %u", l); return RT_ERR_UNSUPPORTED; }
+        pd.lv[l].hstride = (uint32_t)hits_l;
+        if (counted && casts_shadows) RT_TRY(reserve_level_shadows(p, l, hits_l, l == 0 ? shadow_slots : 2u, compact));
+        bind_level(p, pd, (int)l);
+        if (spawns) {
+            slots = (l == 0 ? 2 : 1) * hits_l;
+            if (l == 0) pd.lv[1].rstride = (uint32_t)hits_l;
+            if (counted) RT_TRY(reserve_level_rays(p, l + 1, slots, deep));
+            bind_level(p, pd, (int)l + 1);
+        }
+        return RT_OK;
+    };
     if (T) record(ev[0], st);
     // primary rays are coherent: one 8x8 tile per wave, scheduled by the hardware dispatcher
     if (pd.n_frames > 1u) k_primary<STACK, TWO_LEVEL, true><<<blocks(cap), PBLOCK, 0, st>>>(pd);
     else k_primary<STACK, TWO_LEVEL, false><<<blocks(cap), PBLOCK, 0, st>>>(pd);
     k_compact_level<<<(cap + CTILES * CBLOCK - 1) / (CTILES * CBLOCK), CBLOCK, 0, st>>>(pd, 0);
     if (T) record(ev[1], st);
+    RT_TRY(size_next(0, true, levels >= 1));
     const bool B = pd.n_frames > 1u;            // a batch of frames: the shading kernels pick the constants of every hit's frame
-    if (B) k_shade_emit<true, true><<<blocks(cap), PBLOCK, 0, st>>>(pd, 0, shadow_slots, levels >= 1 ? 1u : 0u);
-    else k_shade_emit<true, false><<<blocks(cap), PBLOCK, 0, st>>>(pd, 0, shadow_slots, levels >= 1 ? 1u : 0u);
+    if (B) k_shade_emit<true, true><<<blocks(hits_l), PBLOCK, 0, st>>>(pd, 0, shadow_slots, levels >= 1 ? 1u : 0u);
+    else k_shade_emit<true, false><<<blocks(hits_l), PBLOCK, 0, st>>>(pd, 0, shadow_slots, levels >= 1 ? 1u : 0u);
     if (T) record(ev[2], st);
     ShadowQueues shadows;
     memset(&shadows, 0, sizeof shadows);
@@ -833,22 +918,19 @@ hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots
     shadows.frame_lights = fl;
     shadows.cache = p->shadow_cache_dev;
     shadows.lights = lr;
-    shadows.q[0] = RayQueue{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, shadow_slots, any};     // RaytracingCommon.hlsli:94
+    shadows.q[0] = RayQueue{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], pd.lv[0].hstride, shadow_slots, any};     // RaytracingCommon.hlsli:94
     shadows.vis[0] = pd.lv[0].vis;
     shadows.nq = 1;
-    size_t shadow_max = (size_t)cap * shadow_slots;
+    size_t shadow_max = hits_l * shadow_slots;
     auto trace_shadows = [&](const ShadowQueues &sq, size_t rays_max, uint32_t *pool, hipStream_t s) {
         if (B) k_trace_shadow<STACK, TWO_LEVEL, true><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL, true>, PBLOCK, rays_max), PBLOCK, 0, s>>>(
             pd.sc, sq, pool, &pd.counters[C_SHADOW]);
         else k_trace_shadow<STACK, TWO_LEVEL, false><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL, false>, PBLOCK, rays_max), PBLOCK, 0, s>>>(
             pd.sc, sq, pool, &pd.counters[C_SHADOW]);
     };
-    // The shadow rays of the primary hits depend on nothing the secondary rays produce: their launch goes to a second
-    // stream and runs BESIDE the secondary launch -- both are persistent launches sized to fill the chip, so the workgroups
-    // of the one that comes second start as those of the first run out of rays, and the machine stays full through what
-    // would be the first one's drain (a third of a stage at 1080p, profiles/r03/drain_vs_occupancy.txt).  The shadow rays of
-    // the deeper hits follow in a launch of their own at the end, as before.
-    const bool early = p->overlap_shadow0 > 0 && levels >= 1 && p->side != nullptr;
+    // (RT_OVERLAP_SHADOW0=1, off by default and measured no faster: the shadow rays of the primary hits on a second stream beside
+    // the secondary launch)
+    const bool early = p->overlap_shadow0 > 0 && levels >= 1 && p->side != nullptr && !counted;
     if (early) {
         record(p->ev_fork, st);
         if (hipStreamWaitEvent(p->side, p->ev_fork, 0) != hipSuccess && first_error == hipSuccess) first_error = hipErrorUnknown;
@@ -859,22 +941,23 @@ hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots
     }
     for (uint32_t l = 1; l <= levels; l++) {
         // level 1: the diffuse and the specular batch of the primary hits; deeper: one ray per hit of level l-1
-        const QueueSrc rays = {{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE}, none};   // ProgressiveRaytracing.hlsl:53
-        k_trace_secondary<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_secondary<STACK, TWO_LEVEL>, PBLOCK, (size_t)cap * 2), PBLOCK, 0, st>>>(
+        const QueueSrc rays = {{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], pd.lv[1].rstride, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE}, none};   // ProgressiveRaytracing.hlsl:53
+        k_trace_secondary<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_secondary<STACK, TWO_LEVEL>, PBLOCK, slots), PBLOCK, 0, st>>>(
             pd.sc, rays, pd.lv[l].hit, pd.lv[l].inst, pd.pools + (size_t)l * RT_POOL_GROUPS * RT_POOL_STRIDE, &pd.counters[C_SECONDARY]);
-        k_compact_level<<<(2 * cap + CTILES * CBLOCK - 1) / (CTILES * CBLOCK), CBLOCK, 0, st>>>(pd, (int)l);
+        k_compact_level<<<(unsigned)((slots + CTILES * CBLOCK - 1) / (CTILES * CBLOCK)), CBLOCK, 0, st>>>(pd, (int)l);
         if (T) record(ev[3 + 2 * (l - 1)], st);
         const bool casts_shadows = l < pd.max_shadow, spawns = l < levels;
+        RT_TRY(size_next(l, casts_shadows, spawns));
         if (casts_shadows || spawns) {
-            if (B) k_shade_emit<false, true><<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd, (int)l, 2u, spawns ? 1u : 0u);
-            else k_shade_emit<false, false><<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd, (int)l, 2u, spawns ? 1u : 0u);
+            if (B) k_shade_emit<false, true><<<blocks(hits_l), PBLOCK, 0, st>>>(pd, (int)l, 2u, spawns ? 1u : 0u);
+            else k_shade_emit<false, false><<<blocks(hits_l), PBLOCK, 0, st>>>(pd, (int)l, 2u, spawns ? 1u : 0u);
         }
         if (T) record(ev[4 + 2 * (l - 1)], st);
         if (casts_shadows) {
-            shadows.q[shadows.nq] = RayQueue{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any};
+            shadows.q[shadows.nq] = RayQueue{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], pd.lv[l].hstride, 2u, any};
             shadows.vis[shadows.nq] = pd.lv[l].vis;
             shadows.nq++;
-            shadow_max += (size_t)cap * 4;
+            shadow_max += hits_l * 2;
         }
     }
     if (shadows.nq > 0) trace_shadows(shadows, shadow_max, pd.pools, st);
@@ -886,20 +969,22 @@ hipError_t launch_frame(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots
         else k_resolve<false, false><<<blocks(pd.fcap), PBLOCK, 0, st>>>(pd);
     } else {
         for (uint32_t l = levels; l >= 1; l--) {
-            if (B) k_shade_level<true><<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd, (int)l);
-            else k_shade_level<false><<<blocks((size_t)cap * 2), PBLOCK, 0, st>>>(pd, (int)l);
+            const size_t n_l = pd.lv[l].hstride;       // (one thread per hit of the level)
+            if (B) k_shade_level<true><<<blocks(n_l), PBLOCK, 0, st>>>(pd, (int)l);
+            else k_shade_level<false><<<blocks(n_l), PBLOCK, 0, st>>>(pd, (int)l);
         }
         if (B) k_resolve<true, true><<<blocks(pd.fcap), PBLOCK, 0, st>>>(pd);
         else k_resolve<true, false><<<blocks(pd.fcap), PBLOCK, 0, st>>>(pd);
     }
     if (T) { record(ev[EV_RESOLVE], st); p->ring_levels[ring_slot] = (uint8_t)levels; p->ring_nframes[ring_slot] = (uint8_t)pd.n_frames; p->ring_pos++; }
-    return first_error;
+    HIP_TRY(first_error);
+    return RT_OK;
 }
 
 template <int STACK>
-hipError_t launch_frame_any(rt_pipeline *p, const PipeDev &pd, uint32_t shadow_slots)
+int launch_frame_any(rt_pipeline *p, PipeDev &pd, uint32_t shadow_slots, bool counted)
 {
-    return p->scene->two_level ? launch_frame<STACK, true>(p, pd, shadow_slots) : launch_frame<STACK, false>(p, pd, shadow_slots);
+    return p->scene->two_level ? launch_frame<STACK, true>(p, pd, shadow_slots, counted) : launch_frame<STACK, false>(p, pd, shadow_slots, counted);
 }
 
 template <bool TWO_LEVEL>
@@ -915,13 +1000,13 @@ static int count_walk_launch(rt_pipeline *p, unsigned long long *w)
     const unsigned gs = rt_persistent_grid(ctx, k_walk_shadow<TWO_LEVEL>, PBLOCK, (size_t)cap * 2);
     const LightRays lr = light_rays(pd), none = no_light_rays();
     const LightRays *fl = pd.n_frames > 1u ? pd.frame_lights : nullptr;
-    k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any}, lr}, fl}, w + RT_WALK_WORDS * RT_STAGE_SHADOW0);
+    k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], pd.lv[0].hstride, ss, any}, lr}, fl}, w + RT_WALK_WORDS * RT_STAGE_SHADOW0);
     const uint32_t levels = pd.max_rad < (uint32_t)MAXD ? pd.max_rad : (uint32_t)MAXD;
     for (uint32_t l = 1; l <= levels; l++) {
-        k_walk_queue<TWO_LEVEL><<<gq, PBLOCK, 0, st>>>(pd.sc, QueueSrc{{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE}, none},
+        k_walk_queue<TWO_LEVEL><<<gq, PBLOCK, 0, st>>>(pd.sc, QueueSrc{{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], pd.lv[1].rstride, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE}, none},
                                                        w + RT_WALK_WORDS * RT_STAGE_SECONDARY);
         if (l < pd.max_shadow)
-            k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2u * cap, 2u, any}, lr}, fl}, w + RT_WALK_WORDS * RT_STAGE_SHADOW1);
+            k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], pd.lv[l].hstride, 2u, any}, lr}, fl}, w + RT_WALK_WORDS * RT_STAGE_SHADOW1);
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -968,7 +1053,13 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     const uint32_t cap = fcap * n_frames;
     const bool ao_view = p->kind == RT_PIPELINE_PROGRESSIVE && frames[0].options.showAmbientOcclusionOnly;
     const uint32_t shadow_slots = ao_view ? 4u : 2u;
-    RT_TRY(ensure_queues(p, cap, shadow_slots, frame_levels(p)));
+    // queue memory: the worst case up front when it fits the budget, else level by level as the counts come in (launch_frame)
+    const uint32_t levels_now = frame_levels(p);
+    const bool counted = worst_case_queue_bytes(cap, levels_now, p->max_shadow, shadow_slots, !ao_view) > queue_budget(p);
+    RT_TRY(p->counters.reserve(POOL_OFFSET_WORDS * 4 + POOL_BYTES));
+    if (counted) RT_TRY(reserve_level_rays(p, 0, cap, levels_now > 1));
+    else RT_TRY(reserve_worst_case(p, cap, levels_now, p->max_shadow, shadow_slots, !ao_view));
+    p->counted_queues = counted;
     if (!p->totals.p) {
         RT_TRY(p->totals.reserve(8 * sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(p->totals.p, 0, 8 * sizeof(unsigned long long), st));
@@ -1029,12 +1120,10 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     pd.aov_direct = p->accum;                       // realtime: output 0 = direct lighting, output 1 = indirect specular
     pd.aov_indirect = p->aov_own.as<float4>();
     pd.counters = p->counters.as<uint32_t>();
-    for (int l = 0; l <= MAXD; l++) {
-        rt_pipeline::LevelBuf &b = p->lv[l];
-        LevelDev &d = pd.lv[l];
-        d.O = b.O.as<float4>(); d.D = b.D.as<float4>(); d.hit = b.hit.as<float4>(); d.inst = b.inst.as<uint32_t>();
-        d.slot_j = b.slot_j.as<uint32_t>(); d.jlist = b.jlist.as<uint32_t>(); d.pix = b.pix.as<uint32_t>();
-        d.shO = b.shO.as<float4>(); d.shD = b.shD.as<float4>(); d.vis = b.vis.as<uint32_t>(); d.color = b.color.as<float4>();
+    for (int l = 0; l <= MAXD; l++) {          // (counted queues: launch_frame binds a level again once it has sized it)
+        bind_level(p, pd, l);
+        pd.lv[l].rstride = cap;
+        pd.lv[l].hstride = l == 0 ? cap : 2u * cap;
     }
     static_assert(C_COUNT <= POOL_OFFSET_WORDS, "scalar counters overlap the chunk pools");
     pd.pools = pd.counters + POOL_OFFSET_WORDS;
@@ -1050,11 +1139,11 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     }
     // 18 LDS stack rows + the 8-row top table = 26 KiB per 256-thread block = 6 resident blocks per CU, whatever
     // the depth of the tree; the rare deeper walk continues in global rows (rt_trace_wave.h)
-    hipError_t launched;
-    if (ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST) launched = launch_frame_any<RT_LDS_STACK_ROWS_TEST>(p, pd, shadow_slots);
-    else if (set_rows) launched = launch_frame<RT_LDS_STACK_ROWS_SETS, false>(p, pd, shadow_slots);
-    else launched = launch_frame_any<RT_LDS_STACK_ROWS>(p, pd, shadow_slots);
-    HIP_TRY(launched);
+    int launched;
+    if (ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST) launched = launch_frame_any<RT_LDS_STACK_ROWS_TEST>(p, pd, shadow_slots, counted);
+    else if (set_rows) launched = launch_frame<RT_LDS_STACK_ROWS_SETS, false>(p, pd, shadow_slots, counted);
+    else launched = launch_frame_any<RT_LDS_STACK_ROWS>(p, pd, shadow_slots, counted);
+    RT_TRY(launched);
     HIP_TRY(hipGetLastError());
     p->last_pd = pd;
     p->last_shadow_slots = shadow_slots;
@@ -1065,30 +1154,15 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     return RT_OK;
 }
 
-int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
+// n frames through shared sets of launches; band_rows != 0: only the rank's interleaved bands of every frame
+static int render_frames(rt_pipeline *p, uint32_t width, uint32_t height, const rt_per_frame_constants *constants, uint32_t n,
+                         uint32_t band_rows, uint32_t band_rank, uint32_t band_world)
 {
-    return render_region(p, width, height, x0, y0, x1, y1, 0, 0, 1);
-}
-
-int rt_pipeline_render_bands(rt_pipeline *p, uint32_t width, uint32_t height, uint32_t band_rows, uint32_t rank, uint32_t world)
-{
-    RT_REQUIRE(world > 0 && rank < world, "rank outside [0, world)");
-    RT_REQUIRE(band_rows > 0 && band_rows % 8 == 0, "band_rows must be a positive multiple of 8 (pixel slots are 8x8 tiles)");
-    uint32_t n = 0;
-    RT_TRY(rt_tile_bands(height, band_rows, rank, world, nullptr, nullptr, 0, &n));
-    if (n == 0) return RT_OK;                   // more ranks than bands: nothing to render here
-    return render_region(p, width, height, 0, 0, width, n * band_rows, band_rows, rank, world);
-}
-
-int rt_pipeline_render(rt_pipeline *p, uint32_t width, uint32_t height)
-{
-    return rt_pipeline_render_tile(p, width, height, 0, 0, width, height);
-}
-
-int rt_pipeline_render_batch(rt_pipeline *p, uint32_t width, uint32_t height, const rt_per_frame_constants *constants, uint32_t n)
-{
-    RT_REQUIRE(p && (constants || n == 0), "null argument");
-    RT_REQUIRE(p->kind == RT_PIPELINE_PROGRESSIVE, "render_batch: only the progressive pipeline accumulates frames");
+    uint32_t band_count = 0;
+    if (band_rows) {
+        RT_TRY(rt_tile_bands(height, band_rows, band_rank, band_world, nullptr, nullptr, 0, &band_count));
+        if (band_count == 0) n = 0;             // more ranks than bands: nothing to render here (the constants still become current)
+    }
     uint32_t batch_max = RT_MAX_BATCH;
     if (const char *e = getenv("RT_BATCH_MAX")) { const int v = atoi(e); if (v >= 1 && v <= (int)RT_MAX_BATCH) batch_max = (uint32_t)v; }
     // frames RayGen would leave at once (accumCount >= maxIterations, ProgressiveRaytracing.hlsl:14-16) are dropped here;
@@ -1098,7 +1172,8 @@ int rt_pipeline_render_batch(rt_pipeline *p, uint32_t width, uint32_t height, co
         // the queues grow with the batch: when the device cannot hold them, the same frames go through in smaller sets
         for (size_t at = 0; at < run.size();) {
             const size_t n_now = run.size() - at < batch_max ? run.size() - at : batch_max;
-            const int rc = render_region(p, width, height, 0, 0, width, height, 0, 0, 1, run.data() + at, (uint32_t)n_now);
+            const int rc = band_rows ? render_region(p, width, height, 0, 0, width, band_count * band_rows, band_rows, band_rank, band_world, run.data() + at, (uint32_t)n_now)
+                                     : render_region(p, width, height, 0, 0, width, height, 0, 0, 1, run.data() + at, (uint32_t)n_now);
             if (rc == RT_ERR_OOM && n_now > 1) { batch_max = (uint32_t)(n_now / 2); continue; }
             if (rc != RT_OK) { run.clear(); return rc; }
             at += n_now;
@@ -1112,8 +1187,133 @@ int rt_pipeline_render_batch(rt_pipeline *p, uint32_t width, uint32_t height, co
         if (!run.empty() && (run.size() >= batch_max || (run[0].options.showAmbientOcclusionOnly != 0) != (c.options.showAmbientOcclusionOnly != 0))) RT_TRY(flush());
         run.push_back(c);
     }
-    RT_TRY(flush());
+    return flush();
+}
+
+}  // extern "C"
+
+int rt_pipeline_flush_pending(rt_pipeline *p)
+{
+    if (!p || p->pending.empty()) return RT_OK;
+    std::vector<rt_per_frame_constants> frames;
+    frames.swap(p->pending);                    // (whatever happens, the frames are not rendered twice)
+    std::vector<rt_pipeline *> &reg = p->ctx->deferred;
+    for (size_t k = 0; k < reg.size(); k++) if (reg[k] == p) { reg.erase(reg.begin() + (long)k); break; }
+    const rt_per_frame_constants keep = p->pfc;              // the constants of the last update(): a frame may have been updated and not rendered yet
+    const int rc = render_frames(p, p->width, p->height, frames.data(), (uint32_t)frames.size(), 0, 0, 1);
+    p->pfc = keep;
+    return rc;
+}
+
+int rt_context_flush_deferred(rt_context *ctx)
+{
+    if (!ctx) return RT_OK;
+    while (!ctx->deferred.empty()) RT_TRY(rt_pipeline_flush_pending(ctx->deferred.back()));      // (a flush takes the pipeline off the list)
+    return RT_OK;
+}
+
+extern "C" {
+
+int rt_pipeline_flush(rt_pipeline *p)
+{
+    RT_REQUIRE(p, "null pipeline");
+    return rt_pipeline_flush_pending(p);
+}
+
+int rt_pipeline_set_deferred(rt_pipeline *p, uint32_t max_frames)
+{
+    RT_REQUIRE(p, "null pipeline");
+    RT_REQUIRE(max_frames <= RT_MAX_BATCH, "set_deferred: at most 32 frames share a set of launches");
+    RT_REQUIRE(p->kind == RT_PIPELINE_PROGRESSIVE || max_frames <= 1, "set_deferred: only the progressive pipeline accumulates frames");
+    RT_TRY(rt_pipeline_flush_pending(p));
+    p->deferred_max = max_frames;
+    return RT_OK;
+}
+
+int rt_pipeline_get_deferred(const rt_pipeline *p, uint32_t *max_frames, uint32_t *pending)
+{
+    RT_REQUIRE(p, "null pipeline");
+    if (max_frames) *max_frames = p->deferred_max;
+    if (pending) *pending = (uint32_t)p->pending.size();
+    return RT_OK;
+}
+
+int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
+{
+    RT_TRY(rt_pipeline_flush_pending(p));
+    return render_region(p, width, height, x0, y0, x1, y1, 0, 0, 1);
+}
+
+int rt_pipeline_render_bands(rt_pipeline *p, uint32_t width, uint32_t height, uint32_t band_rows, uint32_t rank, uint32_t world)
+{
+    RT_REQUIRE(world > 0 && rank < world, "rank outside [0, world)");
+    RT_REQUIRE(band_rows > 0 && band_rows % 8 == 0, "band_rows must be a positive multiple of 8 (pixel slots are 8x8 tiles)");
+    RT_TRY(rt_pipeline_flush_pending(p));
+    uint32_t n = 0;
+    RT_TRY(rt_tile_bands(height, band_rows, rank, world, nullptr, nullptr, 0, &n));
+    if (n == 0) return RT_OK;                   // more ranks than bands: nothing to render here
+    return render_region(p, width, height, 0, 0, width, n * band_rows, band_rows, rank, world);
+}
+
+int rt_pipeline_render(rt_pipeline *p, uint32_t width, uint32_t height)
+{
+    RT_REQUIRE(p, "null pipeline");
+    if (p->deferred_max > 1 && p->kind == RT_PIPELINE_PROGRESSIVE) {
+        // the checks render_region would make now, so that a bad call fails where it is made and not at some later flush
+        if (!p->scene || !p->scene->built) { rt_set_error("render: acceleration structures not built"); return RT_ERR_STATE; }
+        if (!p->accum) { rt_set_error("render: no output resource"); return RT_ERR_STATE; }
+        if (!p->have_pfc) { rt_set_error("render: update() has not been called"); return RT_ERR_STATE; }
+        if (p->mats.empty()) { rt_set_error("render: no material"); return RT_ERR_STATE; }
+        RT_REQUIRE(width == p->width && height == p->height, "width/height differ from the output resource");
+        if (p->pending.empty()) p->ctx->deferred.push_back(p);
+        p->pending.push_back(p->pfc);
+        p->rendered = false;                    // (nothing of the LAST frame is on the device yet: count_work / stats flush first)
+        if (p->pending.size() >= p->deferred_max) return rt_pipeline_flush_pending(p);
+        return RT_OK;
+    }
+    return rt_pipeline_render_tile(p, width, height, 0, 0, width, height);
+}
+
+int rt_pipeline_render_batch(rt_pipeline *p, uint32_t width, uint32_t height, const rt_per_frame_constants *constants, uint32_t n)
+{
+    RT_REQUIRE(p && (constants || n == 0), "null argument");
+    RT_REQUIRE(p->kind == RT_PIPELINE_PROGRESSIVE, "render_batch: only the progressive pipeline accumulates frames");
+    RT_TRY(rt_pipeline_flush_pending(p));
+    RT_TRY(render_frames(p, width, height, constants, n, 0, 0, 1));
     if (n) { p->pfc = constants[n - 1]; p->have_pfc = true; }     // as after n x (update, render)
+    return RT_OK;
+}
+
+int rt_pipeline_render_bands_batch(rt_pipeline *p, uint32_t width, uint32_t height, uint32_t band_rows, uint32_t rank, uint32_t world,
+                                   const rt_per_frame_constants *constants, uint32_t n)
+{
+    RT_REQUIRE(p && (constants || n == 0), "null argument");
+    RT_REQUIRE(p->kind == RT_PIPELINE_PROGRESSIVE, "render_bands_batch: only the progressive pipeline accumulates frames");
+    RT_REQUIRE(world > 0 && rank < world, "rank outside [0, world)");
+    RT_REQUIRE(band_rows > 0 && band_rows % 8 == 0, "band_rows must be a positive multiple of 8 (pixel slots are 8x8 tiles)");
+    RT_TRY(rt_pipeline_flush_pending(p));
+    RT_TRY(render_frames(p, width, height, constants, n, band_rows, rank, world));
+    if (n) { p->pfc = constants[n - 1]; p->have_pfc = true; }
+    return RT_OK;
+}
+
+int rt_pipeline_set_queue_budget(rt_pipeline *p, size_t bytes)
+{
+    RT_REQUIRE(p, "null pipeline");
+    p->queue_budget = bytes;
+    return RT_OK;
+}
+
+int rt_pipeline_get_queue_memory(rt_pipeline *p, size_t *bytes_reserved, uint32_t *sized_by_count)
+{
+    RT_REQUIRE(p, "null pipeline");
+    size_t total = p->counters.bytes + p->batch_consts.bytes;
+    for (const rt_pipeline::LevelBuf &l : p->lv) {
+        const DevBuf *lb[] = {&l.O, &l.D, &l.hit, &l.inst, &l.slot_j, &l.jlist, &l.pix, &l.shO, &l.shD, &l.vis, &l.color};
+        for (const DevBuf *b : lb) total += b->bytes;
+    }
+    if (bytes_reserved) *bytes_reserved = total;
+    if (sized_by_count) *sized_by_count = p->counted_queues ? 1u : 0u;
     return RT_OK;
 }
 
@@ -1124,7 +1324,12 @@ int rt_pipeline_reserve_batch(rt_pipeline *p, uint32_t width, uint32_t height, u
     const uint32_t fcap = ((width + 7u) / 8u) * ((height + 7u) / 8u) * 64u;
     RT_REQUIRE((uint64_t)fcap * frames < 0x40000000ull, "batch: more than 2^30 pixel slots in one set of launches");
     const bool ao_view = p->have_pfc && p->pfc.options.showAmbientOcclusionOnly != 0;
-    RT_TRY(ensure_queues(p, fcap * frames, ao_view ? 4u : 2u, frame_levels(p)));
+    // (a set whose worst case is over the budget sizes its levels by count as it goes: only the pixel slots are known now)
+    const uint32_t levels_now = frame_levels(p);
+    const size_t cap = (size_t)fcap * frames;
+    RT_TRY(p->counters.reserve(POOL_OFFSET_WORDS * 4 + POOL_BYTES));
+    if (worst_case_queue_bytes(cap, levels_now, p->max_shadow, ao_view ? 4u : 2u, !ao_view) > queue_budget(p)) RT_TRY(reserve_level_rays(p, 0, cap, levels_now > 1));
+    else RT_TRY(reserve_worst_case(p, cap, levels_now, p->max_shadow, ao_view ? 4u : 2u, !ao_view));
     if (frames > 1) RT_TRY(p->batch_consts.reserve((sizeof(rt_per_frame_constants) + sizeof(LightRays)) * RT_MAX_BATCH));
     if (p->scene) {                                    // the shadow cache's table as well
         LightRays only_allocate = no_light_rays();
@@ -1151,6 +1356,7 @@ int rt_pipeline_get_free_sphere(rt_pipeline *p, float *radius)
 int rt_pipeline_count_work(rt_pipeline *p, rt_stage_work *out)
 {
     RT_REQUIRE(p && out, "null argument");
+    RT_TRY(rt_pipeline_flush_pending(p));
     if (!p->rendered || !p->scene->built || p->scene->generation != p->last_scene_gen) { rt_set_error("count_work: nothing rendered since the last change of scene, materials or output"); return RT_ERR_STATE; }
     HIP_TRY(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->stream;
@@ -1163,16 +1369,16 @@ int rt_pipeline_count_work(rt_pipeline *p, rt_stage_work *out)
     k_count_primary<<<blocks(cap), PBLOCK, 0, st>>>(pd, w + 3 * RT_STAGE_PRIMARY);
     const LightRays lr = light_rays(pd), none = no_light_rays();
     const LightRays *fl = pd.n_frames > 1u ? pd.frame_lights : nullptr;
-    k_count_queue<<<(blocks(cap) + 1) * ss, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], cap, ss, any}, lr}, fl},
+    k_count_queue<<<(blocks(cap) + 1) * ss, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], pd.lv[0].hstride, ss, any}, lr}, fl},
                                                              w + 3 * RT_STAGE_SHADOW0);
     const uint32_t levels = pd.max_rad < (uint32_t)MAXD ? pd.max_rad : (uint32_t)MAXD;
     for (uint32_t l = 1; l <= levels; l++) {        // every secondary level adds into the same two rows
         const uint32_t batches = l == 1 ? 2u : 1u;
         k_count_queue<<<(blocks((size_t)cap * 2) + 1) * batches, PBLOCK, 0, st>>>(
-            pd.sc, LitQueueSrc{QueueSrc{{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], cap, batches, RT_RAY_FLAG_NONE}, none}, nullptr}, w + 3 * RT_STAGE_SECONDARY);
+            pd.sc, LitQueueSrc{QueueSrc{{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], pd.lv[1].rstride, batches, RT_RAY_FLAG_NONE}, none}, nullptr}, w + 3 * RT_STAGE_SECONDARY);
         if (l < pd.max_shadow)
             k_count_queue<<<(blocks((size_t)cap * 2) + 1) * 2, PBLOCK, 0, st>>>(
-                pd.sc, LitQueueSrc{QueueSrc{{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], 2 * cap, 2, any}, lr}, fl}, w + 3 * RT_STAGE_SHADOW1);
+                pd.sc, LitQueueSrc{QueueSrc{{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], pd.lv[l].hstride, 2, any}, lr}, fl}, w + 3 * RT_STAGE_SHADOW1);
     }
     HIP_TRY(hipGetLastError());
     unsigned long long h[RT_STAGE_COUNT * 3];
@@ -1185,6 +1391,7 @@ int rt_pipeline_count_work(rt_pipeline *p, rt_stage_work *out)
 int rt_pipeline_count_walk(rt_pipeline *p, rt_stage_walk *out)
 {
     RT_REQUIRE(p && out, "null argument");
+    RT_TRY(rt_pipeline_flush_pending(p));
     if (!p->rendered || !p->scene->built || p->scene->generation != p->last_scene_gen) { rt_set_error("count_walk: nothing rendered since the last change of scene, materials or output"); return RT_ERR_STATE; }
     HIP_TRY(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->stream;
@@ -1203,7 +1410,7 @@ int rt_pipeline_count_walk(rt_pipeline *p, rt_stage_walk *out)
         out[k].tris = hk[3]; out[k].instance_entries = hk[4]; out[k].lines = hk[5];
         out[k].longest_walk = hk[6] >> 32;
         out[k].longest_walk_ray = (uint32_t)hk[6];
-        out[k].wave_node_steps = hk[7]; out[k].wave_leaf_phases = hk[8]; out[k].wave_tri_steps = hk[9];
+        out[k].wave_node_steps = hk[7]; out[k].wave_leaf_phases = hk[8]; out[k].wave_tri_steps = hk[9]; out[k].node_lines = hk[10];
     }
     return RT_OK;
 }
@@ -1212,13 +1419,14 @@ int rt_pipeline_count_walk(rt_pipeline *p, rt_stage_walk *out)
 int rt_debug_read_secondary_ray(rt_pipeline *p, uint32_t index, float origin_tmin[4], float dir_tmax[4])
 {
     RT_REQUIRE(p && origin_tmin && dir_tmax, "null argument");
+    RT_TRY(rt_pipeline_flush_pending(p));
     if (!p->rendered) { rt_set_error("nothing rendered yet"); return RT_ERR_STATE; }
     HIP_TRY(hipSetDevice(p->ctx->device));
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     uint32_t n = 0;
     HIP_TRY(hipMemcpy(&n, p->last_pd.counters + C_NHIT, 4, hipMemcpyDeviceToHost));
     RT_REQUIRE(n > 0 && index < 2 * n, "ray index out of range");
-    const size_t slot = (size_t)(index / n) * p->last_pd.cap + index % n;
+    const size_t slot = (size_t)(index / n) * p->last_pd.lv[1].rstride + index % n;
     HIP_TRY(hipMemcpy(origin_tmin, p->last_pd.lv[1].O + slot, 16, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(dir_tmax, p->last_pd.lv[1].D + slot, 16, hipMemcpyDeviceToHost));
     return RT_OK;
@@ -1227,6 +1435,7 @@ int rt_debug_read_secondary_ray(rt_pipeline *p, uint32_t index, float origin_tmi
 int rt_pipeline_read_primary_hits(rt_pipeline *p, float *t, uint32_t *prim, uint32_t *inst)
 {
     RT_REQUIRE(p, "null pipeline");
+    RT_TRY(rt_pipeline_flush_pending(p));
     if (!p->rendered) { rt_set_error("nothing rendered yet"); return RT_ERR_STATE; }
     HIP_TRY(hipSetDevice(p->ctx->device));
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));

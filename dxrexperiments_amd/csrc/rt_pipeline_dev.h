@@ -39,10 +39,15 @@ enum { C_NHIT = 0,                       // [0..MAXD] compacted hits per level
 
 // Level L: the rays at radiance depth L (L >= 1; primary rays are generated, not stored), their hit
 // records, the compaction of the hits, and the shadow-ray queue of those hits.
-//   slots of level 1: w*cap + k  (w = 0 diffuse / 1 specular batch, k = compact index of the primary hit)
+//   slots of level 1: w*rstride + k  (w = 0 diffuse / 1 specular batch, k = compact index of the primary hit)
 //   slots of level L >= 2: j     (compact index of the level L-1 hit that spawned the ray)
-//   shadow queue of level L: s*hcap(L) + idx, idx = compact hit index, hcap(0) = cap, hcap(L>=1) = 2 cap
+//   shadow queue of level L: s*hstride + idx, idx = compact hit index
+// The strides are the capacities the level's buffers were sized for: the worst case (rstride = hstride(0) = cap pixel slots,
+// hstride(L >= 1) = 2 cap) or, for sets of frames whose worst case would not fit the device, the counts the compaction of the
+// level before has just produced (launch_frame, "counted" queues).
 struct LevelDev {
+    uint32_t rstride;           // level 1: slots between its two batches (>= the hits of level 0); other levels: unused
+    uint32_t hstride;           // slots between the shadow batches of this level (>= its hits)
     float4 *O, *D;              // ray queue (unused at level 0)
     float4 *hit; uint32_t *inst;   // hit records, indexed by slot (level 0: by pixel slot q)
     uint32_t *slot_j, *jlist;   // slot -> compact hit index (RT_NO_HIT if none), compact index -> slot
@@ -118,7 +123,7 @@ constexpr size_t POOL_BYTES = (size_t)(2 + MAXD) * RT_POOL_GROUPS * RT_POOL_STRI
 #endif
 constexpr size_t POOL_OFFSET_WORDS = 64;      // the pools start on a 256-B boundary after the scalar counters
 
-RT_DEV uint32_t hcap(const PipeDev &pd, int L) { return L == 0 ? pd.cap : 2u * pd.cap; }
+RT_DEV uint32_t hcap(const PipeDev &pd, int L) { return pd.lv[L].hstride; }
 
 inline unsigned blocks(size_t n) { return (unsigned)((n + PBLOCK - 1) / PBLOCK); }
 
@@ -147,8 +152,16 @@ struct rt_pipeline {
     bool have_pfc = false;
     uint32_t max_rad = 1, max_shadow = 2, accum_mode = RT_ACCUM_RUNNING_MEAN;
     uint32_t skip_unlit = 0;           // off by default: every shadow ray the reference traces is traversed (rt_pipeline_set_skip_unlit_shadow_rays)
-    // queues (sized for `cap` pixels)
-    uint32_t cap = 0, sh0_batches = 0, levels = 0;
+    // queues: every render call asks each buffer for what its launches need (DevBuf::reserve keeps what it has when that is
+    // enough), so there is no second book of capacities that could disagree with the allocations after a failed growth
+    size_t queue_budget = 0;           // worst-case queue bytes a set of launches may reserve up front; above it the levels are sized by
+                                       //   count (0: a quarter of the device's memory, or RT_QUEUE_BUDGET_MB)
+    bool counted_queues = false;       // what the last set of launches did
+    // Deferred rendering (rt_pipeline_set_deferred, progressive pipeline): render() only records the frame's constants; the
+    // frames go through ONE set of launches when `deferred_max` of them have gathered or when anything asks for -- or changes --
+    // what they produce.  Bit for bit the image of immediate rendering (rt_pipeline_render_batch's guarantee).
+    uint32_t deferred_max = 0;         // 0 / 1: render() renders
+    std::vector<rt_per_frame_constants> pending;
     struct LevelBuf { DevBuf O, D, hit, inst, slot_j, jlist, pix, shO, shD, vis, color; } lv[MAXD + 1];
     DevBuf counters;
     DevBuf half_out;
@@ -190,6 +203,9 @@ struct rt_pipeline {
     bool rendered = false;
     uint32_t last_scene_gen = 0;       // generation of the scene last_pd was filled from
 };
+
+// renders the frames a deferred pipeline holds (rt_pipeline.hip); every entry point that reads or changes what they see calls it first
+int rt_pipeline_flush_pending(rt_pipeline *p);
 
 namespace rtp {
 

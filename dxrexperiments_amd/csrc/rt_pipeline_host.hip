@@ -47,6 +47,11 @@ int rt_pipeline_create(rt_context *ctx, uint32_t kind, rt_pipeline **out)
 int rt_pipeline_destroy(rt_pipeline *p)
 {
     if (!p) return RT_OK;
+    {   // frames accepted and not rendered yet die with the pipeline (nothing could read them any more)
+        std::vector<rt_pipeline *> &reg = p->ctx->deferred;
+        for (size_t k = 0; k < reg.size(); k++) if (reg[k] == p) { reg.erase(reg.begin() + (long)k); break; }
+        p->pending.clear();
+    }
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     DevBuf *all[] = {&p->d_mats, &p->d_env, &p->accum_own, &p->aov_own, &p->counters, &p->half_out, &p->totals, &p->work, &p->batch_consts, &p->shadow_cache};
@@ -80,6 +85,7 @@ int rt_pipeline_set_scene(rt_pipeline *p, rt_scene *s)
 {
     RT_REQUIRE(p && s, "null argument");
     RT_REQUIRE(s->ctx == p->ctx, "scene belongs to a different context");
+    RT_TRY(rt_pipeline_flush_pending(p));
     rt_scene_retain(s);
     if (p->scene) rt_scene_destroy(p->scene);
     p->scene = s;
@@ -92,6 +98,7 @@ int rt_pipeline_set_scene(rt_pipeline *p, rt_scene *s)
 int rt_pipeline_add_material(rt_pipeline *p, const rt_material_params *m)
 {
     RT_REQUIRE(p && m, "null argument");
+    RT_TRY(rt_pipeline_flush_pending(p));
     p->mats.push_back(*m);
     p->mats_dirty = true;
     p->rendered = false;        // d_mats may be reallocated by the next render
@@ -102,6 +109,10 @@ int rt_pipeline_set_material(rt_pipeline *p, uint32_t index, const rt_material_p
 {
     RT_REQUIRE(p && m, "null argument");
     RT_REQUIRE(index < p->mats.size(), "material index out of range");
+    // (the reference rewrites every hit record every frame, libs/DXRFramework/RtBindings.cpp:100-129, and so does the C++ mirror:
+    // a record that says what it said before changes nothing -- no upload, and no flush of a deferred set)
+    if (memcmp(&p->mats[index], m, sizeof *m) == 0) return RT_OK;
+    RT_TRY(rt_pipeline_flush_pending(p));
     p->mats[index] = *m;
     p->mats_dirty = true;
     p->rendered = false;
@@ -111,6 +122,7 @@ int rt_pipeline_set_material(rt_pipeline *p, uint32_t index, const rt_material_p
 int rt_pipeline_set_environment_cube(rt_pipeline *p, const float *faces, uint32_t size)
 {
     RT_REQUIRE(p && faces && size > 0, "bad argument");
+    RT_TRY(rt_pipeline_flush_pending(p));
     HIP_TRY(hipSetDevice(p->ctx->device));
     const size_t bytes = (size_t)6 * size * size * 16;
     RT_TRY(p->d_env.reserve(bytes));
@@ -123,6 +135,7 @@ int rt_pipeline_set_environment_cube(rt_pipeline *p, const float *faces, uint32_
 int rt_pipeline_set_environment_constant(rt_pipeline *p, const float rgb[3])
 {
     RT_REQUIRE(p && rgb, "null argument");
+    RT_TRY(rt_pipeline_flush_pending(p));
     p->env_size = 0;
     for (int k = 0; k < 3; k++) p->env_const[k] = rgb[k];
     return RT_OK;
@@ -132,6 +145,7 @@ int rt_pipeline_set_environment_filter(rt_pipeline *p, uint32_t filter)
 {
     RT_REQUIRE(p, "null pipeline");
     RT_REQUIRE(filter == RT_CUBE_SEAMLESS || filter == RT_CUBE_FACE_CLAMP, "unknown cube-map filter");
+    RT_TRY(rt_pipeline_flush_pending(p));
     p->env_filter = filter;
     return RT_OK;
 }
@@ -150,6 +164,7 @@ int rt_pipeline_create_output(rt_pipeline *p, uint32_t format, uint32_t width, u
     RT_REQUIRE(p, "null pipeline");
     RT_REQUIRE(width > 0 && height > 0, "empty output");
     RT_REQUIRE(format == RT_FORMAT_R32G32B32A32_FLOAT || format == RT_FORMAT_R16G16B16A16_FLOAT, "unsupported output format");
+    RT_TRY(rt_pipeline_flush_pending(p));
     HIP_TRY(hipSetDevice(p->ctx->device));
     RT_TRY(p->accum_own.reserve((size_t)width * height * 16));
     if (p->kind == RT_PIPELINE_REALTIME) RT_TRY(p->aov_own.reserve((size_t)width * height * 16));     // kNumOutputResources = 2
@@ -164,6 +179,7 @@ int rt_pipeline_bind_output(rt_pipeline *p, void *device_rgba32f, uint32_t width
     RT_REQUIRE(p && device_rgba32f, "null argument");
     RT_REQUIRE(width > 0 && height > 0, "empty output");
     RT_REQUIRE(p->kind == RT_PIPELINE_PROGRESSIVE, "bind_output: only the progressive pipeline renders into caller memory");
+    RT_TRY(rt_pipeline_flush_pending(p));
     p->accum = (float4 *)device_rgba32f;
     p->width = width; p->height = height; p->format = RT_FORMAT_R32G32B32A32_FLOAT;
     p->rendered = false;
@@ -173,6 +189,7 @@ int rt_pipeline_bind_output(rt_pipeline *p, void *device_rgba32f, uint32_t width
 int rt_pipeline_build_acceleration_structures(rt_pipeline *p)
 {
     RT_REQUIRE(p, "null pipeline");
+    RT_TRY(rt_pipeline_flush_pending(p));
     if (!p->scene) { rt_set_error("buildAccelerationStructures: no scene set"); return RT_ERR_STATE; }
     if (p->scene->built) return RT_OK;       // built once, shared between pipelines
     p->rendered = false;                     // a rebuild reallocates what last_pd points at
@@ -182,6 +199,7 @@ int rt_pipeline_build_acceleration_structures(rt_pipeline *p)
 int rt_pipeline_set_depth_limits(rt_pipeline *p, uint32_t max_radiance_depth, uint32_t max_shadow_depth)
 {
     RT_REQUIRE(p, "null pipeline");
+    RT_TRY(rt_pipeline_flush_pending(p));
     if (max_radiance_depth > (uint32_t)MAXD) {
         rt_set_error("max radiance depth %u: the wavefront DAG holds at most %d radiance levels", max_radiance_depth, MAXD);
         return RT_ERR_UNSUPPORTED;
@@ -210,6 +228,7 @@ int rt_pipeline_get_shadow_cache(const rt_pipeline *p, int *cells_per_side)
 int rt_pipeline_set_skip_unlit_shadow_rays(rt_pipeline *p, int on)
 {
     RT_REQUIRE(p, "null pipeline");
+    RT_TRY(rt_pipeline_flush_pending(p));
     p->skip_unlit = on ? 1u : 0u;
     return RT_OK;
 }
@@ -218,6 +237,7 @@ int rt_pipeline_set_accumulation_mode(rt_pipeline *p, uint32_t mode)
 {
     RT_REQUIRE(p, "null pipeline");
     RT_REQUIRE(mode == RT_ACCUM_RUNNING_MEAN || mode == RT_ACCUM_SUM, "unknown accumulation mode");
+    RT_TRY(rt_pipeline_flush_pending(p));
     p->accum_mode = mode;
     return RT_OK;
 }
@@ -225,6 +245,7 @@ int rt_pipeline_set_accumulation_mode(rt_pipeline *p, uint32_t mode)
 int rt_pipeline_clear_output(rt_pipeline *p)
 {
     RT_REQUIRE(p, "null pipeline");
+    RT_TRY(rt_pipeline_flush_pending(p));
     if (!p->accum) { rt_set_error("no output resource"); return RT_ERR_STATE; }
     HIP_TRY(hipSetDevice(p->ctx->device));
     HIP_TRY(hipMemsetAsync(p->accum, 0, (size_t)p->width * p->height * 16, p->ctx->stream));
@@ -251,6 +272,7 @@ int rt_pipeline_get_output_device_ptr(rt_pipeline *p, uint32_t id, void **ptr)
 {
     RT_REQUIRE(p && ptr, "null argument");
     RT_REQUIRE(id < (p->kind == RT_PIPELINE_REALTIME ? 2u : 1u), "output index out of range");
+    RT_TRY(rt_pipeline_flush_pending(p));
     *ptr = id == 0 ? (void *)p->accum : p->aov_own.p;
     return RT_OK;
 }
@@ -259,6 +281,7 @@ int rt_pipeline_read_output_n(rt_pipeline *p, uint32_t id, void *host, size_t by
 {
     RT_REQUIRE(p && host, "null argument");
     RT_REQUIRE(id < (p->kind == RT_PIPELINE_REALTIME ? 2u : 1u), "output index out of range");
+    RT_TRY(rt_pipeline_flush_pending(p));
     const float4 *src = id == 0 ? p->accum : p->aov_own.as<float4>();
     if (!src) { rt_set_error("no output resource"); return RT_ERR_STATE; }
     HIP_TRY(hipSetDevice(p->ctx->device));
@@ -282,6 +305,7 @@ int rt_pipeline_read_output(rt_pipeline *p, void *host, size_t bytes) { return r
 int rt_pipeline_write_output(rt_pipeline *p, const void *host_rgba32f, size_t bytes)
 {
     RT_REQUIRE(p && host_rgba32f, "null argument");
+    RT_TRY(rt_pipeline_flush_pending(p));
     if (!p->accum) { rt_set_error("no output resource"); return RT_ERR_STATE; }
     RT_REQUIRE(bytes == (size_t)p->width * p->height * 16, "host buffer must be width*height*16 bytes (RGBA32F)");
     HIP_TRY(hipSetDevice(p->ctx->device));
@@ -296,6 +320,7 @@ static const char kCheckpointMagic[10] = {'D', 'X', 'R', 'A', 'C', 'C', 'U', 'M'
 int rt_pipeline_save_checkpoint(rt_pipeline *p, const rt_progressive_host *h, const char *path)
 {
     RT_REQUIRE(p && path, "null argument");
+    RT_TRY(rt_pipeline_flush_pending(p));
     if (!p->accum) { rt_set_error("no output resource"); return RT_ERR_STATE; }
     RT_REQUIRE(p->kind == RT_PIPELINE_PROGRESSIVE, "checkpoint: only the progressive pipeline accumulates");
     HIP_TRY(hipSetDevice(p->ctx->device));
@@ -323,6 +348,7 @@ int rt_pipeline_save_checkpoint(rt_pipeline *p, const rt_progressive_host *h, co
 int rt_pipeline_load_checkpoint(rt_pipeline *p, rt_progressive_host *h, const char *path)
 {
     RT_REQUIRE(p && path, "null argument");
+    RT_TRY(rt_pipeline_flush_pending(p));
     if (!p->accum) { rt_set_error("no output resource"); return RT_ERR_STATE; }
     FILE *f = fopen(path, "rb");
     if (!f) { rt_set_error("checkpoint: cannot open %s", path); return RT_ERR_IO; }
@@ -356,6 +382,7 @@ int rt_pipeline_enable_timing(rt_pipeline *p, int frames)
 {
     RT_REQUIRE(p, "null pipeline");
     RT_REQUIRE(frames >= 0 && frames <= 4096, "timing ring holds 0..4096 frames");
+    RT_TRY(rt_pipeline_flush_pending(p));
     HIP_TRY(hipSetDevice(p->ctx->device));
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     for (hipEvent_t e : p->ring) if (e) (void)hipEventDestroy(e);
@@ -401,6 +428,7 @@ static void add_times(rt_stats *out, const float ms[8])
 int rt_pipeline_get_stats(rt_pipeline *p, rt_stats *out)
 {
     RT_REQUIRE(p && out, "null argument");
+    RT_TRY(rt_pipeline_flush_pending(p));
     HIP_TRY(hipSetDevice(p->ctx->device));
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     memset(out, 0, sizeof *out);
@@ -427,6 +455,7 @@ int rt_pipeline_get_stats(rt_pipeline *p, rt_stats *out)
 int rt_pipeline_get_totals(rt_pipeline *p, rt_stats *out)
 {
     RT_REQUIRE(p && out, "null argument");
+    RT_TRY(rt_pipeline_flush_pending(p));
     HIP_TRY(hipSetDevice(p->ctx->device));
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     memset(out, 0, sizeof *out);
@@ -453,6 +482,7 @@ int rt_pipeline_get_totals(rt_pipeline *p, rt_stats *out)
 int rt_pipeline_reset_totals(rt_pipeline *p)
 {
     RT_REQUIRE(p, "null pipeline");
+    RT_TRY(rt_pipeline_flush_pending(p));
     HIP_TRY(hipSetDevice(p->ctx->device));
     if (p->totals.p) HIP_TRY(hipMemsetAsync(p->totals.p, 0, 8 * sizeof(unsigned long long), p->ctx->stream));
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));

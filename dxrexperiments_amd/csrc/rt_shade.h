@@ -372,6 +372,7 @@ struct EmitIO {
     // the shadow slots of this hit that no ray went to are marked "not traced"
     RT_DEV void finish_shadows(uint32_t shadow_slots) const
     {
+        if (L > 0 && (uint32_t)L >= pd.max_shadow) return;      // a level that casts no shadow rays has no shadow queue (launch_frame)
         if (pd.shadow_compact) {
             pd.lv[L].shO[idx] = make_float4(shadow_origin.x, shadow_origin.y, shadow_origin.z, __uint_as_float(shadow_mask | (skip_mask << 2) | (frame << 8)));
             return;
@@ -382,7 +383,7 @@ struct EmitIO {
     RT_DEV f3 secondary(int w, f3 o, f3 d, float tmin, uint32_t depth)
     {
         if (depth >= pd.max_rad || L >= MAXD) return mk3(0.0f, 0.0f, 0.0f);
-        const size_t slot = L == 0 ? (size_t)w * pd.cap + idx : idx;
+        const size_t slot = L == 0 ? (size_t)w * pd.lv[1].rstride + idx : idx;
         store_ray(pd.lv[L + 1].O, pd.lv[L + 1].D, slot, o, tmin, d, RAY_MAX_T);
         pd.lv[L + 1].pix[slot] = q;
         sec_mask |= 1u << w;
@@ -409,7 +410,7 @@ struct ResolveIO {
             return mk3(0.0f, 0.0f, 0.0f);
         } else {
             if (depth >= pd.max_rad) return mk3(0.0f, 0.0f, 0.0f);
-            const size_t slot = L == 0 ? (size_t)w * pd.cap + idx : idx;
+            const size_t slot = L == 0 ? (size_t)w * pd.lv[1].rstride + idx : idx;
             const float4 h = pd.lv[L + 1].hit[slot];
             if (h.x == HIT_MISS) return sample_environment(pd, d);             // PrimaryMiss, :160-164
             if (h.x == HIT_UNTRACED) return mk3(0.0f, 0.0f, 0.0f);
@@ -439,7 +440,7 @@ struct LevelResolveIO {
     RT_DEV f3 secondary(int w, f3, f3 d, float, uint32_t depth)
     {
         if (depth >= pd.max_rad || L >= MAXD) return mk3(0.0f, 0.0f, 0.0f);
-        const size_t slot = L == 0 ? (size_t)w * pd.cap + idx : idx;
+        const size_t slot = L == 0 ? (size_t)w * pd.lv[1].rstride + idx : idx;
         const float4 h = pd.lv[L + 1].hit[slot];
         if (h.x == HIT_MISS) return sample_environment(pd, d);             // PrimaryMiss, :160-164
         if (h.x == HIT_UNTRACED) return mk3(0.0f, 0.0f, 0.0f);

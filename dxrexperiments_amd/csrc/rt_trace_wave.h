@@ -258,9 +258,9 @@ RT_DEV unsigned long long lanemask_lt()
 // walk[6] = max over rays of (node steps << 32 | ray index), the longest single walk (a tail detector);
 // walk[7..9] = what the WAVES did: node steps issued (one per wave per pass of the node loop), leaf phases, triangle
 // iterations of those phases -- with walk[1] + walk[2] (the lanes live in the node steps) and walk[3] (the lanes live in
-// the triangle iterations) the lane utilisation of the two halves of the walk.
+// the triangle iterations) the lane utilisation of the two halves of the walk; walk[10] = the node part of walk[5].
 // The per-ray numbers depend on the ray and the tree only, not on chunking or lane assignment; the per-wave ones on both.
-#define RT_WALK_WORDS 10
+#define RT_WALK_WORDS 11
 template <int STACK, int BLOCK, bool TWO_LEVEL, uint32_t CHUNK, bool ANYHIT = false, bool COUNT = false, class Src, class Sink>
 RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uint32_t *pool, int *smem, uint32_t *traced_counter,
                        unsigned long long *walk = nullptr)
@@ -271,6 +271,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
     uint32_t wk_ray0 = 0;                        // node steps tallied when the lane's current ray started
     unsigned long long wk_longest = 0;           // (node steps << 32 | ray index) of the lane's longest walk
     uint32_t wv_steps = 0, wv_leaf = 0, wv_tri = 0;      // what the wave did (COUNT): tallied by the first live lane of each step
+    uint32_t wk_node_lines = 0;                  // the node part of wk_lines
     const uint32_t total = src.count();
     const uint32_t flags = src.flags();
     // ANYHIT instantiations (unordered walks) are only launched for ACCEPT_FIRST_HIT searches: as a compile-time fact it lets the
@@ -424,7 +425,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
             if (COUNT) {
                 if ((uint32_t)node < top_lim) wk_top++; else wk_glob++;
                 const uint32_t dl = distinct_node_lines(node, !((uint32_t)node < top_lim));
-                if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_read_exec())) { wk_lines += (RT_WIDE == 8 ? 2u : 1u) * dl; wv_steps++; }       // 64-B lines (96 B of a 128-B record: two)
+                if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_read_exec())) { wk_lines += (RT_WIDE == 8 ? 2u : 1u) * dl; wk_node_lines += (RT_WIDE == 8 ? 2u : 1u) * dl; wv_steps++; }       // 64-B lines (96 B of a 128-B record: two)
             }
             wide_step<false, ANYHIT>(nodes, top_cur, top_lim, cur.ri, r.tmin, ANYHIT ? r.tmax : best.t, st, node, sp);
 #if RT_EXIT_K > 0
@@ -438,7 +439,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
             if (COUNT) {
                 if ((uint32_t)node < top_lim) wk_top++; else wk_glob++;
                 const uint32_t dl = distinct_node_lines(node, !((uint32_t)node < top_lim));
-                if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_read_exec())) { wk_lines += (RT_WIDE == 8 ? 2u : 1u) * dl; wv_steps++; }       // 64-B lines (96 B of a 128-B record: two)
+                if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_read_exec())) { wk_lines += (RT_WIDE == 8 ? 2u : 1u) * dl; wk_node_lines += (RT_WIDE == 8 ? 2u : 1u) * dl; wv_steps++; }       // 64-B lines (96 B of a 128-B record: two)
             }
             wide_step<true, ANYHIT>(nodes, top_cur, top_lim, cur.ri, r.tmin, ANYHIT ? r.tmax : best.t, st, node, sp);
         }
@@ -516,8 +517,8 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 #endif
     }
     if (COUNT && walk) {
-        const unsigned long long w9[9] = {(threadIdx.x & 63u) == 0u ? n_traced : 0u, wk_glob, wk_top, wk_tri, wk_inst, wk_lines, wv_steps, wv_leaf, wv_tri};
-        for (int k = 0; k < 9; k++) {
+        const unsigned long long w9[10] = {(threadIdx.x & 63u) == 0u ? n_traced : 0u, wk_glob, wk_top, wk_tri, wk_inst, wk_lines, wv_steps, wv_leaf, wv_tri, wk_node_lines};
+        for (int k = 0; k < 10; k++) {
             unsigned long long v = w9[k];
             for (int o = 32; o > 0; o >>= 1) v += (unsigned long long)__shfl_xor((long long)v, o, 64);
             if ((threadIdx.x & 63u) == 0u && v) atomicAdd(&walk[k < 6 ? k : k + 1], v);

@@ -53,6 +53,23 @@ public:
         DXRFramework::ThrowIfFailed(rt_pipeline_render_bands(mPipeline, width, height, bandRows, rank, world));
     }
 
+    // renderBatch for a tile-partitioned run: n frames of this rank's bands through shared sets of launches
+    void renderBandsBatch(float elapsedTime, UINT firstElapsedFrames, UINT n, UINT width, UINT height, UINT bandRows, UINT rank, UINT world)
+    {
+        std::vector<PerFrameConstants> constants(n);
+        float cam[11];
+        mCamera->Pack(cam);
+        rt_debug_options *opt = nullptr;
+        DXRFramework::ThrowIfFailed(rt_progressive_host_options(mHost, &opt));
+        *opt = mShaderDebugOptions;
+        DXRFramework::ThrowIfFailed(rt_progressive_host_set_flags(mHost, mFrameAccumulationEnabled, mAnimationPaused));
+        for (UINT i = 0; i < n; ++i)
+            DXRFramework::ThrowIfFailed(rt_progressive_host_update(mHost, cam, elapsedTime, firstElapsedFrames + i, width, height, &constants[i]));
+        fillShaderTable();
+        DXRFramework::ThrowIfFailed(rt_pipeline_render_bands_batch(mPipeline, width, height, bandRows, rank, world, constants.data(), n));
+        if (n) mConstants = constants[n - 1];
+    }
+
     // n frames = n x { update(...); render(...) } with the same bits in the output, through shared sets of launches
     // (rt_pipeline_render_batch; the sample-batch mode of long accumulations).  elapsedFrames is the frame count of the FIRST
     // of them; the host state (jitter RNG, accumulation counter) advances exactly as n update() calls would advance it.
@@ -71,6 +88,17 @@ public:
         DXRFramework::ThrowIfFailed(rt_pipeline_render_batch(mPipeline, width, height, constants.data(), n));
         if (n) mConstants = constants[n - 1];
     }
+
+    // Sets of frames behind update() + render() (rt_pipeline_set_deferred; ON by default here, 32 frames): render() records the
+    // frame, the recorded frames go through one set of launches when 32 have gathered or when anything reads or changes what
+    // they produce -- getOutputResource() / readOutput() / saveCheckpoint(), a material or scene change, RtContext::synchronize.
+    // Bit for bit the image of rendering every frame at once; an application that presents every frame (the reference's
+    // OnRender copies the output each frame, src/DXRExperimentsApp.cpp:194-214) flushes every frame and loses nothing.
+    // 0 or 1: render() renders.
+    void setDeferredFrames(UINT frames) { DXRFramework::ThrowIfFailed(rt_pipeline_set_deferred(mPipeline, frames)); }
+    UINT getDeferredFrames() const { uint32_t m = 0; rt_pipeline_get_deferred(mPipeline, &m, nullptr); return m; }
+    UINT getPendingFrames() const { uint32_t n = 0; rt_pipeline_get_deferred(mPipeline, nullptr, &n); return n; }
+    void flush() { DXRFramework::ThrowIfFailed(rt_pipeline_flush(mPipeline)); }
 
     // the light buffer of occluders shadow rays test first (-1 automatic, 0 off, else cells per side): same image, less time
     void setShadowCache(int cellsPerSide) { DXRFramework::ThrowIfFailed(rt_pipeline_set_shadow_cache(mPipeline, cellsPerSide)); }
@@ -159,6 +187,7 @@ private:
         mRtState->setMaxAttributeSize(8);
         mRtState->setMaxPayloadSize(20);
         ThrowIfFailed(rt_pipeline_create(context->getHandle(), RT_PIPELINE_PROGRESSIVE, &mPipeline));
+        ThrowIfFailed(rt_pipeline_set_deferred(mPipeline, 32));       // sets of frames behind update() + render(): setDeferredFrames()
         ThrowIfFailed(rt_progressive_host_create(rngSeed, &mHost));
         rt_debug_options *opt = nullptr;
         ThrowIfFailed(rt_progressive_host_options(mHost, &opt));

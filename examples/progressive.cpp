@@ -50,8 +50,10 @@ int main(int argc, char **argv)
         pipeline->buildAccelerationStructures();
 
         const auto t0 = std::chrono::steady_clock::now();
-        // DXR_SETS=n (1..32): the frames go through shared sets of launches, n at a time (renderBatch: the same image bit for bit,
-        // a quarter less time); default: one update + render per frame as the reference's app loop issues them
+        // Default: one update() + render() per frame as the reference's app loop issues them (src/DXRExperimentsApp.cpp:162-165, :194);
+        // the pipeline records the frames and renders them in sets of 32 (deferred mode: the same image bit for bit, a quarter
+        // less time) -- DXR_DEFERRED=n changes the set size, 0 renders every frame at once.  DXR_SETS=n: the explicit form, renderBatch.
+        if (const char *d = std::getenv("DXR_DEFERRED")) pipeline->setDeferredFrames((UINT)std::atoi(d));
         const char *sets_env = std::getenv("DXR_SETS");
         const UINT per_set = sets_env ? (UINT)std::atoi(sets_env) : 1u;
         if (per_set > 1) {

@@ -219,7 +219,8 @@ int rt_pipeline_render(rt_pipeline *p, uint32_t width, uint32_t height);
  * share the ray queues (a slot's frame selects constants, lights and RNG seed), so the persistent traversal launches and
  * their tails are paid once per batch, and the resolve kernel folds a pixel's frames in frame order -- the running mean is
  * the one n single frames leave.  Frames with accumCount >= maxIterations are skipped (:14-16).  Progressive pipeline only;
- * afterwards the pipeline's constants are constants[n - 1].  Queue memory grows with the batch (1080p: ~0.8 GB per frame). */
+ * afterwards the pipeline's constants are constants[n - 1].  Queue memory grows with the batch (1080p: at most 0.47 GB per frame;
+ * rt_pipeline_set_queue_budget). */
 int rt_pipeline_render_batch(rt_pipeline *p, uint32_t width, uint32_t height, const rt_per_frame_constants *constants, uint32_t n);
 /* Sizes the ray queues for sets of `frames` frames of width x height now, so that the first rt_pipeline_render_batch of that size
  * does not allocate (the counterpart of createOutputResource for the per-frame work memory the reference's Fallback Layer keeps
@@ -231,6 +232,28 @@ int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height,
 /* same, restricted to the interleaved row bands {b : b mod world == rank} of band_rows rows each (rt_tile_bands), all of
  * them in ONE set of launches: the per-frame call of a tile-partitioned multi-GPU run.  band_rows must be a multiple of 8. */
 int rt_pipeline_render_bands(rt_pipeline *p, uint32_t width, uint32_t height, uint32_t band_rows, uint32_t rank, uint32_t world);
+/* rt_pipeline_render_batch restricted to the rank's bands: n frames of a tile-partitioned run through shared sets of launches
+ * (BASELINE configs[4]: at 8 ranks a band set of ONE 4K frame is an eighth of a frame per persistent launch; sets of frames give
+ * the launches back their length).  Pixels are seeded by their global index (assets/shaders/ProgressiveRaytracing.hlsl:89), so
+ * the rows equal the same rows of n whole frames bit for bit. */
+int rt_pipeline_render_bands_batch(rt_pipeline *p, uint32_t width, uint32_t height, uint32_t band_rows, uint32_t rank, uint32_t world,
+                                   const rt_per_frame_constants *constants, uint32_t n);
+/* Sets of frames BEHIND the reference's own per-frame calls (src/DXRExperimentsApp.cpp:162-165, :194: one update() and one
+ * render() per frame; accumulation order src/ProgressiveRaytracingPipeline.cpp:188-195).  With max_frames > 1, rt_pipeline_render
+ * records the frame's constants and returns; the recorded frames go through ONE set of launches (rt_pipeline_render_batch:
+ * bit for bit the image of rendering each frame at once) as soon as max_frames (<= 32) have gathered, or when a call reads what
+ * they produce (read_output, get_output_device_ptr, checkpoints, statistics, the counting re-walks), changes what they would
+ * see (scene, materials, environment, output, depth limits, accumulation mode, clear), or synchronises the context.  Errors of
+ * a deferred frame surface at the call that flushes it.  Progressive pipeline only; 0 or 1 = render() renders (the default). */
+int rt_pipeline_set_deferred(rt_pipeline *p, uint32_t max_frames);
+int rt_pipeline_get_deferred(const rt_pipeline *p, uint32_t *max_frames, uint32_t *pending);      /* either may be NULL */
+int rt_pipeline_flush(rt_pipeline *p);
+/* Queue memory.  A set of launches reserves the worst case of its ray / hit / shadow queues up front when that fits `bytes`
+ * (0: the default, a quarter of the device's memory, or env RT_QUEUE_BUDGET_MB); above it every radiance level is sized by the
+ * count the compaction before it has produced (one 4-byte read-back per level and set).  get: bytes reserved now, and whether
+ * the last set of launches sized its levels by count. */
+int rt_pipeline_set_queue_budget(rt_pipeline *p, size_t bytes);
+int rt_pipeline_get_queue_memory(rt_pipeline *p, size_t *bytes_reserved, uint32_t *sized_by_count);
 int rt_pipeline_get_num_outputs(const rt_pipeline *p, int *n);               /* getNumOutputs .h:34 */
 int rt_pipeline_get_output_device_ptr(rt_pipeline *p, uint32_t id, void **ptr); /* getOutputResource .h:35 */
 /* synchronises; host buffer is w*h*4 floats (RGBA32F) or halfs (RGBA16F) */
@@ -360,6 +383,8 @@ int rt_debug_math(rt_context *ctx, int fn, const float *x, const float *y, float
 int rt_debug_sample(rt_context *ctx, int kind, const uint32_t *seeds, const float *vec3_in, float exponent,
                     float *vec3_out, float *pdf_brdf, uint32_t *seeds_out, size_t n);
 int rt_debug_read_secondary_ray(rt_pipeline *p, uint32_t index, float origin_tmin[4], float dir_tmax[4]);   /* tools/longest_walk.py */
+/* test hook: device allocations of more than `bytes` bytes fail with RT_ERR_OOM as if the device were full (0: no limit) */
+int rt_debug_set_alloc_limit(size_t bytes);
 int rt_debug_sample_cube(rt_context *ctx, const float *faces_rgba32f, uint32_t size, uint32_t filter, const float *dirs, float *out, size_t n);
 /* The DDS cube-map reader behind rt_pipeline_load_environment_dds, without a device (tests run it on the reference's
  * own assets/textures/CathedralRadiance.dds): *size = edge length of mip 0; faces_rgba32f (may be NULL to query the

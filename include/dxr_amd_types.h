@@ -174,6 +174,7 @@ typedef struct rt_stage_walk {
     uint64_t wave_node_steps;    /* node steps issued: one per wave per pass of the node loop                        */
     uint64_t wave_leaf_phases;   /* leaf phases (triangles, instance entry / exit, ray end) entered by a wave         */
     uint64_t wave_tri_steps;     /* triangle-test iterations issued by the waves' leaf phases                         */
+    uint64_t node_lines;         /* the node part of `lines`: distinct 64-B node lines per wave step, summed             */
 } rt_stage_walk;
 
 /* Status codes returned by every export. */

@@ -40,8 +40,32 @@ int main(int argc, char **argv)
             pipeline->update(0.0f, frame, 0, 0, W, H);
             pipeline->render(0, W, H);
         }
+        // (round 4) the mirror records the frames and renders them in sets behind update() + render(): four frames are held
+        // until something reads them
+        if (static_cast<ProgressiveRaytracingPipeline *>(pipeline.get())->getDeferredFrames() != 32 ||
+            static_cast<ProgressiveRaytracingPipeline *>(pipeline.get())->getPendingFrames() != 4) return 14;
         std::vector<float> image(size_t(W) * H * 4);
         static_cast<ProgressiveRaytracingPipeline *>(pipeline.get())->readOutput(image.data(), image.size() * 4);
+        if (static_cast<ProgressiveRaytracingPipeline *>(pipeline.get())->getPendingFrames() != 0) return 15;
+        // ... and the image is the one of rendering every frame at once
+        {
+            auto immediate = ProgressiveRaytracingPipeline::create(context, 1234);
+            immediate->setDeferredFrames(0);
+            immediate->setScene(scene);
+            immediate->addMaterial(material);
+            immediate->setCamera(camera);
+            immediate->loadResources(3);
+            immediate->createOutputResource(RT_FORMAT_R32G32B32A32_FLOAT, W, H);
+            immediate->buildAccelerationStructures();
+            for (UINT frame = 1; frame <= 4; ++frame) {
+                immediate->update(0.0f, frame, 0, 0, W, H);
+                immediate->render(0, W, H);
+                if (immediate->getPendingFrames() != 0) return 16;
+            }
+            std::vector<float> again(image.size());
+            immediate->readOutput(again.data(), again.size() * 4);
+            if (std::memcmp(again.data(), image.data(), image.size() * 4) != 0) return 17;
+        }
         FILE *f = std::fopen(argv[2], "wb");
         if (!f) return 4;
         std::fwrite(image.data(), 4, image.size(), f);

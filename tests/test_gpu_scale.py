@@ -171,14 +171,19 @@ def test_bench_two_ranks_on_one_gpu():
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     # weak scaling: two ranks trace twice the frames, i.e. about twice the rays per step
     assert abs(d["value"] * d["ms_per_step"] / (d1["value"] * d1["ms_per_step"]) - 2.0) < 0.05
-    # the single-GPU line carries the contract's objects: sets of frames as the entry point, frame by frame beside it, and a
-    # roofline whose fraction is achieved / peak of the same unit
-    assert d1["config"]["frames_per_launch_set"] == 4 and d1["config"]["launch_sets"] == 1 and d1["config"]["entry_point"] == "rt_pipeline_render_batch"
+    # the single-GPU line carries the contract's objects: the reference's per-frame calls as the entry point (rendered in sets by the
+    # deferred pipeline), the same calls with deferred mode off beside it, and a roofline whose fraction is achieved / peak of the same unit
+    assert d1["config"]["frames_per_launch_set"] == 4 and d1["config"]["launch_sets"] == 1
+    assert d1["config"]["entry_point"].startswith("rt_pipeline_update + rt_pipeline_render per frame") and "rt_pipeline_set_deferred(4)" in d1["config"]["entry_point"]
+    assert d1["config"]["queue_memory_bytes_per_frame"] > 0
     fb = d1["frame_by_frame"]
     assert fb["frames"] == 4 and fb["ms_per_frame"] > 0 and fb["Mrays_per_s"] > 0
     rl = d1["roofline"]
-    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "frames_per_launch", "memory_path"):
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "frames_per_launch", "memory_path", "algorithmic_bytes",
+              "compulsory_bytes", "lane_utilisation"):
         assert k in rl, k
+    assert rl["bound"] == "hbm" and rl["unit"] == "GB/s" and rl["peak"] == 8000.0
+    assert 0.2 < rl["lane_utilisation"]["node_steps"] <= 1.0 and 0.1 < rl["lane_utilisation"]["triangle_steps"] <= 1.0
     assert rl["frac"] is None          # (no live counters asked for and not the default workload: the committed profile does not apply)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert key in d1 and key in d, key
