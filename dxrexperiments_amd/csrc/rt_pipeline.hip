@@ -181,6 +181,23 @@ RT_DEV void shade_emit_body(const PipeDev &pd_arg, int level, uint32_t shadow_sl
     (void)pix_xy(pd, ql, px, py);
     const RayD r = L == 0 ? primary_ray(pd, px, py) : load_ray(pd.lv[L].O, pd.lv[L].D, slot);
     const float4 h = pd.lv[L].hit[slot];
+    if (!PRIMARY && !emit_next && pd.shadow_compact && !pd.skip_unlit) {
+        // The LAST radiance level (round 4): its hits spawn nothing, so all the emit pass has to leave is where their two light
+        // rays start -- P = O + t D, the expression of closest_hit_aov -- and which of the two exist: both
+        // (RaytracingCommon.hlsli:126-147 trace them whatever N.L is), or the one shade() draws in the one-light view
+        // (ProgressiveRaytracing.hlsl:92-97: the first number of the pixel's sequence).  No normals record, no material, no
+        // lobe sample: the resolve pass shades these hits anyway.  (With the reference's depth limits this is every secondary
+        // hit: 3.7 M per 1080p frame, the emit kernel 0.065 -> 0.02 ms.)
+        const f3 P = r.o + r.d * h.x;
+        uint32_t mask = 3u;
+        if (pd.kind != RT_PIPELINE_REALTIME && pd.pfc.options.debug == 2) {
+            uint32_t seed = init_rand(px + py * pd.width, pd.pfc.cameraParams.frameCount);
+            mask = next_rand(seed) < 0.5f ? 1u : 2u;
+        }
+        if ((uint32_t)L >= pd.max_shadow) mask = 0u;
+        pd.lv[L].shO[idx] = make_float4(P.x, P.y, P.z, __uint_as_float(mask | (frame << 8)));
+        return;
+    }
     EmitIO io(pd, L, idx, q, frame);
     (void)closest_hit(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.lv[L].inst[slot], (uint32_t)L, px + py * pd.width);
     io.finish_shadows(shadow_slots);
@@ -218,15 +235,26 @@ struct RayQueue {
     RT_DEV uint32_t n() const { return *count_ptr; }
     RT_DEV uint32_t count() const { return n() * batches; }
     RT_DEV uint32_t flags() const { return fl; }
-    RT_DEV size_t slot(uint32_t i) const { const uint32_t c = n(); return (size_t)(i / c) * stride + i % c; }
+    // ray i of the queue = ray k of batch b.  At most four batches: compares against multiples of the (wave-uniform) count instead
+    // of a division and a remainder -- ~50 vector instructions per ray loaded and per result stored, in the part of the persistent
+    // kernels that runs with the fewest lanes (round 4)
+    RT_DEV void split(uint32_t i, uint32_t &b, uint32_t &k) const
+    {
+        const uint32_t c = n();
+        b = i >= c ? 1u : 0u;
+        if (batches > 2u) { b += i >= 2u * c ? 1u : 0u; b += i >= 3u * c ? 1u : 0u; }      // (c <= cap < 2^30 there)
+        k = i - b * c;
+    }
+    RT_DEV size_t slot(uint32_t i) const { uint32_t b, k; split(i, b, k); return (size_t)b * stride + k; }
     // per_frame: a batch of frames -- the lights of frame f (bits 8.. of the hit's word).  The single-frame kernels call this
     // with a literal nullptr: the branch folds away and their code is what it was before batches existed (with the branch
     // compiled in, the five inlined copies of this loader cost the any-hit kernel 30 VGPRs and 128 B of scratch).
     RT_DEV bool load_lit(uint32_t i, RayD &r, const LightRays &lights, const LightRays *per_frame) const
     {
         if (lights.on) {
-            const uint32_t c = n(), b = i / c;
-            const v4f a = ldg16(O, (size_t)(i % c) * 16);
+            uint32_t b, k;
+            split(i, b, k);
+            const v4f a = ldg16(O, (size_t)k * 16);
             const uint32_t bits = __float_as_uint(a.w);
             r.o = mk3(a.x, a.y, a.z);
             r.d = mk3(0.0f, 0.0f, 0.0f);
