@@ -194,8 +194,7 @@ RT_DEV void shade_emit_body(const PipeDev &pd_arg, int level, uint32_t shadow_sl
             uint32_t seed = init_rand(px + py * pd.width, pd.pfc.cameraParams.frameCount);
             mask = next_rand(seed) < 0.5f ? 1u : 2u;
         }
-        if ((uint32_t)L >= pd.max_shadow) mask = 0u;
-        pd.lv[L].shO[idx] = make_float4(P.x, P.y, P.z, __uint_as_float(mask | (frame << 8)));
+        if ((uint32_t)L < pd.sh_levels) pd.sh_hits[pd.sh_cbase[L] + idx] = make_float4(P.x, P.y, P.z, __uint_as_float(mask | (frame << 8)));
         return;
     }
     EmitIO io(pd, L, idx, q, frame);
@@ -218,85 +217,31 @@ __global__ void __launch_bounds__(PBLOCK) k_shade_emit(PipeDev pd, int level, ui
     else shade_emit_body<PRIMARY, BATCH, MAXD>(pd, level, shadow_slots, emit_next);
 }
 
-// a ray queue of `batches` batches of *count rays; batch b lives at [b*stride, b*stride + *count).
-// Shadow queues are normally COMPACT ("light rays"): both shadow rays of a shaded hit start at the hit point and go to the
-// frame's two lights, so the emit pass stores one float4 per hit -- the point and, in the bits of w, which of the two rays
-// exist (bits 0-1) and which need not be traversed (bits 2-3) -- and this loader rebuilds ray b of hit k with the very
-// expressions of evaluateDirectionalLight / evaluatePointLight (RaytracingCommon.hlsli:126-147; directional_light /
-// point_light above): 16 B written and read per hit instead of 128 B.  The four rays of the ambient-occlusion view have
-// random directions and keep the explicit origin / direction form.
-// (RayQueue: the queue itself; QueueSrc: a queue with the frame's light rays, a ray source of its own.  The launch of all shadow
-// queues holds ONE copy of the lights beside its queues -- five copies in the kernel argument cost the two-level any-hit kernel
-// the scalar registers it spills into vector ones.)
-struct RayQueue {
+// a ray queue of `batches` batches of *count rays; batch b lives at [b*stride, b*stride + *count): the radiance rays of a level
+// (level 1: the diffuse and the specular batch of the primary hits)
+struct QueueSrc {
     const float4 *O, *D;
     const uint32_t *count_ptr;
     uint32_t stride, batches, fl;
     RT_DEV uint32_t n() const { return *count_ptr; }
     RT_DEV uint32_t count() const { return n() * batches; }
     RT_DEV uint32_t flags() const { return fl; }
-    // ray i of the queue = ray k of batch b.  At most four batches: compares against multiples of the (wave-uniform) count instead
-    // of a division and a remainder -- ~50 vector instructions per ray loaded and per result stored, in the part of the persistent
+    // ray i of the queue = ray k of batch b.  At most two batches: a compare against the (wave-uniform) count instead of a
+    // division and a remainder -- ~50 vector instructions per ray loaded and per result stored, in the part of the persistent
     // kernels that runs with the fewest lanes (round 4)
-    RT_DEV void split(uint32_t i, uint32_t &b, uint32_t &k) const
+    RT_DEV size_t slot(uint32_t i) const
     {
-        const uint32_t c = n();
-        b = i >= c ? 1u : 0u;
-        if (batches > 2u) { b += i >= 2u * c ? 1u : 0u; b += i >= 3u * c ? 1u : 0u; }      // (c <= cap < 2^30 there)
-        k = i - b * c;
+        const uint32_t c = n(), b = i >= c ? 1u : 0u;
+        return (size_t)b * stride + (i - b * c);
     }
-    RT_DEV size_t slot(uint32_t i) const { uint32_t b, k; split(i, b, k); return (size_t)b * stride + k; }
-    // per_frame: a batch of frames -- the lights of frame f (bits 8.. of the hit's word).  The single-frame kernels call this
-    // with a literal nullptr: the branch folds away and their code is what it was before batches existed (with the branch
-    // compiled in, the five inlined copies of this loader cost the any-hit kernel 30 VGPRs and 128 B of scratch).
-    RT_DEV bool load_lit(uint32_t i, RayD &r, const LightRays &lights, const LightRays *per_frame) const
+    RT_DEV bool load(uint32_t i, RayD &r) const
     {
-        if (lights.on) {
-            uint32_t b, k;
-            split(i, b, k);
-            const v4f a = ldg16(O, (size_t)k * 16);
-            const uint32_t bits = __float_as_uint(a.w);
-            r.o = mk3(a.x, a.y, a.z);
-            r.d = mk3(0.0f, 0.0f, 0.0f);
-            r.tmin = 0.0f;
-            r.tmax = -1.0f;                                  // no such ray: never traced
-            if (!((bits >> b) & 1u)) return false;
-            if ((bits >> (2u + b)) & 1u) { r.tmax = RT_TMAX_SKIPPED; return false; }
-            r.tmin = RAY_EPSILON;
-            if (per_frame) {                                 // (three floats by hand: a struct copy ends up in scratch memory)
-                const float *fl = b == 0u ? per_frame[(bits >> 8) & 0xffu].dir_to_light : per_frame[(bits >> 8) & 0xffu].point_pos;
-                const f3 l = mk3(fl[0], fl[1], fl[2]);
-                if (b == 0u) { r.d = l; r.tmax = RAY_MAX_T; }
-                else {
-                    const f3 path = l - r.o;
-                    const float dist = length(path);
-                    r.d = normalize(path);
-                    r.tmax = dist - fmaxf(RAY_EPSILON, fl[3]);       // (fl[3]: point_free of that frame's lights)
-                }
-                return r.tmax > r.tmin;
-            }
-            if (b == 0u) {
-                r.d = mk3(lights.dir_to_light[0], lights.dir_to_light[1], lights.dir_to_light[2]);
-                r.tmax = RAY_MAX_T;
-            } else {
-                const f3 path = mk3(lights.point_pos[0], lights.point_pos[1], lights.point_pos[2]) - r.o;
-                const float dist = length(path);
-                r.d = normalize(path);
-                r.tmax = dist - fmaxf(RAY_EPSILON, lights.point_free);
-            }
-            return r.tmax > r.tmin;
-        }
         const size_t sl = slot(i);
         const v4f a = ldg16(O, sl * 16), b = ldg16(D, sl * 16);
         r.o = mk3(a.x, a.y, a.z); r.tmin = a.w;
         r.d = mk3(b.x, b.y, b.z); r.tmax = b.w;
         return r.tmax > r.tmin;
     }
-};
-struct QueueSrc : RayQueue {
-    LightRays lights;
-    RT_DEV bool load(uint32_t i, RayD &r) const { return RayQueue::load_lit(i, r, lights, nullptr); }
-    RT_DEV bool load_lit(uint32_t i, RayD &r, const LightRays *per_frame) const { return RayQueue::load_lit(i, r, lights, per_frame); }
 };
 static inline LightRays light_rays(uint32_t shadow_compact, const rt_per_frame_constants &pfc)
 {
@@ -321,16 +266,6 @@ static inline LightRays no_light_rays()
     return l;
 }
 
-// a queue read with the batch's per-frame lights (nullptr: a single frame); the counting kernels are not register critical
-struct LitQueueSrc {
-    QueueSrc q;
-    const LightRays *per_frame;
-    RT_DEV uint32_t n() const { return q.n(); }
-    RT_DEV uint32_t count() const { return q.count(); }
-    RT_DEV uint32_t flags() const { return q.flags(); }
-    RT_DEV bool load(uint32_t i, RayD &r) const { return q.load_lit(i, r, per_frame); }
-};
-
 struct SecondarySink {
     QueueSrc q;
     float4 *hit1;
@@ -344,39 +279,99 @@ struct SecondarySink {
     }
 };
 
-// every shadow ray of the frame in ONE launch: the shadow queues of all shaded levels, back to back
-// BATCH: the launch covers several frames, a ray takes the light rays of its hit's frame
-struct ShadowQueues {
-    RayQueue q[MAXD + 1];
-    LightRays lights;                   // the frame's light rays, for all the queues
-    uint32_t *vis[MAXD + 1];
-    int nq;
-    const LightRays *frame_lights;      // device array [n_frames] (batches)
+// The shadow rays of the frame: ONE queue for the hits of every level (PipeDev::sh_*), ONE persistent any-hit launch.  Ray number i
+// -> chunk i >> 6 -> the chunk's hits ((chunk >> log2) << 6 ...) and which of a hit's rays the chunk holds (chunk & (rays per
+// hit - 1)): shifts and masks.  Normally the queue is COMPACT ("light rays"): both shadow rays of a shaded hit start at the hit
+// point and go to the frame's two lights, so the emit pass stores one float4 per hit -- the point and, in the bits of w, which of
+// the two rays exist (bits 0-1), which need not be traversed (bits 2-3) and the hit's frame of the set (bits 8..) -- and the loader
+// rebuilds ray b of hit H with the very expressions of evaluateDirectionalLight / evaluatePointLight
+// (RaytracingCommon.hlsli:126-147; directional_light / point_light in rt_shade.h): 16 B written and read per hit instead of
+// 128 B.  The four rays of the ambient-occlusion view have random directions and keep the explicit origin / direction form.
+struct ShadowQueue {
+    const float4 *hits, *O, *D;
+    uint32_t *vis;
+    const uint32_t *nhit;               // counters + C_NHIT: the hits of every level
+    uint32_t log2, fl;
+    uint32_t lv_first, lv_count;        // the levels whose rays this launch covers (the frame's launch: all; the counting re-walks: 0 / the rest)
+    uint32_t cbase[MAXD + 1], hstride[MAXD + 1];      // storage: PipeDev::sh_cbase, LevelDev::hstride
+    LightRays lights;                   // the frame's light rays (lights.on: the compact form)
+    const LightRays *frame_lights;      // device array [n_frames] (sets of frames)
     ShadowCacheDev cache;
-};
-template <bool BATCH>
-struct ShadowSrcN : ShadowQueues {
-    // (the loops are fully unrolled so that q[k] is always a compile-time member of the kernel argument)
+    // the launch enumerates, level after level, round64(hits) rays of kind 0, then of kind 1, ... (wave-uniform: scalar loads and adds)
     RT_DEV uint32_t count() const
     {
-        uint32_t c = 0;
+        uint32_t b = 0;
 #pragma unroll
-        for (int k = 0; k <= MAXD; k++) if (k < nq) c += q[k].count();
-        return c;
+        for (uint32_t k = 0; k <= (uint32_t)MAXD; k++) if (k >= lv_first && k < lv_first + lv_count) b += (nhit[k] + 63u) & ~63u;
+        return b << log2;
     }
-    RT_DEV uint32_t flags() const { return q[0].fl; }
-    RT_DEV bool load(uint32_t i, RayD &r) const
+    RT_DEV uint32_t flags() const { return fl; }
+};
+template <bool BATCH>
+struct ShadowSrcN : ShadowQueue {
+    // Ray i of the launch -> (level, kind of ray b, hit j of the level) by compares against wave-uniform thresholds; `ticket` =
+    // the ray's number in storage order, which is where the sink puts its result (the walk carries it in place of i).
+    // BATCH: a set of frames -- the lights of frame f (bits 8.. of the hit's word).  The single-frame kernels pass a literal nullptr:
+    // the branch folds away
+    RT_DEV bool load(uint32_t i, RayD &r, uint32_t &ticket) const
     {
+        uint32_t n = 0, R = 0, cb = 0, hs = 0, before = 0;
+        ticket = 0;
 #pragma unroll
-        for (int k = 0; k <= MAXD; k++) {
-            if (k < nq) {
-                const uint32_t c = q[k].count();
-                if (i < c) return q[k].load_lit(i, r, lights, BATCH ? frame_lights : nullptr);
-                i -= c;
+        for (uint32_t k = 0; k <= (uint32_t)MAXD; k++) {
+            if (k >= lv_first && k < lv_first + lv_count) {
+                const uint32_t nk = nhit[k], Rk = (nk + 63u) & ~63u, start = before;
+                before += Rk << log2;
+                const bool here = i >= start;             // (the last level that says so wins)
+                n = here ? nk : n; R = here ? Rk : R; cb = here ? cbase[k] : cb; hs = here ? hstride[k] : hs;
+                if (here) ticket = start;                 // (queue index of the level's first ray, for now)
             }
         }
-        r.o = mk3(0.0f, 0.0f, 0.0f); r.d = r.o; r.tmin = 0.0f; r.tmax = -1.0f;
-        return false;
+        const uint32_t local = i - ticket;
+        uint32_t b = local >= R ? 1u : 0u;
+        if (log2 > 1u) { b += local >= 2u * R ? 1u : 0u; b += local >= 3u * R ? 1u : 0u; }
+        const uint32_t j = local - b * R;
+        ticket = (cb << log2) + b * hs + j;
+        r.o = mk3(0.0f, 0.0f, 0.0f);
+        r.d = mk3(0.0f, 0.0f, 0.0f);
+        r.tmin = 0.0f;
+        r.tmax = -1.0f;                                      // no such ray: never traced
+        if (j >= n) { ticket = RT_NO_HIT; return false; }   // (the entries that round a level up to 64: nothing to load, nothing to store)
+        if (lights.on) {
+            const v4f a = ldg16(hits, (size_t)(cb + j) * 16);
+            const uint32_t bits = __float_as_uint(a.w);
+            r.o = mk3(a.x, a.y, a.z);
+            if (!((bits >> b) & 1u)) return false;
+            if ((bits >> (2u + b)) & 1u) { r.tmax = RT_TMAX_SKIPPED; return false; }
+            r.tmin = RAY_EPSILON;
+            const LightRays *per_frame = BATCH ? frame_lights : nullptr;
+            if (per_frame) {                                 // (three floats by hand: a struct copy ends up in scratch memory)
+                const float *fl = b == 0u ? per_frame[(bits >> 8) & 0xffu].dir_to_light : per_frame[(bits >> 8) & 0xffu].point_pos;
+                const f3 l = mk3(fl[0], fl[1], fl[2]);
+                if (b == 0u) { r.d = l; r.tmax = RAY_MAX_T; }
+                else {
+                    const f3 path = l - r.o;
+                    const float dist = length(path);
+                    r.d = normalize(path);
+                    r.tmax = dist - fmaxf(RAY_EPSILON, fl[3]);       // (fl[3]: point_free of that frame's lights)
+                }
+                return r.tmax > r.tmin;
+            }
+            if (b == 0u) {
+                r.d = mk3(lights.dir_to_light[0], lights.dir_to_light[1], lights.dir_to_light[2]);
+                r.tmax = RAY_MAX_T;
+            } else {
+                const f3 path = mk3(lights.point_pos[0], lights.point_pos[1], lights.point_pos[2]) - r.o;
+                const float dist = length(path);
+                r.d = normalize(path);
+                r.tmax = dist - fmaxf(RAY_EPSILON, lights.point_free);
+            }
+            return r.tmax > r.tmin;
+        }
+        const v4f a = ldg16(O, (size_t)ticket * 16), d = ldg16(D, (size_t)ticket * 16);
+        r.o = mk3(a.x, a.y, a.z); r.tmin = a.w;
+        r.d = mk3(d.x, d.y, d.z); r.tmax = d.w;
+        return r.tmax > r.tmin;
     }
     // ---- the shadow cache (ShadowCacheDev): where this ray's entry lives, what it holds, what to put there ----
     RT_DEV uint32_t cache_slot(const RayD &r) const
@@ -430,26 +425,16 @@ struct ShadowSrcN : ShadowQueues {
     }
 };
 struct ShadowSinkN {      // ShadowMiss sets visibility 1 (ProgressiveRaytracing.hlsl:178-182)
-    ShadowQueues s;
-    RT_DEV void store(uint32_t i, const HitD &h, bool) const
-    {
-#pragma unroll
-        for (int k = 0; k <= MAXD; k++) {
-            if (k < s.nq) {
-                const uint32_t c = s.q[k].count();
-                if (i < c) { s.vis[k][s.q[k].slot(i)] = h.inst == RT_NO_HIT ? 1u : 0u; return; }
-                i -= c;
-            }
-        }
-    }
+    ShadowQueue s;
+    RT_DEV void store(uint32_t ticket, const HitD &h, bool) const { if (ticket != RT_NO_HIT) s.vis[ticket] = h.inst == RT_NO_HIT ? 1u : 0u; }
 };
 
 template <int STACK, bool TWO_LEVEL, bool BATCH>
-__global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_trace_shadow(SceneDev sc, ShadowQueues queues, uint32_t *pool, uint32_t *stat)
+__global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_trace_shadow(SceneDev sc, ShadowQueue queues, uint32_t *pool, uint32_t *stat)
 {
     __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     ShadowSrcN<BATCH> src;
-    static_cast<ShadowQueues &>(src) = queues;
+    static_cast<ShadowQueue &>(src) = queues;
     ShadowSinkN sink = {queues};
     trace_wave<STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK, RT_SHADOW_UNORDERED != 0>(sc, src, sink, pool, smem, stat);
 }
@@ -482,9 +467,11 @@ __global__ void __launch_bounds__(PBLOCK) k_walk_queue(SceneDev sc, QueueSrc src
     trace_wave<RT_LDS_STACK_ROWS, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK, false, true>(sc, src, sink, nullptr, smem, nullptr, walk);
 }
 template <bool TWO_LEVEL>
-__global__ void __launch_bounds__(PBLOCK) k_walk_shadow(SceneDev sc, LitQueueSrc src, unsigned long long *walk)
+__global__ void __launch_bounds__(PBLOCK) k_walk_shadow(SceneDev sc, ShadowQueue queue, unsigned long long *walk)
 {
     __shared__ int smem[(RT_LDS_STACK_ROWS + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
+    ShadowSrcN<true> src;
+    static_cast<ShadowQueue &>(src) = queue;
     NullSink sink;
     trace_wave<RT_LDS_STACK_ROWS, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK, RT_SHADOW_UNORDERED != 0, true>(sc, src, sink, nullptr, smem, nullptr, walk);
 }
@@ -599,19 +586,18 @@ RT_DEV void wave_add64(unsigned long long v, unsigned long long *counter)
 }
 
 // canonical-order re-trace of a queue: sums rays / nodes / triangles into out[0..2]
+template <class Src>
 __global__ void __launch_bounds__(PBLOCK)
-k_count_queue(SceneDev sc, LitQueueSrc src, unsigned long long *__restrict__ out)
+k_count_queue(SceneDev sc, Src src, unsigned long long *__restrict__ out)
 {
-    const uint32_t n = src.n();
     const uint32_t idx = blockIdx.x * PBLOCK + threadIdx.x;
-    const uint32_t per = (n + PBLOCK - 1) / PBLOCK * PBLOCK;
-    const uint32_t b = per ? idx / per : src.q.batches, k = per ? idx % per : 0;
     unsigned long long rays = 0, nodes = 0, tris = 0;
-    if (b < src.q.batches && k < n) {
+    if (idx < src.count()) {
         RayD r;
-        if (src.load(b * n + k, r)) {
+        uint32_t ticket;
+        if (load_ray_of(src, idx, r, ticket, 0)) {
             uint32_t cn, ct;
-            (void)trace_canonical(sc, r, src.q.fl, cn, ct);
+            (void)trace_canonical(sc, r, src.flags(), cn, ct);
             rays = 1; nodes = cn; tris = ct;
         }
     }
@@ -808,7 +794,7 @@ int prepare_shadow_cache(rt_pipeline *p, const rt_per_frame_constants &pfc, cons
 // ---- queue memory ------------------------------------------------------------------------------------------------------
 // Level l keeps, per RAY slot (l = 0: per pixel slot; no ray is stored there), the ray (32 B + 4 B pixel slot), its hit record
 // (16 + 4 B) and the two compaction maps (4 + 4 B); per HIT of the level its shadow rays -- compact form: ONE float4 per hit +
-// 4 B of visibility per shadow ray; explicit form (the ambient-occlusion view): 32 B per shadow ray -- and, for paths of more
+// 4 B of visibility per shadow ray; explicit form (the ambient-occlusion view): 36 B per shadow ray; all levels in ONE queue -- and, for paths of more
 // than one bounce, 16 B of colour per ray slot.  How many slots a level needs is only known once the level before has been
 // compacted: the worst case is 2 rays per pixel at level 1 and as many rays as slots at every deeper level, 228 B per pixel and
 // frame for the reference's depth limits and 884 B with four bounces -- times up to 32 frames per set of launches.  So:
@@ -835,23 +821,41 @@ int reserve_level_rays(rt_pipeline *p, uint32_t l, size_t slots, bool deep)
     if (l > 0 && deep) RT_TRY(grow(b.color, slots * 16));          // deep paths only (k_shade_level)
     return RT_OK;
 }
-// shadow queue of level l for `hits` hits with `shadow_slots` rays each
-int reserve_level_shadows(rt_pipeline *p, uint32_t l, size_t hits, uint32_t shadow_slots, bool compact)
+// the shared shadow queue for `hits` hits (of all levels together) with 1 << log2 rays each; the first `keep` hits' entries
+// survive a growth (counted queues: earlier levels have written theirs when a later level turns out to need more room)
+int grow_keep(DevBuf &b, size_t bytes, size_t keep_bytes, hipStream_t st)
 {
-    rt_pipeline::LevelBuf &b = p->lv[l];
-    if (compact) RT_TRY(grow(b.shO, hits * 16));
-    else { RT_TRY(grow(b.shO, hits * shadow_slots * 16)); RT_TRY(grow(b.shD, hits * shadow_slots * 16)); }
-    return grow(b.vis, hits * shadow_slots * 4);
+    if (bytes <= b.bytes) return RT_OK;
+    DevBuf bigger;
+    RT_TRY(bigger.reserve(bytes + bytes / 8));
+    if (keep_bytes && b.p) {
+        if (hipMemcpyAsync(bigger.p, b.p, keep_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            rt_set_error("shadow queue: copy into the grown buffer failed: %s", hipGetErrorString(hipGetLastError()));
+            bigger.release();
+            return RT_ERR_HIP;
+        }
+    }
+    b.release();
+    b = bigger;
+    return RT_OK;
 }
+int reserve_shadows(rt_pipeline *p, size_t hits, uint32_t log2, bool compact, size_t keep_hits)
+{
+    hipStream_t st = p->ctx->stream;
+    if (compact) RT_TRY(grow_keep(p->sh_hits, hits * 16, keep_hits * 16, st));
+    else { RT_TRY(grow_keep(p->sh_O, (hits << log2) * 16, (keep_hits << log2) * 16, st)); RT_TRY(grow_keep(p->sh_D, (hits << log2) * 16, (keep_hits << log2) * 16, st)); }
+    return grow_keep(p->sh_vis, (hits << log2) * 4, 0, st);         // (results: nothing is in there before the shadow launch)
+}
+// levels 0 .. n - 1 cast shadow rays: level 0 always has its entries (their masks are empty when no shadow ray is allowed at all)
+inline uint32_t shadow_levels(uint32_t levels, uint32_t max_shadow) { return 1u + (max_shadow > 1u ? (levels < max_shadow - 1u ? levels : max_shadow - 1u) : 0u); }
 inline size_t level_ray_bytes(uint32_t l, bool deep) { return (l > 0 ? 36u : 0u) + 28u + (l > 0 && deep ? 16u : 0u); }
 inline size_t level_shadow_bytes(uint32_t shadow_slots, bool compact) { return compact ? 16u + 4u * shadow_slots : 36u * shadow_slots; }
 size_t worst_case_queue_bytes(size_t cap, uint32_t levels, uint32_t max_shadow, uint32_t shadow_slots0, bool compact)
 {
     const bool deep = levels > 1;
-    size_t total = cap * (level_ray_bytes(0, deep) + level_shadow_bytes(shadow_slots0, compact));
-    for (uint32_t l = 1; l <= levels; l++)
-        total += 2 * cap * (level_ray_bytes(l, deep) + (l < max_shadow ? level_shadow_bytes(2, compact) : 0));
-    return total;
+    size_t total = cap * level_ray_bytes(0, deep);
+    for (uint32_t l = 1; l <= levels; l++) total += 2 * cap * level_ray_bytes(l, deep);
+    return total + (cap + 2 * cap * (shadow_levels(levels, max_shadow) - 1u)) * level_shadow_bytes(shadow_slots0, compact);
 }
 size_t queue_budget(rt_pipeline *p)
 {
@@ -870,12 +874,8 @@ int reserve_worst_case(rt_pipeline *p, size_t cap, uint32_t levels, uint32_t max
 {
     const bool deep = levels > 1;
     RT_TRY(reserve_level_rays(p, 0, cap, deep));
-    RT_TRY(reserve_level_shadows(p, 0, cap, shadow_slots0, compact));
-    for (uint32_t l = 1; l <= levels; l++) {
-        RT_TRY(reserve_level_rays(p, l, 2 * cap, deep));
-        if (l < max_shadow) RT_TRY(reserve_level_shadows(p, l, 2 * cap, 2, compact));
-    }
-    return RT_OK;
+    for (uint32_t l = 1; l <= levels; l++) RT_TRY(reserve_level_rays(p, l, 2 * cap, deep));
+    return reserve_shadows(p, cap + 2 * cap * (shadow_levels(levels, max_shadow) - 1u), shadow_slots0 > 2u ? 2u : 1u, compact, 0);
 }
 void bind_level(const rt_pipeline *p, PipeDev &pd, int l)
 {
@@ -883,7 +883,8 @@ void bind_level(const rt_pipeline *p, PipeDev &pd, int l)
     LevelDev &d = pd.lv[l];
     d.O = b.O.as<float4>(); d.D = b.D.as<float4>(); d.hit = b.hit.as<float4>(); d.inst = b.inst.as<uint32_t>();
     d.slot_j = b.slot_j.as<uint32_t>(); d.jlist = b.jlist.as<uint32_t>(); d.pix = b.pix.as<uint32_t>();
-    d.shO = b.shO.as<float4>(); d.shD = b.shD.as<float4>(); d.vis = b.vis.as<uint32_t>(); d.color = b.color.as<float4>();
+    d.color = b.color.as<float4>();
+    pd.sh_hits = p->sh_hits.as<float4>(); pd.sh_O = p->sh_O.as<float4>(); pd.sh_D = p->sh_D.as<float4>(); pd.sh_vis = p->sh_vis.as<uint32_t>();
 }
 
 // radiance levels a frame traces: level l exists when hits of depth l-1 may spawn rays
@@ -909,6 +910,7 @@ int launch_frame(rt_pipeline *p, PipeDev &pd, uint32_t shadow_slots, bool counte
     // counted queues: the hits the compaction of level l has just produced -> the shadow queue of level l and the ray queue of
     // level l + 1 get their sizes; `slots` = ray slots of the level whose launches come next (level 1: two batches)
     size_t hits_l = cap, slots = cap;
+    size_t sh_total = 0;                        // entries of the shared shadow queue taken by the levels sized so far
     auto size_next = [&](uint32_t l, bool casts_shadows, bool spawns) -> int {
         if (counted) {
             HIP_TRY(hipMemcpyAsync(ctx->pinned, &pd.counters[C_NHIT + l], 4, hipMemcpyDeviceToHost, st));
@@ -918,7 +920,12 @@ int launch_frame(rt_pipeline *p, PipeDev &pd, uint32_t shadow_slots, bool counte
         } else hits_l = l == 0 ? (size_t)cap : 2 * (size_t)cap;
         if (hits_l > 0xffffffc0ull / 2) { rt_set_error("render: more than 2^31 hits at radiance level %u", l); return RT_ERR_UNSUPPORTED; }
         pd.lv[l].hstride = (uint32_t)hits_l;
-        if (counted && casts_shadows) RT_TRY(reserve_level_shadows(p, l, hits_l, l == 0 ? shadow_slots : 2u, compact));
+        if (casts_shadows) {
+            if (((sh_total + hits_l) << pd.sh_log2) >= 0xffffffc0ull) { rt_set_error("render: more than 2^32 shadow rays in one set of launches"); return RT_ERR_UNSUPPORTED; }
+            if (counted) RT_TRY(reserve_shadows(p, sh_total + hits_l, pd.sh_log2, compact, sh_total));
+            pd.sh_cbase[l] = (uint32_t)sh_total;
+            sh_total += hits_l;
+        }
         bind_level(p, pd, (int)l);
         if (spawns) {
             slots = (l == 0 ? 2 : 1) * hits_l;
@@ -939,57 +946,39 @@ int launch_frame(rt_pipeline *p, PipeDev &pd, uint32_t shadow_slots, bool counte
     if (B) k_shade_emit<true, true><<<blocks(hits_l), PBLOCK, 0, st>>>(pd, 0, shadow_slots, levels >= 1 ? 1u : 0u);
     else k_shade_emit<true, false><<<blocks(hits_l), PBLOCK, 0, st>>>(pd, 0, shadow_slots, levels >= 1 ? 1u : 0u);
     if (T) record(ev[2], st);
-    ShadowQueues shadows;
-    memset(&shadows, 0, sizeof shadows);
-    const LightRays lr = light_rays(pd), none = no_light_rays();
-    const LightRays *fl = B ? pd.frame_lights : nullptr;
-    shadows.frame_lights = fl;
-    shadows.cache = p->shadow_cache_dev;
-    shadows.lights = lr;
-    shadows.q[0] = RayQueue{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], pd.lv[0].hstride, shadow_slots, any};     // RaytracingCommon.hlsli:94
-    shadows.vis[0] = pd.lv[0].vis;
-    shadows.nq = 1;
-    size_t shadow_max = hits_l * shadow_slots;
-    auto trace_shadows = [&](const ShadowQueues &sq, size_t rays_max, uint32_t *pool, hipStream_t s) {
-        if (B) k_trace_shadow<STACK, TWO_LEVEL, true><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL, true>, PBLOCK, rays_max), PBLOCK, 0, s>>>(
-            pd.sc, sq, pool, &pd.counters[C_SHADOW]);
-        else k_trace_shadow<STACK, TWO_LEVEL, false><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL, false>, PBLOCK, rays_max), PBLOCK, 0, s>>>(
-            pd.sc, sq, pool, &pd.counters[C_SHADOW]);
-    };
-    // (RT_OVERLAP_SHADOW0=1, off by default and measured no faster: the shadow rays of the primary hits on a second stream beside
-    // the secondary launch)
-    const bool early = p->overlap_shadow0 > 0 && levels >= 1 && p->side != nullptr && !counted;
-    if (early) {
-        record(p->ev_fork, st);
-        if (hipStreamWaitEvent(p->side, p->ev_fork, 0) != hipSuccess && first_error == hipSuccess) first_error = hipErrorUnknown;
-        trace_shadows(shadows, shadow_max, pd.pools + (size_t)(1 + MAXD) * RT_POOL_GROUPS * RT_POOL_STRIDE, p->side);
-        record(p->ev_join, p->side);
-        shadows.nq = 0;
-        shadow_max = 0;
-    }
+    const LightRays lr = light_rays(pd);
     for (uint32_t l = 1; l <= levels; l++) {
         // level 1: the diffuse and the specular batch of the primary hits; deeper: one ray per hit of level l-1
-        const QueueSrc rays = {{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], pd.lv[1].rstride, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE}, none};   // ProgressiveRaytracing.hlsl:53
+        const QueueSrc rays = {pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], pd.lv[1].rstride, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE};   // ProgressiveRaytracing.hlsl:53
         k_trace_secondary<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_trace_secondary<STACK, TWO_LEVEL>, PBLOCK, slots), PBLOCK, 0, st>>>(
             pd.sc, rays, pd.lv[l].hit, pd.lv[l].inst, pd.pools + (size_t)l * RT_POOL_GROUPS * RT_POOL_STRIDE, &pd.counters[C_SECONDARY]);
         k_compact_level<<<(unsigned)((slots + CTILES * CBLOCK - 1) / (CTILES * CBLOCK)), CBLOCK, 0, st>>>(pd, (int)l);
         if (T) record(ev[3 + 2 * (l - 1)], st);
-        const bool casts_shadows = l < pd.max_shadow, spawns = l < levels;
+        const bool casts_shadows = l < pd.sh_levels, spawns = l < levels;
         RT_TRY(size_next(l, casts_shadows, spawns));
         if (casts_shadows || spawns) {
             if (B) k_shade_emit<false, true><<<blocks(hits_l), PBLOCK, 0, st>>>(pd, (int)l, 2u, spawns ? 1u : 0u);
             else k_shade_emit<false, false><<<blocks(hits_l), PBLOCK, 0, st>>>(pd, (int)l, 2u, spawns ? 1u : 0u);
         }
         if (T) record(ev[4 + 2 * (l - 1)], st);
-        if (casts_shadows) {
-            shadows.q[shadows.nq] = RayQueue{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], pd.lv[l].hstride, 2u, any};
-            shadows.vis[shadows.nq] = pd.lv[l].vis;
-            shadows.nq++;
-            shadow_max += hits_l * 2;
-        }
     }
-    if (shadows.nq > 0) trace_shadows(shadows, shadow_max, pd.pools, st);
-    if (early && hipStreamWaitEvent(st, p->ev_join, 0) != hipSuccess && first_error == hipSuccess) first_error = hipErrorUnknown;
+    {   // every shadow ray of the frame (or set) in ONE persistent any-hit launch over the shared queue
+        ShadowQueue sq;
+        memset(&sq, 0, sizeof sq);
+        sq.hits = pd.sh_hits; sq.O = pd.sh_O; sq.D = pd.sh_D; sq.vis = pd.sh_vis;
+        sq.nhit = &pd.counters[C_NHIT];
+        sq.log2 = pd.sh_log2; sq.fl = any;                                   // RaytracingCommon.hlsli:94
+        sq.lv_first = 0; sq.lv_count = pd.sh_levels;
+        for (int k = 0; k <= MAXD; k++) { sq.cbase[k] = pd.sh_cbase[k]; sq.hstride[k] = pd.lv[k].hstride; }
+        sq.lights = lr;
+        sq.frame_lights = B ? pd.frame_lights : nullptr;
+        sq.cache = p->shadow_cache_dev;
+        const size_t rays_max = sh_total << pd.sh_log2;
+        if (B) k_trace_shadow<STACK, TWO_LEVEL, true><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL, true>, PBLOCK, rays_max), PBLOCK, 0, st>>>(
+            pd.sc, sq, pd.pools, &pd.counters[C_SHADOW]);
+        else k_trace_shadow<STACK, TWO_LEVEL, false><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL, false>, PBLOCK, rays_max), PBLOCK, 0, st>>>(
+            pd.sc, sq, pd.pools, &pd.counters[C_SHADOW]);
+    }
     if (T) record(ev[EV_SHADOW], st);
     // (resolve: one thread per pixel slot of ONE frame; a batch's frames are accumulated in order inside the thread)
     if (levels <= 1) {                          // (level by level is slower here: 0.143 vs 0.118 ms at 1080p)
@@ -1021,20 +1010,28 @@ static int count_walk_launch(rt_pipeline *p, unsigned long long *w)
     hipStream_t st = p->ctx->stream;
     const rt_context *ctx = p->ctx;
     const PipeDev &pd = p->last_pd;
-    const uint32_t cap = pd.cap, ss = p->last_shadow_slots;
+    const uint32_t cap = pd.cap;
     const uint32_t any = RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH | RT_RAY_FLAG_SKIP_CLOSEST_HIT_SHADER;
     k_walk_primary<TWO_LEVEL><<<rt_persistent_grid(ctx, k_walk_primary<TWO_LEVEL>, PBLOCK, cap), PBLOCK, 0, st>>>(pd, w + RT_WALK_WORDS * RT_STAGE_PRIMARY);
     const unsigned gq = rt_persistent_grid(ctx, k_walk_queue<TWO_LEVEL>, PBLOCK, (size_t)cap * 2);
     const unsigned gs = rt_persistent_grid(ctx, k_walk_shadow<TWO_LEVEL>, PBLOCK, (size_t)cap * 2);
-    const LightRays lr = light_rays(pd), none = no_light_rays();
-    const LightRays *fl = pd.n_frames > 1u ? pd.frame_lights : nullptr;
-    k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], pd.lv[0].hstride, ss, any}, lr}, fl}, w + RT_WALK_WORDS * RT_STAGE_SHADOW0);
+    ShadowQueue sq;
+    memset(&sq, 0, sizeof sq);
+    sq.hits = pd.sh_hits; sq.O = pd.sh_O; sq.D = pd.sh_D; sq.vis = pd.sh_vis;
+    sq.nhit = &pd.counters[C_NHIT];
+    sq.log2 = pd.sh_log2; sq.fl = any;
+    sq.lights = light_rays(pd);
+    sq.frame_lights = pd.n_frames > 1u ? pd.frame_lights : nullptr;
+    for (int k = 0; k <= MAXD; k++) { sq.cbase[k] = pd.sh_cbase[k]; sq.hstride[k] = pd.lv[k].hstride; }
+    sq.lv_first = 0; sq.lv_count = 1;                       // the shadow rays of the primary hits ...
+    k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, sq, w + RT_WALK_WORDS * RT_STAGE_SHADOW0);
     const uint32_t levels = pd.max_rad < (uint32_t)MAXD ? pd.max_rad : (uint32_t)MAXD;
-    for (uint32_t l = 1; l <= levels; l++) {
-        k_walk_queue<TWO_LEVEL><<<gq, PBLOCK, 0, st>>>(pd.sc, QueueSrc{{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], pd.lv[1].rstride, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE}, none},
+    for (uint32_t l = 1; l <= levels; l++)
+        k_walk_queue<TWO_LEVEL><<<gq, PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], pd.lv[1].rstride, l == 1 ? 2u : 1u, RT_RAY_FLAG_NONE},
                                                        w + RT_WALK_WORDS * RT_STAGE_SECONDARY);
-        if (l < pd.max_shadow)
-            k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], pd.lv[l].hstride, 2u, any}, lr}, fl}, w + RT_WALK_WORDS * RT_STAGE_SHADOW1);
+    if (pd.sh_levels > 1u) {                                // ... and of all deeper hits
+        sq.lv_first = 1; sq.lv_count = pd.sh_levels - 1u;
+        k_walk_shadow<TWO_LEVEL><<<gs, PBLOCK, 0, st>>>(pd.sc, sq, w + RT_WALK_WORDS * RT_STAGE_SHADOW1);
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -1141,6 +1138,9 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     }
     pd.n_pixels = tw * owned_rows;                  // (per frame)
     pd.max_rad = p->max_rad; pd.max_shadow = p->max_shadow;
+    pd.sh_log2 = ao_view ? 2u : 1u;
+    pd.sh_levels = shadow_levels(levels_now, p->max_shadow);
+    for (int k = 0; k <= MAXD; k++) pd.sh_cbase[k] = 0;
     pd.accum_mode = p->accum_mode;
     pd.skip_unlit = p->skip_unlit;
     pd.kind = p->kind;
@@ -1156,15 +1156,6 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     static_assert(C_COUNT <= POOL_OFFSET_WORDS, "scalar counters overlap the chunk pools");
     pd.pools = pd.counters + POOL_OFFSET_WORDS;
     pd.totals = p->totals.as<unsigned long long>();
-    if (p->overlap_shadow0 < 0) {
-        const char *e = getenv("RT_OVERLAP_SHADOW0");
-        p->overlap_shadow0 = e ? (atoi(e) != 0 ? 1 : 0) : RT_OVERLAP_SHADOW0_DEFAULT;
-    }
-    if (p->overlap_shadow0 > 0 && p->side == nullptr) {
-        HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-    }
     // 18 LDS stack rows + the 8-row top table = 26 KiB per 256-thread block = 6 resident blocks per CU, whatever
     // the depth of the tree; the rare deeper walk continues in global rows (rt_trace_wave.h)
     int launched;
@@ -1335,9 +1326,9 @@ int rt_pipeline_set_queue_budget(rt_pipeline *p, size_t bytes)
 int rt_pipeline_get_queue_memory(rt_pipeline *p, size_t *bytes_reserved, uint32_t *sized_by_count)
 {
     RT_REQUIRE(p, "null pipeline");
-    size_t total = p->counters.bytes + p->batch_consts.bytes;
+    size_t total = p->counters.bytes + p->batch_consts.bytes + p->sh_hits.bytes + p->sh_O.bytes + p->sh_D.bytes + p->sh_vis.bytes;
     for (const rt_pipeline::LevelBuf &l : p->lv) {
-        const DevBuf *lb[] = {&l.O, &l.D, &l.hit, &l.inst, &l.slot_j, &l.jlist, &l.pix, &l.shO, &l.shD, &l.vis, &l.color};
+        const DevBuf *lb[] = {&l.O, &l.D, &l.hit, &l.inst, &l.slot_j, &l.jlist, &l.pix, &l.color};
         for (const DevBuf *b : lb) total += b->bytes;
     }
     if (bytes_reserved) *bytes_reserved = total;
@@ -1392,21 +1383,31 @@ int rt_pipeline_count_work(rt_pipeline *p, rt_stage_work *out)
     HIP_TRY(hipMemsetAsync(p->work.p, 0, RT_STAGE_COUNT * 3 * sizeof(unsigned long long), st));
     unsigned long long *w = p->work.as<unsigned long long>();
     const PipeDev &pd = p->last_pd;
-    const uint32_t cap = pd.cap, ss = p->last_shadow_slots;
+    const uint32_t cap = pd.cap;
     const uint32_t any = RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH | RT_RAY_FLAG_SKIP_CLOSEST_HIT_SHADER;
     k_count_primary<<<blocks(cap), PBLOCK, 0, st>>>(pd, w + 3 * RT_STAGE_PRIMARY);
-    const LightRays lr = light_rays(pd), none = no_light_rays();
-    const LightRays *fl = pd.n_frames > 1u ? pd.frame_lights : nullptr;
-    k_count_queue<<<(blocks(cap) + 1) * ss, PBLOCK, 0, st>>>(pd.sc, LitQueueSrc{QueueSrc{{pd.lv[0].shO, pd.lv[0].shD, &pd.counters[C_NHIT], pd.lv[0].hstride, ss, any}, lr}, fl},
-                                                             w + 3 * RT_STAGE_SHADOW0);
+    ShadowSrcN<true> sq;
+    memset(&sq, 0, sizeof sq);
+    sq.hits = pd.sh_hits; sq.O = pd.sh_O; sq.D = pd.sh_D; sq.vis = pd.sh_vis;
+    sq.nhit = &pd.counters[C_NHIT];
+    sq.log2 = pd.sh_log2; sq.fl = any;
+    sq.lights = light_rays(pd);
+    sq.frame_lights = pd.n_frames > 1u ? pd.frame_lights : nullptr;
+    for (int k = 0; k <= MAXD; k++) { sq.cbase[k] = pd.sh_cbase[k]; sq.hstride[k] = pd.lv[k].hstride; }
+    sq.lv_first = 0; sq.lv_count = 1;
+    k_count_queue<<<blocks((size_t)pd.lv[0].hstride << pd.sh_log2), PBLOCK, 0, st>>>(pd.sc, sq, w + 3 * RT_STAGE_SHADOW0);
     const uint32_t levels = pd.max_rad < (uint32_t)MAXD ? pd.max_rad : (uint32_t)MAXD;
-    for (uint32_t l = 1; l <= levels; l++) {        // every secondary level adds into the same two rows
+    size_t deeper = 0;
+    for (uint32_t l = 1; l <= levels; l++) {        // every secondary level adds into the same row
         const uint32_t batches = l == 1 ? 2u : 1u;
-        k_count_queue<<<(blocks((size_t)cap * 2) + 1) * batches, PBLOCK, 0, st>>>(
-            pd.sc, LitQueueSrc{QueueSrc{{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], pd.lv[1].rstride, batches, RT_RAY_FLAG_NONE}, none}, nullptr}, w + 3 * RT_STAGE_SECONDARY);
-        if (l < pd.max_shadow)
-            k_count_queue<<<(blocks((size_t)cap * 2) + 1) * 2, PBLOCK, 0, st>>>(
-                pd.sc, LitQueueSrc{QueueSrc{{pd.lv[l].shO, pd.lv[l].shD, &pd.counters[C_NHIT + l], pd.lv[l].hstride, 2, any}, lr}, fl}, w + 3 * RT_STAGE_SHADOW1);
+        const size_t slots = l == 1 ? 2 * (size_t)pd.lv[1].rstride : (size_t)pd.lv[l - 1].hstride;
+        k_count_queue<<<blocks(slots), PBLOCK, 0, st>>>(pd.sc, QueueSrc{pd.lv[l].O, pd.lv[l].D, &pd.counters[C_NHIT + l - 1], pd.lv[1].rstride, batches, RT_RAY_FLAG_NONE},
+                                                        w + 3 * RT_STAGE_SECONDARY);
+        if (l < pd.sh_levels) deeper += pd.lv[l].hstride;
+    }
+    if (pd.sh_levels > 1u) {
+        sq.lv_first = 1; sq.lv_count = pd.sh_levels - 1u;
+        k_count_queue<<<blocks(deeper << pd.sh_log2), PBLOCK, 0, st>>>(pd.sc, sq, w + 3 * RT_STAGE_SHADOW1);
     }
     HIP_TRY(hipGetLastError());
     unsigned long long h[RT_STAGE_COUNT * 3];

@@ -41,18 +41,17 @@ enum { C_NHIT = 0,                       // [0..MAXD] compacted hits per level
 // records, the compaction of the hits, and the shadow-ray queue of those hits.
 //   slots of level 1: w*rstride + k  (w = 0 diffuse / 1 specular batch, k = compact index of the primary hit)
 //   slots of level L >= 2: j     (compact index of the level L-1 hit that spawned the ray)
-//   shadow queue of level L: s*hstride + idx, idx = compact hit index
 // The strides are the capacities the level's buffers were sized for: the worst case (rstride = hstride(0) = cap pixel slots,
 // hstride(L >= 1) = 2 cap) or, for sets of frames whose worst case would not fit the device, the counts the compaction of the
 // level before has just produced (launch_frame, "counted" queues).
+// The SHADOW rays of all levels share one queue (PipeDev::sh_*, round 4).
 struct LevelDev {
     uint32_t rstride;           // level 1: slots between its two batches (>= the hits of level 0); other levels: unused
-    uint32_t hstride;           // slots between the shadow batches of this level (>= its hits)
+    uint32_t hstride;           // hits this level's buffers have room for (host side: grids, the shared shadow queue's size)
     float4 *O, *D;              // ray queue (unused at level 0)
     float4 *hit; uint32_t *inst;   // hit records, indexed by slot (level 0: by pixel slot q)
     uint32_t *slot_j, *jlist;   // slot -> compact hit index (RT_NO_HIT if none), compact index -> slot
     uint32_t *pix;              // slot -> pixel slot q (unused at level 0)
-    float4 *shO, *shD; uint32_t *vis;
     float4 *color;              // deep paths (more than one radiance level): the shaded colour of every hit of this level, by slot
 };
 
@@ -113,17 +112,34 @@ struct PipeDev {
     uint32_t *counters;
     unsigned long long *totals;         // running sums over frames (rt_pipeline_get_totals); updated by the frame's last kernel
     float point_free;           // LightRays::point_free of pfc's point light
-    uint32_t *pools;            // chunk counters of the persistent launches: [2 + MAXD][RT_POOL_GROUPS], 128 B apart
+    // ONE shadow queue for the hits of every level (round 4; before: a queue per level, five loaders and five sinks unrolled into
+    // the any-hit kernel, a division and a remainder per ray loaded and per result stored, and so many kernel arguments that the
+    // scalar registers spilled into vector lanes: the any-hit stage -15 % in sets of frames, -24 % frame by frame).
+    // Storage: level L's hits take the entries sh_cbase[L] + idx (idx = compact hit index; sh_cbase = the room of the levels
+    // before it, lv[].hstride each: host constants, so the shading passes address their entries without reading a counter);
+    // shadow ray s of that hit is ray number (sh_cbase[L] << sh_log2) + s * lv[L].hstride + idx -- per level all rays to the
+    // directional light, then all rays to the point light: 64-ray chunks hold one kind of ray of consecutive hits.
+    //   compact form (both light rays start at the hit point and are rebuilt by the loader): sh_hits[entry] = point + bits
+    //   explicit form (the ambient-occlusion view's four random rays): sh_O / sh_D [ray number]
+    //   results: sh_vis[ray number]
+    // The any-hit launch enumerates only what is there (ShadowSrcN::load: round64(hits) rays per kind and level).
+    float4 *sh_hits, *sh_O, *sh_D;
+    uint32_t *sh_vis;
+    uint32_t sh_log2;           // log2 of the shadow rays per hit: 1 (the two lights) or 2 (the ambient-occlusion view)
+    uint32_t sh_levels;         // levels 0 .. sh_levels - 1 cast shadow rays (level 0 always has its entries)
+    uint32_t sh_cbase[MAXD + 1];
+    uint32_t *pools;            // chunk counters of the persistent launches: [1 + MAXD][RT_POOL_GROUPS], 128 B apart
     LevelDev lv[MAXD + 1];
 };
 
-constexpr size_t POOL_BYTES = (size_t)(2 + MAXD) * RT_POOL_GROUPS * RT_POOL_STRIDE * 4;      // shadow launch, levels 1..MAXD, early shadow launch
-#ifndef RT_OVERLAP_SHADOW0_DEFAULT
-#define RT_OVERLAP_SHADOW0_DEFAULT 0
-#endif
+constexpr size_t POOL_BYTES = (size_t)(1 + MAXD) * RT_POOL_GROUPS * RT_POOL_STRIDE * 4;      // shadow launch, levels 1..MAXD
 constexpr size_t POOL_OFFSET_WORDS = 64;      // the pools start on a 256-B boundary after the scalar counters
 
-RT_DEV uint32_t hcap(const PipeDev &pd, int L) { return pd.lv[L].hstride; }
+// ray number of shadow ray s of hit idx of level L (storage order: see PipeDev::sh_*)
+RT_DEV size_t sh_ray(const PipeDev &pd, int L, uint32_t idx, uint32_t s)
+{
+    return ((size_t)pd.sh_cbase[L] << pd.sh_log2) + (size_t)s * pd.lv[L].hstride + idx;
+}
 
 inline unsigned blocks(size_t n) { return (unsigned)((n + PBLOCK - 1) / PBLOCK); }
 
@@ -162,7 +178,8 @@ struct rt_pipeline {
     // what they produce.  Bit for bit the image of immediate rendering (rt_pipeline_render_batch's guarantee).
     uint32_t deferred_max = 0;         // 0 / 1: render() renders
     std::vector<rt_per_frame_constants> pending;
-    struct LevelBuf { DevBuf O, D, hit, inst, slot_j, jlist, pix, shO, shD, vis, color; } lv[MAXD + 1];
+    struct LevelBuf { DevBuf O, D, hit, inst, slot_j, jlist, pix, color; } lv[MAXD + 1];
+    DevBuf sh_hits, sh_O, sh_D, sh_vis;      // the shared shadow queue (PipeDev::sh_*)
     DevBuf counters;
     DevBuf half_out;
     std::vector<hipEvent_t> ring;      // EV_COUNT events per remembered frame
@@ -188,11 +205,6 @@ struct rt_pipeline {
         float asked_size = 0.0f;           // the largest coordinate of the scene's bounds when the pass was queued
         bool in_flight = false;
     } free_sphere;
-    // the shadow rays of the primary hits are traced beside the secondary rays (launch_frame): a second stream and the fork /
-    // join events of that launch
-    int overlap_shadow0 = -1;          // -1: not decided yet (RT_OVERLAP_SHADOW0)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint64_t ring_pos = 0;             // frames recorded since enable / reset
     DevBuf totals, work;
     PipeDev last_pd;

@@ -54,17 +54,14 @@ int rt_pipeline_destroy(rt_pipeline *p)
     }
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    DevBuf *all[] = {&p->d_mats, &p->d_env, &p->accum_own, &p->aov_own, &p->counters, &p->half_out, &p->totals, &p->work, &p->batch_consts, &p->shadow_cache};
+    DevBuf *all[] = {&p->d_mats, &p->d_env, &p->accum_own, &p->aov_own, &p->counters, &p->half_out, &p->totals, &p->work, &p->batch_consts, &p->shadow_cache,
+                     &p->sh_hits, &p->sh_O, &p->sh_D, &p->sh_vis};
     for (DevBuf *b : all) b->release();
     for (rt_pipeline::LevelBuf &l : p->lv) {
-        DevBuf *lb[] = {&l.O, &l.D, &l.hit, &l.inst, &l.slot_j, &l.jlist, &l.pix, &l.shO, &l.shD, &l.vis, &l.color};
+        DevBuf *lb[] = {&l.O, &l.D, &l.hit, &l.inst, &l.slot_j, &l.jlist, &l.pix, &l.color};
         for (DevBuf *b : lb) b->release();
     }
     for (hipEvent_t e : p->ring) if (e) (void)hipEventDestroy(e);
-    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
-    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
-    if (p->side) (void)hipStreamDestroy(p->side);
-    p->ev_fork = p->ev_join = nullptr; p->side = nullptr;
     if (p->free_sphere.landed) (void)hipEventDestroy(p->free_sphere.landed);
     if (p->free_sphere.h_min) (void)hipHostFree(p->free_sphere.h_min);
     p->free_sphere.d_min.release();

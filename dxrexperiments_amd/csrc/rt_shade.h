@@ -349,7 +349,7 @@ struct EmitIO {
     uint32_t idx, q;            // compact hit index at level L, pixel slot
     uint32_t frame;             // frame of the batch the hit belongs to (single frames: 0)
     uint32_t shadow_mask, skip_mask, sec_mask;
-    f3 shadow_origin;           // compact shadow queues: the hit point both light rays start from
+    f3 shadow_origin;           // compact shadow queue: the hit point both light rays start from
     RT_DEV EmitIO(const PipeDev &p, int level, uint32_t i, uint32_t qq, uint32_t f) : pd(p), L(level), idx(i), q(qq), frame(f), shadow_mask(0), skip_mask(0), sec_mask(0)
     {
         shadow_origin = mk3(0.0f, 0.0f, 0.0f);
@@ -361,24 +361,24 @@ struct EmitIO {
         const bool skipped = !matters && pd.skip_unlit;     // "emitted but not worth traversing"; the trace kernel counts these
         shadow_mask |= 1u << s;
         if (skipped) skip_mask |= 1u << s;
-        if (pd.shadow_compact) {                            // the ray is rebuilt from the hit point by QueueSrc::load
+        if (pd.shadow_compact) {                            // the ray is rebuilt from the hit point by the loader (ShadowSrc::load)
             shadow_origin = o;
             return 1.0f;
         }
-        if (skipped) store_ray(pd.lv[L].shO, pd.lv[L].shD, (size_t)s * hcap(pd, L) + idx, mk3(0.0f, 0.0f, 0.0f), 0.0f, mk3(0.0f, 0.0f, 0.0f), RT_TMAX_SKIPPED);
-        else store_ray(pd.lv[L].shO, pd.lv[L].shD, (size_t)s * hcap(pd, L) + idx, o, tmin, d, tmax);
+        if (skipped) store_ray(pd.sh_O, pd.sh_D, sh_ray(pd, L, idx, (uint32_t)s), mk3(0.0f, 0.0f, 0.0f), 0.0f, mk3(0.0f, 0.0f, 0.0f), RT_TMAX_SKIPPED);
+        else store_ray(pd.sh_O, pd.sh_D, sh_ray(pd, L, idx, (uint32_t)s), o, tmin, d, tmax);
         return 1.0f;
     }
     // the shadow slots of this hit that no ray went to are marked "not traced"
     RT_DEV void finish_shadows(uint32_t shadow_slots) const
     {
-        if (L > 0 && (uint32_t)L >= pd.max_shadow) return;      // a level that casts no shadow rays has no shadow queue (launch_frame)
+        if ((uint32_t)L >= pd.sh_levels) return;            // a level that casts no shadow rays has no entries in the queue
         if (pd.shadow_compact) {
-            pd.lv[L].shO[idx] = make_float4(shadow_origin.x, shadow_origin.y, shadow_origin.z, __uint_as_float(shadow_mask | (skip_mask << 2) | (frame << 8)));
+            pd.sh_hits[pd.sh_cbase[L] + idx] = make_float4(shadow_origin.x, shadow_origin.y, shadow_origin.z, __uint_as_float(shadow_mask | (skip_mask << 2) | (frame << 8)));
             return;
         }
         for (uint32_t s = 0; s < shadow_slots; s++)
-            if (!(shadow_mask & (1u << s))) store_invalid(pd.lv[L].shO, pd.lv[L].shD, (size_t)s * hcap(pd, L) + idx);
+            if (!(shadow_mask & (1u << s))) store_invalid(pd.sh_O, pd.sh_D, sh_ray(pd, L, idx, s));
     }
     RT_DEV f3 secondary(int w, f3 o, f3 d, float tmin, uint32_t depth)
     {
@@ -402,7 +402,7 @@ struct ResolveIO {
     {
         if (depth >= pd.max_shadow) return 1.0f;
         if (!matters && pd.skip_unlit) return 1.0f;                       // never traced; the caller multiplies by zero
-        return pd.lv[L].vis[(size_t)s * hcap(pd, L) + idx] ? 1.0f : 0.0f;
+        return pd.sh_vis[sh_ray(pd, L, idx, (uint32_t)s)] ? 1.0f : 0.0f;
     }
     RT_DEV f3 secondary(int w, f3 o, f3 d, float tmin, uint32_t depth)
     {
@@ -435,7 +435,7 @@ struct LevelResolveIO {
     {
         if (depth >= pd.max_shadow) return 1.0f;
         if (!matters && pd.skip_unlit) return 1.0f;
-        return pd.lv[L].vis[(size_t)s * hcap(pd, L) + idx] ? 1.0f : 0.0f;
+        return pd.sh_vis[sh_ray(pd, L, idx, (uint32_t)s)] ? 1.0f : 0.0f;
     }
     RT_DEV f3 secondary(int w, f3, f3 d, float, uint32_t depth)
     {

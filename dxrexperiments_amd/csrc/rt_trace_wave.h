@@ -249,7 +249,12 @@ RT_DEV unsigned long long lanemask_lt()
 // Ray sources / hit sinks are small functor structs:
 //   struct Src  { uint32_t count() const; bool load(uint32_t i, RayD &r) const;   // false: not to be traced
 //                 uint32_t flags() const; };
-//   struct Sink { void store(uint32_t i, const HitD &h, bool traced) const; };
+//   struct Sink { void store(uint32_t ticket, const HitD &h, bool traced) const; };
+// A source may hand out a TICKET with the ray -- bool load(uint32_t i, RayD &r, uint32_t &ticket) -- which the walk carries in
+// place of i and gives to the sink with the ray's result (the shared shadow queue enumerates its rays in one order and stores
+// them in another); without it the ticket is i.
+template <class S> RT_DEV auto load_ray_of(const S &src, uint32_t i, RayD &r, uint32_t &ticket, int) -> decltype(src.load(i, r, ticket)) { return src.load(i, r, ticket); }
+template <class S> RT_DEV bool load_ray_of(const S &src, uint32_t i, RayD &r, uint32_t &ticket, long) { ticket = i; return src.load(i, r); }
 
 // COUNT: the walk-counting instantiation (rt_pipeline_count_walk): the same walk, plus per-lane tallies of what it
 // fetches -- 64-B nodes from global memory, nodes from the LDS-resident top, 48-B triangle records, the 96-B traversal prefix of
@@ -306,7 +311,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
     uint32_t next_chunk = blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;   // wave-uniform
     const uint32_t n_groups = gridDim.x < RT_POOL_GROUPS ? gridDim.x : RT_POOL_GROUPS;
     const uint32_t pool_group = blockIdx.x % n_groups;
-    uint32_t idx = 0;
+    uint32_t idx = 0;                 // the ticket of the lane's ray: what the sink gets with its result
     RayD r;
     RayInv wri;
     HitD best;
@@ -364,8 +369,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
             bool started = false, skipped = false;
             if (!alive && rank < avail) {
                 const uint32_t my = chunk_next + rank;
-                idx = my;
-                const bool traced = src.load(my, r);
+                const bool traced = load_ray_of(src, my, r, idx, 0);
                 best = make_miss(r);
                 if (traced && r.tmax > r.tmin && sc.n_inst != 0) {
                     wri = make_inv(r.o, r.d);
@@ -402,7 +406,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     if (COUNT) wk_ray0 = wk_glob + wk_top;
                 } else {
                     if (ANYHIT && r.tmax == RT_TMAX_SKIPPED) skipped = true;
-                    sink.store(my, best, traced);
+                    sink.store(idx, best, traced);
                 }
             }
             n_traced += (uint32_t)__popcll(__ballot(started));
