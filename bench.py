@@ -341,7 +341,7 @@ def headline_roofline(args, stages, dom, n_t, n_sets, S, live, W, H, ms_per_step
     traffic / minimum as the wasted-traffic ratio; the vector-issue reading with BOTH denominators (the nominal 2 cycles per
     wave64 instruction and the measured 2.65 of this instruction mix); the active-lane fraction; where the waves' cycles go."""
     d = stages[dom]
-    prof_name = "c2" if S == 1 else "c2b"
+    prof_name = "c2" if S == 1 else ("c2s" if S <= 24 and committed_profile("c2s") else "c2b")
     # (the committed counters are those of the default workload: they stand in for live ones only when this run is that workload)
     default_workload = (W, H) == (1920, 1080) and not args.obj and not args.camera
     prof = committed_profile(prof_name).get("kernels", {}).get(d["kernel"], {}) if default_workload else {}
@@ -402,8 +402,10 @@ def headline_roofline(args, stages, dom, n_t, n_sets, S, live, W, H, ms_per_step
             mean_lanes = (150.0 * lu["wave_node_steps"] * lu["node_steps"] + 120.0 * lu["wave_triangle_steps"] * lu["triangle_steps"]) / steps_w
             vi["mean_live_lane_fraction"] = mean_lanes
             vi["frac_nominal_x_live_lanes"] = vi["frac_nominal"] * mean_lanes
-        if "SQ_THREAD_CYCLES_VALU" in pm and pm.get("SQ_ACTIVE_INST_VALU"):
-            rl["lane_utilisation"]["pmc_thread_cycles_over_64x_active_inst_valu"] = pm["SQ_THREAD_CYCLES_VALU"] / (64.0 * pm["SQ_ACTIVE_INST_VALU"])
+        if "SQ_THREAD_CYCLES_VALU" in lv and lv.get("SQ_ACTIVE_INST_VALU"):          # (live: the "lanes" pass came last, both counters are its own)
+            rl["lane_utilisation"]["pmc_thread_cycles_over_64x_active_inst_valu"] = lv["SQ_THREAD_CYCLES_VALU"] / (64.0 * lv["SQ_ACTIVE_INST_VALU"])
+        elif pm.get("active_lane_fraction"):
+            rl["lane_utilisation"]["pmc_thread_cycles_over_64x_active_inst_valu"] = pm["active_lane_fraction"]
         rl["valu_issue"] = vi
         wc = pm["SQ_WAVE_CYCLES"]
         rl["wave_cycles"] = {"parked_on_waitcnt": pm.get("SQ_WAIT_ANY", 0.0) / wc, "issue_stalled": pm.get("SQ_WAIT_INST_ANY", 0.0) / wc,
@@ -567,20 +569,26 @@ def tiles_main(args, rank, world, local_rank, dev, capi, D, T, scenes, torch, di
     cam = capi.camera_array((0.0, 6.0, 19.0), (0.0, -4.0, 0.0), (0, 1, 0), 0.8, W / H)
     pfcs = [host.update(cam, 0.0, f + 1, W, H) for f in range(Wu + K)]
 
-    def step(i):
-        pipe.update(pfcs[i])
-        pipe.render_bands(band, rank, world)          # all of this rank's bands in one set of launches
+XX
 
-    for i in range(Wu):
-        step(i)
+    def steps(lo, hi):
+        """frames lo..hi-1: this rank's bands of S frames at a time through shared sets of launches (rt_pipeline_render_bands_batch)"""
+        if S == 1:
+            for i in range(lo, hi):
+                pipe.update(pfcs[i])
+                pipe.render_bands(band, rank, world)          # all of this rank's bands of ONE frame in one set of launches
+        else:
+            for i in range(lo, hi, S):
+                pipe.render_bands_batch(band, rank, world, pfcs[i:min(i + S, hi)])
+
+    steps(0, Wu)
     if world > 1:
         D.gather_tiles(acc.clone(), band)             # warm the collective
         dist.barrier()
     torch.cuda.synchronize()
     pipe.reset_totals()
     t0 = time.perf_counter()
-    for i in range(Wu, Wu + K):
-        step(i)
+    steps(Wu, Wu + K)
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     ev[0].record()
     if world > 1:
@@ -610,7 +618,8 @@ def tiles_main(args, rank, world, local_rank, dev, capi, D, T, scenes, torch, di
                                    "interleaved %d-row bands per GPU" % (tri.shape[0], W, H, band),
                        "parallelism": "tile-partitioned x%d, one all-gather of %d band slots per rank (%.1f MB sent per rank)"
                                       % (world, slots, floats * 4 / 1e6) if world > 1 else "single GPU",
-                       "frames": K},
+                       "frames": K, "frames_per_launch_set": S,
+                       "entry_point": "rt_pipeline_render_bands_batch" if S > 1 else "rt_pipeline_update + rt_pipeline_render_bands"},
             "frames_per_s": K / elapsed, "primary_mrays_per_s": float(red[2].item()) / elapsed / 1e6, "bvh_build_ms": scene.build_ms(),
             "ranks": report}))
     if world > 1:

@@ -310,6 +310,7 @@ int rt_dist_get_rank(const rt_dist *d, int *rank, int *world)
 int rt_dist_all_reduce_sum(rt_dist *d, void *device_f32, size_t count)
 {
     RT_REQUIRE(d && device_f32, "null argument");
+    RT_TRY(rt_context_flush_deferred(d->ctx));        // frames a deferred pipeline still holds belong to the image that is exchanged
     HIP_TRY(hipSetDevice(d->ctx->device));
     d->timed = false;
     if (d->ev0) HIP_TRY(hipEventRecord(d->ev0, d->ctx->stream));
@@ -339,6 +340,7 @@ int rt_dist_device_pci_bus_id(const rt_context *ctx, char *out, size_t capacity)
 int rt_dist_gather_bands(rt_dist *d, void *device_rgba32f, uint32_t width, uint32_t height, uint32_t band_rows)
 {
     RT_REQUIRE(d && device_rgba32f, "null argument");
+    RT_TRY(rt_context_flush_deferred(d->ctx));        // frames a deferred pipeline still holds belong to the image that is exchanged
     uint32_t slots = 0;
     size_t floats = 0;
     RT_TRY(rt_tile_gather_layout(width, height, band_rows, (uint32_t)d->world, &slots, &floats));

@@ -1091,7 +1091,8 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     }
     PipeDev pd;
     // (threads of the largest launch: the primary stage runs one thread per pixel slot, the persistent stages fewer)
-    const bool set_rows = n_frames > 1 && !p->scene->two_level && ctx->lds_stack_rows != RT_LDS_STACK_ROWS_TEST && RT_LDS_STACK_ROWS_SETS != RT_LDS_STACK_ROWS;
+    static const bool seven_waves_always = getenv("RT_SEVEN_WAVES_ALWAYS") && atoi(getenv("RT_SEVEN_WAVES_ALWAYS")) != 0;      // (experiment: single frames on the sets' kernels)
+    const bool set_rows = (n_frames > 1 || seven_waves_always) && !p->scene->two_level && ctx->lds_stack_rows != RT_LDS_STACK_ROWS_TEST && RT_LDS_STACK_ROWS_SETS != RT_LDS_STACK_ROWS;
     RT_TRY(rt_scene_dev_for_launch(ctx, p->scene, set_rows ? RT_LDS_STACK_ROWS_SETS : rt_lds_stack_rows(ctx), cap > ctx->cu_count * 16u * PBLOCK ? cap : ctx->cu_count * 16u * PBLOCK, &pd.sc));
     pd.pfc = frames[0];
     pd.n_frames = n_frames; pd.fcap = fcap;

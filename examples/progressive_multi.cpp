@@ -84,14 +84,22 @@ static int rank_main(int rank, int world, int id_in, int id_out, char **argv)
         ThrowIfFailed(rt_context_synchronize(context->getHandle()));
         const auto t0 = std::chrono::steady_clock::now();
         uint32_t mine = 0;
-        for (UINT frame = 1; frame <= frames; ++frame) {
-            // every rank advances the SAME host state (jitter RNG, frame / accumulation counters) for every frame ...
-            pipeline->update(0.0f, frame, (frame + 2) % 3, frame % 3, width, height);
-            if (tiles) {                                               // ... and renders its bands of each frame
-                pipeline->renderBands(width, height, band_rows, rank, world);
-            } else if ((frame - 1) % (UINT)world == (UINT)rank) {     // ... or its share of the frames
-                pipeline->render(frame % 3, width, height);
-                mine++;
+        if (tiles) {
+            // every rank advances the SAME host state (jitter RNG, frame / accumulation counters) for every frame and renders its
+            // bands of each -- 16 frames at a time through shared sets of launches (round 4: at 8 ranks a band set of ONE frame is an
+            // eighth of a frame per persistent launch; sets give the launches back their length)
+            const UINT per_set = 16;
+            for (UINT first = 1; first <= frames; first += per_set)
+                pipeline->renderBandsBatch(0.0f, first, first + per_set - 1 <= frames ? per_set : frames - first + 1, width, height, band_rows, rank, world);
+        } else {
+            for (UINT frame = 1; frame <= frames; ++frame) {
+                // every rank advances the SAME host state for every frame and renders its share of the frames (the pipeline records them
+                // and renders them in sets of up to 32: deferred mode, the mirror's default; the collective below flushes the last set)
+                pipeline->update(0.0f, frame, (frame + 2) % 3, frame % 3, width, height);
+                if ((frame - 1) % (UINT)world == (UINT)rank) {
+                    pipeline->render(frame % 3, width, height);
+                    mine++;
+                }
             }
         }
         if (tiles) ThrowIfFailed(rt_dist_gather_bands(dist, image_dev, width, height, band_rows));

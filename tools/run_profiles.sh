@@ -19,17 +19,18 @@ for w in $WL; do
   elif [ $w = c2b ]; then ARGS="--steps 60 --warmup 30 --cpu-seconds 0 --hbm-frames 0 --no-live-pmc --no-frame-by-frame --no-roofline";       # the headline launches only: sets of 30 frames
   elif [ $w = c5 ]; then ARGS="--workload c5 --hbm-frames 4 --no-live-pmc";
   elif [ $w = c5b ]; then ARGS="--workload c5 --hbm-frames 16 --batch 16 --no-live-pmc --no-roofline";
+  elif [ $w = c2s ]; then ARGS="--steps 20 --warmup 20 --batch 20 --cpu-seconds 0 --hbm-frames 0 --no-live-pmc --no-frame-by-frame --no-roofline";      # sets of 20: what the driver's --steps 20 renders
   else PROG=$R/tools/profile_c4.py; ARGS="4"; fi
   run() {   # name, rocprof options...
     n=$1; shift
-    timeout 600 rocprofv3 "$@" -d $OUT/${w}_$n -o p --output-format csv -- python3 $PROG $ARGS > $OUT/${w}_$n.log 2>&1
+    timeout 300 rocprofv3 "$@" -d $OUT/${w}_$n -o p --output-format csv -- python3 $PROG $ARGS > $OUT/${w}_$n.log 2>&1
     python3 $R/tools/profile_summary.py $OUT/${w}_$n "rocprofv3 $* -- python3 $(basename $PROG) $ARGS" > $OUT/${w}_$n.md
     rm -rf $OUT/${w}_$n
     tail -n 1 $OUT/${w}_$n.log | cut -c 1-300
   }
   want() { [ -z "$PASSES" ] || echo " $PASSES " | grep -q " $1 "; }
   want kt && run kt --kernel-trace --stats
-  [ -n "$PASSES" ] && { want ea && run ea --kernel-trace --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_sum; want write && run write --kernel-trace --pmc WRITE_SIZE; want sq && run sq --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU; want fetch && run fetch --kernel-trace --pmc FETCH_SIZE; want mix && run mix --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_TRANS_F32 GRBM_GUI_ACTIVE; want mix2 && run mix2 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE; continue; }
+  [ -n "$PASSES" ] && { want ea && run ea --kernel-trace --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_sum; want write && run write --kernel-trace --pmc WRITE_SIZE; want sq && run sq --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE; want fetch && run fetch --kernel-trace --pmc FETCH_SIZE; want tcp && run tcp --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum; want lanes && run lanes --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE; want tcc && run tcc --kernel-trace --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum; want mix && run mix --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_TRANS_F32 GRBM_GUI_ACTIVE; want mix2 && run mix2 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE; continue; }
   run fetch --kernel-trace --pmc FETCH_SIZE
   run write --kernel-trace --pmc WRITE_SIZE
   run tcc --kernel-trace --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum

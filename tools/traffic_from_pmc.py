@@ -41,10 +41,13 @@ def main():
                          "Infinity-Cache hits are included (MI355X_MICROARCH.md, HBM section)",
            "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, text=True).stdout.strip(),
            "workloads": {}}
-    for w in ("c2", "c5", "c4", "c2b", "c5b"):          # (c2b / c5b: the same workloads at 30 / 16 frames per set of launches)
+    for w in ("c2", "c5", "c4", "c2b", "c5b", "c2s"):          # (c2b / c5b: the same workloads at 30 / 16 frames per set of launches)
         kt, fe, wr = rows("%s/%s_kt.md" % (d, w)), rows("%s/%s_fetch.md" % (d, w)), rows("%s/%s_write.md" % (d, w))
         tcc, sq, ea = rows("%s/%s_tcc.md" % (d, w)), rows("%s/%s_sq.md" % (d, w)), rows("%s/%s_ea.md" % (d, w))
         tcp, ta2 = rows("%s/%s_tcp.md" % (d, w)), rows("%s/%s_ta2.md" % (d, w))
+        # (round 4) thread cycles over 64 x instruction cycles = the active-lane fraction; its two counters come from ONE pass
+        lanes = {(k, c): v for (k, c), v in rows("%s/%s_lanes.md" % (d, w)).items() if c.split(":")[0] in ("SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU")}
+        lanes = {(k, "LANES_" + c if c.startswith("SQ_ACTIVE_INST_VALU") else c): v for (k, c), v in lanes.items()}
         mix = rows("%s/%s_mix.md" % (d, w))              # vector instructions by class (their SQ_INSTS_VALU kept apart: shares within one pass)
         mix = {(k, "SQ_INSTS_VALU_MIX" if c == "SQ_INSTS_VALU" else c): v for (k, c), v in mix.items() if c != "GRBM_GUI_ACTIVE" and not c.startswith("GRBM_GUI_ACTIVE")}
         if not fe and not ea:
@@ -68,12 +71,14 @@ def main():
                 e["bytes_per_launch"] = int(e["read_bytes_by_request_size"] + wv * 1024)
             else:
                 e["bytes_per_launch"] = e["bytes_per_launch_fetch_x2"]
+            if w == "c2s":
+                e["frames_per_launch"] = 20                                # (sets of 20: the driver's --steps 20)
             if w.endswith("b"):
                 e["frames_per_launch"] = 30 if w == "c2b" else 16         # (tools/run_profiles.sh: c2b = the bench default's sets of 30, c5b = --batch 16)
             if (k, "avg_us") in kt:
                 e["avg_us"] = kt[(k, "avg_us")]
                 e["GBps"] = e["bytes_per_launch"] / (e["avg_us"] * 1e-6) / 1e9
-            for src in (tcc, sq, ea, tcp, ta2, mix):
+            for src in (tcc, sq, ea, tcp, ta2, mix, lanes):
                 for (kk, c), v in src.items():
                     if kk == k and not c.endswith(":n"):
                         e[c] = v
@@ -81,6 +86,8 @@ def main():
             # shader-engine-active cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs) and the L1 -> L2 read-request rate
             if "SQ_ACTIVE_INST_VALU" in e and e.get("GRBM_GUI_ACTIVE"):
                 e["valu_busy"] = e["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * e["GRBM_GUI_ACTIVE"] / 8.0)
+            if e.get("LANES_SQ_ACTIVE_INST_VALU") and "SQ_THREAD_CYCLES_VALU" in e:
+                e["active_lane_fraction"] = e["SQ_THREAD_CYCLES_VALU"] / (64.0 * e["LANES_SQ_ACTIVE_INST_VALU"])
             if "TCP_TCC_READ_REQ_sum" in e and "avg_us" in e:
                 e["l2_read_requests_per_s"] = e["TCP_TCC_READ_REQ_sum"] / (e["avg_us"] * 1e-6)
             ks[k] = e
