@@ -569,7 +569,7 @@ def tiles_main(args, rank, world, local_rank, dev, capi, D, T, scenes, torch, di
     cam = capi.camera_array((0.0, 6.0, 19.0), (0.0, -4.0, 0.0), (0, 1, 0), 0.8, W / H)
     pfcs = [host.update(cam, 0.0, f + 1, W, H) for f in range(Wu + K)]
 
-XX
+    S = max(1, min(args.batch if args.batch_given else 32, 32))       # frames per set of launches (1: one set per frame, round 3 form)
 
     def steps(lo, hi):
         """frames lo..hi-1: this rank's bands of S frames at a time through shared sets of launches (rt_pipeline_render_bands_batch)"""
