@@ -103,7 +103,8 @@ __global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_primary(PipeDev pd)
         for (uint32_t i = threadIdx.x; i < (uint32_t)(POOL_OFFSET_WORDS + POOL_BYTES / 4); i += PBLOCK) pd.counters[i] = 0u;
     PrimarySrcT<BATCH> src = {pd};
     PrimarySinkT<BATCH> sink = {pd};
-    trace_wave<STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, nullptr, smem, nullptr);   // one 8x8 tile per wave, dealt by the hardware dispatcher
+    // one 8x8 tile per wave, dealt by the hardware dispatcher -- or (experiment) a persistent launch that refills its lanes from a pool of tiles
+    trace_wave<STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, pd.primary_persistent ? pd.pools + POOL_BYTES / 4 : nullptr, smem, nullptr);
 }
 
 // Compaction of the hits of level L (they get shaded).  Level 0 runs over the pixel slots, level 1 over its two batches,
@@ -937,8 +938,9 @@ int launch_frame(rt_pipeline *p, PipeDev &pd, uint32_t shadow_slots, bool counte
     };
     if (T) record(ev[0], st);
     // primary rays are coherent: one 8x8 tile per wave, scheduled by the hardware dispatcher
-    if (pd.n_frames > 1u) k_primary<STACK, TWO_LEVEL, true><<<blocks(cap), PBLOCK, 0, st>>>(pd);
-    else k_primary<STACK, TWO_LEVEL, false><<<blocks(cap), PBLOCK, 0, st>>>(pd);
+    if (pd.primary_persistent) HIP_TRY(hipMemsetAsync(pd.pools + POOL_BYTES / 4, 0, PRIMARY_POOL_WORDS * 4, st));      // (its own first block cannot clear it: the others already draw from it)
+    if (pd.n_frames > 1u) k_primary<STACK, TWO_LEVEL, true><<<pd.primary_persistent ? rt_persistent_grid(ctx, k_primary<STACK, TWO_LEVEL, true>, PBLOCK, cap) : blocks(cap), PBLOCK, 0, st>>>(pd);
+    else k_primary<STACK, TWO_LEVEL, false><<<pd.primary_persistent ? rt_persistent_grid(ctx, k_primary<STACK, TWO_LEVEL, false>, PBLOCK, cap) : blocks(cap), PBLOCK, 0, st>>>(pd);
     k_compact_level<<<(cap + CTILES * CBLOCK - 1) / (CTILES * CBLOCK), CBLOCK, 0, st>>>(pd, 0);
     if (T) record(ev[1], st);
     RT_TRY(size_next(0, true, levels >= 1));
@@ -1081,7 +1083,10 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     // queue memory: the worst case up front when it fits the budget, else level by level as the counts come in (launch_frame)
     const uint32_t levels_now = frame_levels(p);
     const bool counted = worst_case_queue_bytes(cap, levels_now, p->max_shadow, shadow_slots, !ao_view) > queue_budget(p);
-    RT_TRY(p->counters.reserve(POOL_OFFSET_WORDS * 4 + POOL_BYTES));
+    if (p->counters.bytes < POOL_OFFSET_WORDS * 4 + POOL_BYTES + PRIMARY_POOL_WORDS * 4) {
+        RT_TRY(p->counters.reserve(POOL_OFFSET_WORDS * 4 + POOL_BYTES + PRIMARY_POOL_WORDS * 4));
+        HIP_TRY(hipMemsetAsync(p->counters.p, 0, p->counters.bytes, st));
+    }
     if (counted) RT_TRY(reserve_level_rays(p, 0, cap, levels_now > 1));
     else RT_TRY(reserve_worst_case(p, cap, levels_now, p->max_shadow, shadow_slots, !ao_view));
     p->counted_queues = counted;
@@ -1145,6 +1150,12 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     pd.accum_mode = p->accum_mode;
     pd.skip_unlit = p->skip_unlit;
     pd.kind = p->kind;
+    // The primary stage as a persistent launch that refills its lanes from a pool of tiles (instead of one tile per wave, dealt by the
+    // hardware): pays where the rays of a tile part ways early -- two-level scenes, whose primary waves run at 0.48 of their lanes
+    // (4096 instances at 4K: 1.39 -> 1.31 ms) -- and costs 13 % where they stay together (the single-level bench scene: 0.69 of the lanes
+    // as it is).  RT_PRIMARY_PERSISTENT=0 / 1 overrides.  profiles/r04/c4_variants.txt, primary_persistent.txt
+    static const int primary_persistent_env = getenv("RT_PRIMARY_PERSISTENT") ? atoi(getenv("RT_PRIMARY_PERSISTENT")) : -1;
+    pd.primary_persistent = (primary_persistent_env < 0 ? p->scene->two_level : primary_persistent_env != 0) ? 1u : 0u;
     pd.accum = p->accum;
     pd.aov_direct = p->accum;                       // realtime: output 0 = direct lighting, output 1 = indirect specular
     pd.aov_indirect = p->aov_own.as<float4>();
@@ -1347,7 +1358,10 @@ int rt_pipeline_reserve_batch(rt_pipeline *p, uint32_t width, uint32_t height, u
     // (a set whose worst case is over the budget sizes its levels by count as it goes: only the pixel slots are known now)
     const uint32_t levels_now = frame_levels(p);
     const size_t cap = (size_t)fcap * frames;
-    RT_TRY(p->counters.reserve(POOL_OFFSET_WORDS * 4 + POOL_BYTES));
+    if (p->counters.bytes < POOL_OFFSET_WORDS * 4 + POOL_BYTES + PRIMARY_POOL_WORDS * 4) {
+        RT_TRY(p->counters.reserve(POOL_OFFSET_WORDS * 4 + POOL_BYTES + PRIMARY_POOL_WORDS * 4));
+        HIP_TRY(hipMemsetAsync(p->counters.p, 0, p->counters.bytes, p->ctx->stream));
+    }
     if (worst_case_queue_bytes(cap, levels_now, p->max_shadow, ao_view ? 4u : 2u, !ao_view) > queue_budget(p)) RT_TRY(reserve_level_rays(p, 0, cap, levels_now > 1));
     else RT_TRY(reserve_worst_case(p, cap, levels_now, p->max_shadow, ao_view ? 4u : 2u, !ao_view));
     if (frames > 1) RT_TRY(p->batch_consts.reserve((sizeof(rt_per_frame_constants) + sizeof(LightRays)) * RT_MAX_BATCH));

@@ -107,6 +107,7 @@ struct PipeDev {
     uint32_t skip_unlit;                // do not traverse shadow rays of lights with N.L == 0 (their visibility is multiplied by 0)
     uint32_t shadow_compact;            // shadow queues hold ONE float4 per shaded hit (QueueSrc, "light rays")
     uint32_t kind;                      // RT_PIPELINE_PROGRESSIVE / RT_PIPELINE_REALTIME
+    uint32_t primary_persistent;        // the primary stage is a persistent launch with a chunk pool of its own (experiment: RT_PRIMARY_PERSISTENT=1)
     float4 *accum;
     float4 *aov_direct, *aov_indirect;  // realtime pipeline outputs (RealtimeRaytracing.hlsl:3-4)
     uint32_t *counters;
@@ -133,6 +134,7 @@ struct PipeDev {
 };
 
 constexpr size_t POOL_BYTES = (size_t)(1 + MAXD) * RT_POOL_GROUPS * RT_POOL_STRIDE * 4;      // shadow launch, levels 1..MAXD
+constexpr size_t PRIMARY_POOL_WORDS = (size_t)RT_POOL_GROUPS * RT_POOL_STRIDE;      // the primary stage's own pool, behind the others (cleared by a fill in front of the stage)
 constexpr size_t POOL_OFFSET_WORDS = 64;      // the pools start on a 256-B boundary after the scalar counters
 
 // ray number of shadow ray s of hit idx of level L (storage order: see PipeDev::sh_*)

@@ -79,6 +79,9 @@ RT_DEV v4f ldg16(const void *base, size_t byte_off)
 #define RT_POOL_GROUPS 32u              // chunk counters per traversal launch (8: 3.08, 32: 3.07, 128: 3.09, 512: 3.12 ms; static: 3.21)
 #endif
 #define RT_POOL_STRIDE 32u              // words between two counters: one 128-B L2 line each
+#ifndef RT_SENTINEL_INLINE
+#define RT_SENTINEL_INLINE 1            // two-level walks leave a BLAS inside the node loop (round 4: the 4096-instance frame 4.70 -> 4.60 ms, profiles/r04/c4_variants.txt)
+#endif
 #ifndef RT_EXIT_K
 #define RT_EXIT_K 1                     // leave the node loop once (lanes still on internal nodes) * K < lanes waiting on a leaf
                                         //   (four-wide nodes, ms per frame 1080p / 10 M triangles 4K: K = 0 3.31 / 21.9, 1 2.80 / 15.5, 2 2.86 / 16.5, 3 2.88 / 16.9)
@@ -432,6 +435,18 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_read_exec())) { wk_lines += (RT_WIDE == 8 ? 2u : 1u) * dl; wk_node_lines += (RT_WIDE == 8 ? 2u : 1u) * dl; wv_steps++; }       // 64-B lines (96 B of a 128-B record: two)
             }
             wide_step<false, ANYHIT>(nodes, top_cur, top_lim, cur.ri, r.tmin, ANYHIT ? r.tmax : best.t, st, node, sp);
+#if RT_SENTINEL_INLINE
+            // (two-level walks) a pop that brings up the sentinel ends the walk of a BLAS: the lane returns to the TLAS here, inside the
+            // node loop, and pops what lies beneath -- instead of waiting for the wave's next leaf phase to do only that
+            if (TWO_LEVEL && node == RT_NODE_SENTINEL) {
+                in_blas = false;
+                nodes = sc.tlas_wide;
+                top_lim = sc.top_n;
+                cur.o = r.o; cur.d = r.d; cur.ri = wri;
+                if (sp > 0) { sp--; node = st.lds[sp * BLOCK]; }
+                else node = RT_NODE_EMPTY;
+            }
+#endif
 #if RT_EXIT_K > 0
             // stragglers: most of the wave already waits on a leaf -> run the leaf phase now, come back after
             const int walking = __popcll(__ballot(alive && node_is_internal(node)));

@@ -7,8 +7,9 @@ by hand, on a GPU box, for as long as wanted:
 Every iteration draws a scene (triangle soups, blobs, displaced grids, Cornell; one identity instance or several
 transformed ones), materials, debug options, depth limits, an image size and a tile, renders two frames with the
 GPU pipeline (progressive or realtime) and with the CPU oracle, and demands bit-equal images and ray counts; progressive
-draws then go on for one to five more frames through ONE set of launches (rt_pipeline_render_batch) against the oracle's
-frame-by-frame accumulation.
+draws then go on for one to five more frames through shared sets of launches -- rt_pipeline_render_batch, the deferred
+pipeline behind update() + render(), or the bands of a tile partition rank after rank, with the queues sized for the worst
+case or by count -- against the oracle's frame-by-frame accumulation.
 Exits non-zero on the first difference and prints the draw that caused it."""
 import os
 import sys
@@ -136,7 +137,24 @@ def run(iters, seed, ctx, verbose=True):
                     lit = relight(pfc.copy())
                 pfc["directionalLight"] = lit["directionalLight"]
                 pfc["pointLight"] = lit["pointLight"]
-            p.render_batch(more)
+            # (round 4) ... submitted in one of the ways a set can come about: the explicit call, the reference's per-frame calls with
+            # the pipeline in deferred mode (flushed by the read below), the ranks' bands of a tile partition one after the other
+            # -- and, for half of the draws, with every radiance level's queues sized by count instead of the worst case
+            how = int(r.integers(0, 4))
+            counted = bool(r.random() < 0.5)
+            desc["set"] = ("render_batch", "deferred", "bands", "deferred, small sets")[how] + (", counted queues" if counted else "")
+            p.set_queue_budget(1 if counted else 0)
+            if how == 0:
+                p.render_batch(more)
+            elif how == 2:
+                world = int(r.integers(1, 6))
+                for rank in range(world):
+                    p.render_bands_batch(8, rank, world, more)
+            else:
+                p.set_deferred(32 if how == 1 else 2)
+                for pfc in more:
+                    p.update(pfc)
+                    p.render()
             for pfc in more:
                 acc, ost = osc.render(omats, pfc, W, H, accum=acc, env_faces=env, max_radiance_depth=depth[0], max_shadow_depth=depth[1], nthreads=8)
             if not np.array_equal(p.read_output(), acc):
