@@ -4,7 +4,7 @@ oracle/oracle_shade.h is the one restatement of RayGen -> PrimaryClosestHit -> s
 tests/golden/nversion_shade.py is a SECOND restatement, written from the HLSL text alone in float32 numpy: brute-force
 intersection instead of a BVH, numpy's own transcendentals instead of the polynomial kernels, no code shared with oracle/
 or the product.  Here both render the Cornell box (32 x 32, two accumulated frames) under option / material sets that
-exercise every branch of shade(); primary hit ids must be identical and the images must agree to RMS <= 1e-5 (north_star's
+exercise every branch of shade() -- and, since round 4, the reference's own susanne.obj under three more --; primary hit ids must be identical and the images must agree to RMS <= 1e-5 (north_star's
 tolerance; ulp-level differences of the transcendentals are the only expected source).  The measured values of the
 authoring run are committed in tests/golden/reference_assets.json ("nversion_shading") and checked against as well, so a
 drift of either restatement shows."""
@@ -38,14 +38,25 @@ CASES = {
     "albedo_view": ({"showGBufferAlbedoOnly": 1}, {}),
     "diffuse_material": ({}, {"type": 0}),
     "glass_rough_emissive": ({"environmentStrength": 0.25}, {"type": 2, "roughness": 0.9, "reflectivity": 0.3, "emissive": (0.2, 0.1, 0.4, 0.5)}),
+    # (round 4) a second scene, so that the agreement is not a property of the Cornell box's axis-aligned walls: the reference's own
+    # assets/models/susanne.obj (968 triangles, curved, smooth normals, rays that miss into the environment) seen from outside,
+    # under the reference's lights and under lights of its own (a sun from behind the camera, a point light close to the mesh)
+    "susanne_default": ({}, {}, {"scene": "susanne"}),
+    "susanne_glass_uniform": ({"cosineHemisphereSampling": 0, "environmentStrength": 1.5}, {"type": 2, "roughness": 0.2, "reflectivity": 0.9}, {"scene": "susanne"}),
+    "susanne_own_lights": ({}, {"type": 1, "roughness": 0.7}, {"scene": "susanne", "sun": (-0.2, -0.5, -1.0), "lamp": (0.6, 0.9, 1.4)}),
 }
 
 
-def run_case(options, material):
+def run_case(options, material, setup=None):
     from oracle import pyoracle as O
-    v, tri = O.obj_load(os.path.join(HERE, "golden", "cornell.obj"))
-    c = scenes.cornell_camera()
-    cam = np.array([*c["eye"], *c["at"], *c["up"], c["fov"], W / H], np.float32)
+    setup = setup or {}
+    if setup.get("scene") == "susanne":
+        v, tri = O.obj_load(os.path.join(HERE, "golden", "susanne.obj"))
+        cam = np.array([1.2, 0.8, 3.6, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.7, W / H], np.float32)
+    else:
+        v, tri = O.obj_load(os.path.join(HERE, "golden", "cornell.obj"))
+        c = scenes.cornell_camera()
+        cam = np.array([*c["eye"], *c["at"], *c["up"], c["fov"], W / H], np.float32)
     sc = O.Scene()
     sc.add_instance(sc.add_model(v, tri))
     sc.build()
@@ -62,6 +73,10 @@ def run_case(options, material):
     ids_equal = True
     for frame in range(2):
         pfc = host.update(cam, 0.0, frame + 1, W, H)
+        if "sun" in setup:                                     # (the oracle's host returns the 188 raw bytes)
+            view = pfc.view(T.PER_FRAME_CONSTANTS)
+            view["directionalLight"]["forwardDir"][0, :3] = setup["sun"]
+            view["pointLight"]["worldPos"][0, :3] = setup["lamp"]
         acc, _ = sc.render(mat, pfc, W, H, accum=acc, env_constant=(0.5, 0.5, 0.5))
         pf = np.frombuffer(pfc.tobytes(), T.PER_FRAME_CONSTANTS)[0]
         acc2, prim = NV.render_frame(nsc, pf, mat, W, H, acc2)
