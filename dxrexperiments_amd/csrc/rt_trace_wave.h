@@ -82,6 +82,9 @@ RT_DEV v4f ldg16(const void *base, size_t byte_off)
 #ifndef RT_SENTINEL_INLINE
 #define RT_SENTINEL_INLINE 1            // two-level walks leave a BLAS inside the node loop (round 4: the 4096-instance frame 4.70 -> 4.60 ms, profiles/r04/c4_variants.txt)
 #endif
+#ifndef RT_POOL_XCD
+#define RT_POOL_XCD 1                   // any-hit launches: every XCD works through one contiguous eighth of the queue (then helps its neighbours)
+#endif
 #ifndef RT_EXIT_K
 #define RT_EXIT_K 1                     // leave the node loop once (lanes still on internal nodes) * K < lanes waiting on a leaf
                                         //   (four-wide nodes, ms per frame 1080p / 10 M triangles 4K: K = 0 3.31 / 21.9, 1 2.80 / 15.5, 2 2.86 / 16.5, 3 2.88 / 16.9)
@@ -314,6 +317,9 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
     uint32_t next_chunk = blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;   // wave-uniform
     const uint32_t n_groups = gridDim.x < RT_POOL_GROUPS ? gridDim.x : RT_POOL_GROUPS;
     const uint32_t pool_group = blockIdx.x % n_groups;
+#if RT_POOL_XCD
+    uint32_t xcd_steal = 0;          // wave-uniform: how many XCDs' eighths of the queue this wave has seen run dry
+#endif
     uint32_t idx = 0;                 // the ticket of the lane's ray: what the sink gets with its result
     RayD r;
     RayInv wri;
@@ -351,6 +357,27 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 // the frame).  Workgroups are dealt to the XCDs round-robin and G is a multiple of 8, so a
                 // group and its counter stay on one XCD.
                 uint32_t cidx;
+#if RT_POOL_XCD
+                // Any-hit launches (round 4): every XCD owns one contiguous EIGHTH of the queue -- its four groups deal that eighth among
+                // themselves -- and moves on to the next XCD's eighth when its own is used up: the shadow rays of one part of the image
+                // (their origins: the compaction keeps tile order) share an L2.  Any-hit stage -2.4 % on both workloads; the closest-hit
+                // queues lose what the any-hit queue gains (+0.5 ... +2 %) and keep the round-robin deal (profiles/r04/pool_xcd.txt;
+                // round 3's per-GROUP bands lost frame by frame: profiles/r03/pool_contiguous.txt).
+                if (ANYHIT && pool && n_groups == RT_POOL_GROUPS) {
+                    const uint32_t chunks = (total + CHUNK - 1u) / CHUNK, per = (chunks + 7u) / 8u;
+                    cidx = 0x4000000u;
+                    while (xcd_steal < 8u) {
+                        const uint32_t x = (pool_group + xcd_steal) & 7u;
+                        const uint32_t g = x + (pool_group & ~7u);
+                        uint32_t k = 0;
+                        if ((threadIdx.x & 63u) == 0u) k = atomicAdd(&pool[g * RT_POOL_STRIDE], 1u);
+                        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+                        const uint32_t c = x * per + (pool_group >> 3) + k * (RT_POOL_GROUPS / 8u);
+                        if (c < (x + 1u) * per && c < chunks) { cidx = c; break; }
+                        xcd_steal++;
+                    }
+                } else
+#endif
                 if (pool) {
                     uint32_t k = 0;
                     if ((threadIdx.x & 63u) == 0u) k = atomicAdd(&pool[pool_group * RT_POOL_STRIDE], 1u);
