@@ -401,12 +401,19 @@ struct ShadowSrcN : ShadowQueue {
     // (the slot is computed once, when the ray is loaded; the walk keeps it in a spare row of the lane's LDS stack until a hit wants it)
     static constexpr bool has_first_candidates = true;
     template <bool TWO_LEVEL>
-    RT_DEV uint32_t cached_leaf(uint32_t, const RayD &r, uint32_t &slot, uint32_t &instance) const
+    RT_DEV uint32_t cached_leaf(uint32_t ticket, const RayD &r, uint32_t &slot, uint32_t &instance) const
     {
         slot = RT_NO_HIT;
         instance = 0u;
         if (!cache.table) return RT_NO_HIT;
-        slot = cache_slot(r);
+        slot = RT_NO_HIT;
+        if (cache.px_base && ticket < 2u * cache.hstride0) {          // a primary hit's ray: its pixel's entry
+            const uint32_t b = ticket >= cache.hstride0 ? 1u : 0u;
+            uint32_t q = cache.jlist0[ticket - b * cache.hstride0];
+            if (cache.n_frames > 1u) q = (__umulhi(q >> 6, cache.frames_magic) << 6) | (q & 63u);      // tile-major slots of a set: chunk = tile * frames + frame
+            if (q < cache.px_slots) slot = cache.px_base + 2u * q + b;
+        }
+        if (slot == RT_NO_HIT) slot = cache_slot(r);
         if (TWO_LEVEL) {
             const uint2 e = ((const uint2 *)cache.table)[slot];
             instance = e.y;
@@ -419,8 +426,7 @@ struct ShadowSrcN : ShadowQueue {
     RT_DEV void remember(uint32_t slot, uint32_t sorted_triangle, uint32_t instance) const
     {
         // (a slot that the stack has overwritten in the meantime is some other number: inside the table it only makes a stale entry)
-        const uint32_t entries = cache.res * cache.res + 6u * (cache.res >> 1) * (cache.res >> 1);
-        if (!cache.table || slot >= entries) return;
+        if (!cache.table || slot >= cache.entries) return;
         if (TWO_LEVEL) ((uint2 *)cache.table)[slot] = make_uint2(sorted_triangle, instance);
         else cache.table[slot] = sorted_triangle;
     }
@@ -750,7 +756,16 @@ int prepare_shadow_cache(rt_pipeline *p, const rt_per_frame_constants &pfc, cons
     if (want > 8192) want = 8192;
     if (want < 16) want = 16;
     const uint32_t res = (uint32_t)want & ~1u;
-    const size_t entries = (size_t)res * res + 6u * (size_t)(res / 2) * (res / 2), entry_bytes = s->two_level ? 8 : 4;
+    // (+ two entries per pixel slot of the output for the primary hits' rays: ShadowCacheDev::px_base.  Measured, profiles/r04/
+    // shadow_cache_pixels.txt: two-level scenes -7 % on the any-hit stage (4096 instances: 4.52 -> 4.40 ms); single-level scenes +3 % --
+    // their primary hits' rays no longer seed the light-space cells the secondary hits' rays read.  So: on for two-level scenes;
+    // RT_SHADOW_CACHE_PIXELS=0 / 1 overrides)
+    static const int per_pixel_env = getenv("RT_SHADOW_CACHE_PIXELS") ? atoi(getenv("RT_SHADOW_CACHE_PIXELS")) : -1;
+    const bool per_pixel = per_pixel_env < 0 ? s->two_level : per_pixel_env != 0;
+    const size_t cells = (size_t)res * res + 6u * (size_t)(res / 2) * (res / 2);
+    const size_t px_slots = per_pixel ? (size_t)((p->width + 7u) / 8u) * ((p->height + 7u) / 8u) * 64u : 0;
+    const size_t entries = cells + 2 * px_slots, entry_bytes = s->two_level ? 8 : 4;
+    if (entries >= 0xffffffffull) return RT_OK;
     if (p->shadow_cache.bytes < entries * entry_bytes) { RT_TRY(p->shadow_cache.reserve(entries * entry_bytes)); p->shadow_cache_gen = 0xffffffffu; }
     if (lr.on == 0xffffffffu) return RT_OK;            // (rt_pipeline_reserve_batch: the allocation only)
     if (p->shadow_cache_gen != s->generation) {
@@ -772,6 +787,9 @@ int prepare_shadow_cache(rt_pipeline *p, const rt_per_frame_constants &pfc, cons
     c.res = res; c.res_f = (float)res;
     c.two_level = s->two_level ? 1u : 0u;
     c.n_tris = s->two_level ? 0u : s->inst[0].model->n_tris;
+    c.entries = (uint32_t)entries;
+    c.px_base = px_slots ? (uint32_t)cells : 0u;
+    c.px_slots = (uint32_t)px_slots;                 // (launch_frame fills in what belongs to the launch: jlist0, hstride0, the set's frames)
     // two unit vectors across the direction to the light
     const float d[3] = {lr.dir_to_light[0], lr.dir_to_light[1], lr.dir_to_light[2]};
     const float ref[3] = {fabsf(d[1]) < 0.9f ? 0.0f : 1.0f, fabsf(d[1]) < 0.9f ? 1.0f : 0.0f, 0.0f};
@@ -975,6 +993,11 @@ int launch_frame(rt_pipeline *p, PipeDev &pd, uint32_t shadow_slots, bool counte
         sq.lights = lr;
         sq.frame_lights = B ? pd.frame_lights : nullptr;
         sq.cache = p->shadow_cache_dev;
+        sq.cache.jlist0 = pd.lv[0].jlist;
+        sq.cache.hstride0 = pd.lv[0].hstride;
+        sq.cache.n_frames = pd.n_frames;
+        sq.cache.frames_magic = (uint32_t)(0x100000000ull / (pd.n_frames ? pd.n_frames : 1u)) + 1u;
+        if (sq.cache.px_slots > pd.fcap) sq.cache.px_slots = pd.fcap;
         const size_t rays_max = sh_total << pd.sh_log2;
         if (B) k_trace_shadow<STACK, TWO_LEVEL, true><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL, true>, PBLOCK, rays_max), PBLOCK, 0, st>>>(
             pd.sc, sq, pd.pools, &pd.counters[C_SHADOW]);

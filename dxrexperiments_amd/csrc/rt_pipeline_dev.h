@@ -79,6 +79,15 @@ struct ShadowCacheDev {
     uint32_t res;
     uint32_t two_level;         // entries are (triangle, instance) pairs of 8 B: the triangle index counts inside that instance's BLAS
     uint32_t n_tris;            // single level: triangles of the one model (an entry at or above it is not tested)
+    // Per-PIXEL entries for the shadow rays of the primary hits (round 4): the primary hit of a pixel is the same point, up to the
+    // frame's sub-pixel jitter, frame after frame, so "the triangle that occluded THIS pixel's ray to this light last time" is a
+    // better first candidate than the light-space cell's, and its table is read in slot order (coalesced).  Entries
+    // px_base + 2 * (pixel slot in the frame) + (0: sun, 1: point light); px_base = 0: off.
+    uint32_t px_base, entries;  // first per-pixel entry; entries in all (remember() checks its slot against it)
+    const uint32_t *jlist0;     // compact primary hit -> pixel slot (LevelDev::jlist of level 0)
+    uint32_t hstride0;          // storage stride of level 0's shadow rays (ray number < 2 * hstride0: a primary hit's ray)
+    uint32_t n_frames, frames_magic;      // frames of the set; floor(2^32 / n_frames) + 1: chunk / n_frames by one mul_hi
+    uint32_t px_slots;          // pixel slots of one frame (an index at or above it falls back to the light-space entry)
 };
 
 #define RT_MAX_BATCH 32u                // frames one set of launches renders (rt_pipeline_render_batch)

@@ -240,7 +240,7 @@ RT_DEV uint32_t distinct_node_lines(int node, bool from_global)
 RT_DEV bool node_is_internal(int node) { return node >= 0 && node < RT_NODE_EMPTY; }
 
 // A ray source may keep a cache of first candidates for unordered any-hit searches (the pipeline's shadow
-// cache): uint32_t cached_leaf(ray index, const RayD &, uint32_t &slot, uint32_t &instance) -> index into the instance's sorted triangle
+// cache): uint32_t cached_leaf(ticket, const RayD &, uint32_t &slot, uint32_t &instance) -> index into the instance's sorted triangle
 // array or RT_NO_HIT, and where a better answer would go; void remember(slot, index, instance).  The walk parks the slot in the last LDS row of the lane's stack (a walk that ever
 // needs that row overwrites it: remember() then finds a number that is not a slot, or is somebody else's -- harmless either way).
 template <class S, class = void> struct src_has_cache { static constexpr bool value = false; };
@@ -410,7 +410,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     if constexpr (src_has_cache<Src>::value && ANYHIT && !COUNT) {
                         // the triangle that answered this question last time goes first: a one-triangle leaf in front of the root
                         uint32_t slot, ci;
-                        const uint32_t ct = src.template cached_leaf<TWO_LEVEL>(my, r, slot, ci);
+                        const uint32_t ct = src.template cached_leaf<TWO_LEVEL>(idx, r, slot, ci);       // (idx: the ray's ticket)
                         st.lds[(STACK - 1) * BLOCK] = (int)slot;
                         // (an entry is only ever tested if it names a triangle that exists: the table is emptied with the scene, but a pair
                         // torn between two writers, or a table handed over by mistake, must not read past an array)
