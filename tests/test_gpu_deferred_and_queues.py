@@ -345,3 +345,33 @@ def test_sponza_1080p_window_against_the_oracle(gpu, capi, oracle):
         a, b = img[y0:y1, x0:x1], acc[y0:y1, x0:x1]
         assert np.array_equal(a, b), "%d of %d window pixels differ" % (int((a != b).any(axis=2).sum()), (x1 - x0) * (y1 - y0))
         assert (b[..., :3] > 0).any() and b[..., 3].min() == 1.0
+
+
+def test_sponza_1080p_whole_frame_against_the_oracle(gpu, capi, oracle):
+    """... and the WHOLE 1920x1080 frame, two accumulated frames, every pixel and every ray count against the CPU restatement (the
+    oracle traces a 1080p frame's 15.9 M rays in about a second per frame on the box's 16 host cores)"""
+    import os
+    W, H = 1920, 1080
+    v, i = scenes.sponza_class()
+    env = scenes.sky_cubemap(64)
+    mat = T.default_material()
+    p = make_gpu_pipeline(capi, gpu, [(v, i)], [(0, None)], [mat], W, H, env=env)
+    osc = make_oracle_scene(oracle, [(v, i)], [(0, None)])
+    host = capi.ProgressiveHost(1234)
+    cam = cam_array(scenes.sponza_camera(), W / H)
+    p.set_deferred(2)
+    p.reset_totals()
+    acc = np.zeros((H, W, 4), np.float32)
+    rays = {"rays_primary": 0, "rays_secondary": 0, "rays_shadow": 0, "primary_hits": 0, "secondary_hits": 0}
+    for f in range(2):
+        pfc = host.update(cam, 0.0, f + 1, W, H)
+        p.update(pfc)
+        p.render()
+        acc, ost = osc.render(mat, pfc, W, H, accum=acc, env_faces=env, nthreads=max(1, len(os.sched_getaffinity(0))))
+        for k in rays:
+            rays[k] += ost[k]
+    img = p.read_output()
+    assert np.array_equal(img, acc), "%d of %d pixels differ" % (int((img != acc).any(axis=2).sum()), W * H)
+    tot = p.totals()
+    for k in rays:
+        assert tot[k] == rays[k], (k, tot[k], rays[k])
