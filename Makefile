@@ -12,7 +12,7 @@ LIB = $(LIBDIR)/$(LIBNAME)
 HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math \
            -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize \
            -Wall -Wno-unused-function -Iinclude $(EXTRA)
-SRCS = $(CSRC)/rt_api.hip $(CSRC)/rt_bvh_build.hip $(CSRC)/rt_bvh_ploc.hip $(CSRC)/rt_bvh_wide.hip $(CSRC)/rt_trace.hip $(CSRC)/rt_pipeline.hip $(CSRC)/rt_pipeline_host.hip $(CSRC)/rt_denoise.hip $(CSRC)/rt_dist.hip \
+SRCS = $(CSRC)/rt_api.hip $(CSRC)/rt_bvh_build.hip $(CSRC)/rt_bvh_ploc.hip $(CSRC)/rt_bvh_wide.hip $(CSRC)/rt_trace.hip $(CSRC)/rt_pipeline.hip $(CSRC)/rt_pipeline_render.hip $(CSRC)/rt_pipeline_host.hip $(CSRC)/rt_denoise.hip $(CSRC)/rt_dist.hip \
        $(CSRC)/rt_obj.cpp $(CSRC)/rt_fbx.cpp $(CSRC)/rt_host.cpp $(CSRC)/rt_dds.cpp $(CSRC)/rt_image.cpp
 HDRS = $(wildcard $(CSRC)/*.h) include/dxr_amd.h include/dxr_amd_types.h
 OBJS = $(patsubst $(CSRC)/%,build/%.o,$(SRCS))

@@ -219,7 +219,6 @@ struct rt_pipeline {
     uint64_t ring_pos = 0;             // frames recorded since enable / reset
     DevBuf totals, work;
     PipeDev last_pd;
-    uint32_t last_shadow_slots = 2;
     rt_stats stats;
     uint32_t last_tile[4] = {0, 0, 0, 0};
     uint32_t last_pixels = 0;
