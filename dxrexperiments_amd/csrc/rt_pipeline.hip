@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_trace_shadow(SceneDe
     ShadowSrcN<BATCH> src;
     static_cast<ShadowQueue &>(src) = queues;
     ShadowSinkN sink = {queues};
-    trace_wave<STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK, RT_SHADOW_UNORDERED != 0>(sc, src, sink, pool, smem, stat);
+    trace_wave<STACK, PBLOCK, TWO_LEVEL, (!TWO_LEVEL && STACK == RT_LDS_STACK_ROWS_SETS) ? RT_POOL_CHUNK_SETS : RT_POOL_CHUNK, RT_SHADOW_UNORDERED != 0>(sc, src, sink, pool, smem, stat);
 }
 
 template <int STACK, bool TWO_LEVEL>
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_trace_secondary(Scen
 {
     __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     SecondarySink sink = {src, hit1, inst1};
-    trace_wave<STACK, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem, stat);
+    trace_wave<STACK, PBLOCK, TWO_LEVEL, (!TWO_LEVEL && STACK == RT_LDS_STACK_ROWS_SETS) ? RT_POOL_CHUNK_SETS : RT_POOL_CHUNK>(sc, src, sink, pool, smem, stat);
 }
 
 // ---- walk counting (rt_pipeline_count_walk): the production walk over the last frame's queues with per-lane

@@ -74,6 +74,9 @@ RT_DEV v4f ldg16(const void *base, size_t byte_off)
 #ifndef RT_POOL_CHUNK
 #define RT_POOL_CHUNK 64u               // rays per chunk of the queue a wave takes at a time (32: 3.55, 64: 3.44, 128: 3.47, 256: 3.57 ms/frame)
 #endif
+#ifndef RT_POOL_CHUNK_SETS
+#define RT_POOL_CHUNK_SETS 128u         // ... in the long launches of sets of frames (round 4, profiles/r04/pool_chunk.txt: 64 / 128 / 256 rays: 1.512 / 1.467 / 1.466 ms per frame
+#endif                                  //     in sets -- and 2.06 / 2.15 / 2.33 ms frame by frame, where the end of a launch is a third of it: single frames keep 64)
 
 #ifndef RT_POOL_GROUPS
 #define RT_POOL_GROUPS 32u              // chunk counters per traversal launch (8: 3.08, 32: 3.07, 128: 3.09, 512: 3.12 ms; static: 3.21)
