@@ -318,21 +318,21 @@ inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + bloc
 // Temporaries of a build over n primitives as slices of the context's build arena (sized for the larger of
 // the LBVH and the PLOC phase, which run one after the other).  A slice that turns out too small makes
 // its DevBuf allocate on its own (DevBuf::reserve), so the sizes here are a fast path, not a contract.
-struct BuildTemps { DevBuf boxes, enc, bounds, tkeys, tsort, tenc, tdepth; };
-int take_build_temps(rt_context *ctx, uint32_t n, BuildTemps &t)
+struct BuildTemps { DevBuf boxes, enc, bounds, tkeys, tsort, tenc, tdepth, extra; };
+int take_build_temps(rt_context *ctx, uint32_t n, BuildTemps &t, size_t extra_bytes = 0)
 {
     const size_t A = 256;
     auto up = [&](size_t b) { return (b + A - 1) & ~(A - 1); };
-    const size_t want[7] = {up(sizeof(Box6) * (size_t)n), A, A, up(8 * (size_t)n), up(16 * (size_t)n + (4u << 20)), up(64 * (size_t)n), A};
+    const size_t want[8] = {up(sizeof(Box6) * (size_t)n), A, A, up(8 * (size_t)n), up(16 * (size_t)n + (4u << 20)), up(64 * (size_t)n), A, up(extra_bytes)};
     size_t lbvh = 0;
     for (size_t w : want) lbvh += w;
     const size_t ploc = rt_ploc_temp_bytes(n), wide = rt_wide_lbvh_temp_bytes(n);
     size_t most = lbvh > ploc ? lbvh : ploc;
     most = most > wide ? most : wide;
     RT_TRY(ctx->build_arena.reserve(most));
-    DevBuf *bufs[7] = {&t.boxes, &t.enc, &t.bounds, &t.tkeys, &t.tsort, &t.tenc, &t.tdepth};
+    DevBuf *bufs[8] = {&t.boxes, &t.enc, &t.bounds, &t.tkeys, &t.tsort, &t.tenc, &t.tdepth, &t.extra};
     size_t at = 0;
-    for (int k = 0; k < 7; k++) { bufs[k]->adopt((char *)ctx->build_arena.p + at, want[k]); at += want[k]; }
+    for (int k = 0; k < 8; k++) { bufs[k]->adopt((char *)ctx->build_arena.p + at, want[k]); at += want[k]; }
     return RT_OK;
 }
 void drop_build_arena_if_large(rt_context *ctx)
@@ -491,6 +491,51 @@ static void invert3x4(const float m[12], float o[12])
     }
 }
 
+// The world box of a transformed instance: the exact box of its triangles' transformed vertices (oracle_bvh.h
+// scene_build; the box of the BLAS box's eight transformed corners is up to 1.6x wider in footprint for a rotated mesh, and a third
+// of all instance entries of the 4096-instance frame were false ones, profiles/r04/tight_boxes.txt).  One block per work item =
+// (instance, chunk of INST_BOX_REFS vertex references); x' = ((m0 x + m1 y) + m2 z) + m3 as the oracle's xform_point; min / max
+// are order free, so the atomics cannot change a bit.
+constexpr unsigned INST_BOX_REFS = 4096;
+__global__ void __launch_bounds__(BOUNDS_BLOCK) k_instance_boxes(const InstanceRec *__restrict__ inst, const float *__restrict__ xf,
+                                                                const uint2 *__restrict__ items, uint32_t *__restrict__ enc)
+{
+    const uint2 it = items[blockIdx.x];
+    const InstanceRec &in = inst[it.x];
+    const float *m = xf + 12u * (size_t)it.x;
+    const uint32_t refs = 3u * in.n_prims;
+    const float inf = __uint_as_float(0x7f800000u);
+    Box6 b;
+    for (int c = 0; c < 3; c++) { b.lo[c] = inf; b.hi[c] = -inf; }
+    for (uint32_t k = it.y * INST_BOX_REFS + threadIdx.x; k < refs && k < (it.y + 1u) * INST_BOX_REFS; k += BOUNDS_BLOCK) {
+        const rt_float3 p = in.verts[in.indices[k]].position;
+        for (int r = 0; r < 3; r++) {
+            float w = m[4 * r + 0] * p.x;
+            w = w + m[4 * r + 1] * p.y;
+            w = w + m[4 * r + 2] * p.z;
+            w = w + m[4 * r + 3];
+            b.lo[r] = fminf(b.lo[r], w);
+            b.hi[r] = fmaxf(b.hi[r], w);
+        }
+    }
+    reduce_bounds(b, true, enc + 6u * (size_t)it.x);
+}
+__global__ void k_instance_boxes_init(uint32_t *enc, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 6u * n) enc[i] = (i % 6u) < 3u ? ENC_POS_INF : ENC_NEG_INF;
+}
+// ... into the instance records and the TLAS builder's leaf boxes (identity instances keep the box of their BLAS)
+__global__ void k_instance_boxes_finish(InstanceRec *__restrict__ inst, const uint32_t *__restrict__ enc, Box6 *__restrict__ boxes, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    InstanceRec &r = inst[i];
+    if (!(r.flags & RT_INST_IDENTITY))
+        for (int c = 0; c < 3; c++) { r.wlo[c] = f_dec(enc[6u * i + c]); r.whi[c] = f_dec(enc[6u * i + 3 + c]); }
+    for (int c = 0; c < 3; c++) { boxes[i].lo[c] = r.wlo[c]; boxes[i].hi[c] = r.whi[c]; }
+}
+
 int rt_build_tlas(rt_context *ctx, rt_scene *s)
 {
     hipStream_t st = ctx->stream;
@@ -498,6 +543,8 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
     static const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     s->h_inst.assign(n, InstanceRec());
     std::vector<Box6> hb(n);
+    std::vector<uint2> items;          // (instance, chunk of its vertex references): the work list of k_instance_boxes
+    std::vector<float> xf;             // the forward transforms, for the same kernel (alive until the build's last synchronisation)
     uint32_t deepest = 0;
     for (uint32_t i = 0; i < n; i++) {
         rt_model *m = s->inst[i].model;
@@ -513,19 +560,7 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
             invert3x4(x, r.inv);
             const float inf = __builtin_inff();
             for (int c = 0; c < 3; c++) { r.wlo[c] = inf; r.whi[c] = -inf; }
-            for (int corner = 0; corner < 8; corner++) {
-                float px = (corner & 1) ? bb[3] : bb[0];
-                float py = (corner & 2) ? bb[4] : bb[1];
-                float pz = (corner & 4) ? bb[5] : bb[2];
-                for (int rr = 0; rr < 3; rr++) {
-                    float w = x[4 * rr + 0] * px;
-                    w = w + x[4 * rr + 1] * py;
-                    w = w + x[4 * rr + 2] * pz;
-                    w = w + x[4 * rr + 3];
-                    r.wlo[rr] = w < r.wlo[rr] ? w : r.wlo[rr];
-                    r.whi[rr] = w > r.whi[rr] ? w : r.whi[rr];
-                }
-            }
+            // (the world box of a transformed instance comes from k_instance_boxes below: empty until then)
         }
         r.root_code = m->blas.root_code;
         r.flags = identity ? RT_INST_IDENTITY : 0u;
@@ -537,24 +572,50 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
         r.normals = m->normals.as<TriRec>();
         r.n_prims = m->n_tris;
         r.material = i;
-        for (int c = 0; c < 3; c++) { hb[i].lo[c] = r.wlo[c]; hb[i].hi[c] = r.whi[c]; }
         deepest = m->blas.fast_depth > deepest ? m->blas.fast_depth : deepest;
+        if (!identity)
+            for (uint32_t c = 0; c * INST_BOX_REFS < 3u * m->n_tris; c++) items.push_back(make_uint2(i, c));
     }
     BuildTemps bt;
     DevBuf &boxes = bt.boxes, &enc = bt.enc, &bounds = bt.bounds, &tkeys = bt.tkeys, &tsort = bt.tsort, &tenc = bt.tenc, &tdepth = bt.tdepth;
+    // (k_instance_boxes' work memory, a slice of the build arena: per-instance encoded bounds, the forward transforms, the work list)
+    const size_t ienc_bytes = (6 * sizeof(uint32_t) * (size_t)n + 255) & ~(size_t)255, ixf_bytes = (12 * sizeof(float) * (size_t)n + 255) & ~(size_t)255;
     int rc = RT_OK;
     do {
-        if ((rc = take_build_temps(ctx, n, bt)) != RT_OK) break;
+        if ((rc = take_build_temps(ctx, n, bt, ienc_bytes + ixf_bytes + items.size() * sizeof(uint2))) != RT_OK) break;
+        uint32_t *const ienc = bt.extra.as<uint32_t>();
+        float *const ixf = (float *)((char *)bt.extra.p + ienc_bytes);
+        uint2 *const iitems = (uint2 *)((char *)bt.extra.p + ienc_bytes + ixf_bytes);
         if ((rc = s->d_inst.reserve(sizeof(InstanceRec) * (size_t)n)) != RT_OK) break;
         if ((rc = boxes.reserve(sizeof(Box6) * (size_t)n)) != RT_OK) break;
         if ((rc = enc.reserve(6 * sizeof(uint32_t))) != RT_OK) break;
         if ((rc = bounds.reserve(6 * sizeof(float))) != RT_OK) break;
-        if (hipMemcpyAsync(s->d_inst.p, s->h_inst.data(), sizeof(InstanceRec) * n, hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(boxes.p, hb.data(), sizeof(Box6) * n, hipMemcpyHostToDevice, st) != hipSuccess) {
+        if (hipMemcpyAsync(s->d_inst.p, s->h_inst.data(), sizeof(InstanceRec) * n, hipMemcpyHostToDevice, st) != hipSuccess) {
             rt_set_error("instance upload failed");
             rc = RT_ERR_HIP;
             break;
         }
+        // world boxes: of the transformed instances from their vertices, then all of them into the records and the leaf boxes
+        k_instance_boxes_init<<<grid_for(6 * n, 256), 256, 0, st>>>(ienc, n);        // (a transformed instance without triangles keeps the empty box)
+        if (!items.empty()) {
+            xf.resize(12 * (size_t)n);
+            for (uint32_t i = 0; i < n; i++) memcpy(&xf[12 * (size_t)i], s->inst[i].xform, 12 * sizeof(float));
+            if (hipMemcpyAsync(ixf, xf.data(), xf.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(iitems, items.data(), items.size() * sizeof(uint2), hipMemcpyHostToDevice, st) != hipSuccess) {
+                rt_set_error("instance upload failed");
+                rc = RT_ERR_HIP;
+                break;
+            }
+            k_instance_boxes<<<(uint32_t)items.size(), BOUNDS_BLOCK, 0, st>>>(s->d_inst.as<InstanceRec>(), ixf, iitems, ienc);
+        }
+        k_instance_boxes_finish<<<grid_for(n, 256), 256, 0, st>>>(s->d_inst.as<InstanceRec>(), ienc, boxes.as<Box6>(), n);
+        if (hipMemcpyAsync(hb.data(), boxes.p, sizeof(Box6) * n, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            rt_set_error("instance box read-back failed");
+            rc = RT_ERR_HIP;
+            break;
+        }
+        for (uint32_t i = 0; i < n; i++)
+            for (int c = 0; c < 3; c++) { s->h_inst[i].wlo[c] = hb[i].lo[c]; s->h_inst[i].whi[c] = hb[i].hi[c]; }
         k_init_bounds<<<1, 64, 0, st>>>(enc.as<uint32_t>());
         k_box_bounds<<<grid_for(n, BOUNDS_BLOCK), BOUNDS_BLOCK, 0, st>>>(boxes.as<Box6>(), n, enc.as<uint32_t>());
         k_decode_bounds<<<1, 64, 0, st>>>(enc.as<uint32_t>(), bounds.as<float>());
@@ -576,5 +637,6 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
                     s->tlas.max_depth, deepest, ctx->use_ploc ? "PLOC" : "LBVH", s->stack_need, s->two_level ? "two-level" : "single-level");
     } while (0);
     boxes.release(); enc.release(); bounds.release(); tkeys.release(); tsort.release(); tenc.release(); tdepth.release();
+    bt.extra.release();
     return rc;
 }

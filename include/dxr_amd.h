@@ -98,6 +98,7 @@ int rt_scene_destroy(rt_scene *s);
  * which = -1: TLAS; which >= 0: BLAS of the model used by instance `which`. */
 int rt_scene_bvh_info(const rt_scene *s, int which, uint32_t *n_prims, uint32_t *n_nodes, uint32_t *max_depth);
 int rt_scene_bvh_read(const rt_scene *s, int which, rt_bvh_node *nodes, uint64_t *sorted_keys, uint32_t *parents);
+/* world_box: the TLAS leaf box of the instance = the exact box of its triangles' transformed vertices (an identity instance: of its BLAS) */
 int rt_scene_instance_info(const rt_scene *s, uint32_t instance, float world_box[6], float world_to_object[12]);
 /* Inspection of the PRODUCTION traversal layout of the same structures (tests, tools).  rt_wide_layout_info tells which
  * of the two layouts the library was built with.

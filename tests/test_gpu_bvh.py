@@ -58,6 +58,45 @@ def test_instanced_scene(gpu, oracle, capi):
         assert np.array_equal(gb, ob) and np.array_equal(gi, oi)
 
 
+def world_box_of_vertices(v, idx, m):
+    """the definition (oracle_bvh.h scene_build): exact box of the triangles' transformed vertices, x' = ((m0 x + m1 y) + m2 z) + m3 in fp32"""
+    p = v["position"][np.asarray(idx).reshape(-1)].astype(np.float32)
+    m = np.asarray(m, np.float32).reshape(3, 4)
+    w = np.stack([((m[r, 0] * p[:, 0] + m[r, 1] * p[:, 1]) + m[r, 2] * p[:, 2]) + m[r, 3] for r in range(3)], axis=1)
+    return np.concatenate([w.min(axis=0), w.max(axis=0)])
+
+
+def test_instance_world_boxes_are_the_boxes_of_the_transformed_vertices(gpu, oracle, capi):
+    """k_instance_boxes: meshes of one work item (3840 vertex references), of four (15360) and of a single triangle, plus an unreferenced
+    far-away vertex that must not count; GPU == oracle == the numpy statement of the definition, and tighter than the eight corners"""
+    small, big = scenes.blob_mesh(level=3), scenes.blob_mesh(seed=5, level=4)
+    one = triangle_soup(1, seed=9)
+    bv = np.concatenate([big[0], big[0][:1]])
+    bv["position"][-1] = (1e6, -1e6, 1e6)
+    big = (bv, big[1])
+    xf = random_xforms(24, seed=11)
+    models = [small, big, one]
+    inst = [(k % 3, xf[k]) for k in range(24)] + [(1, None)]
+    p = Pair(oracle, capi, gpu, models, inst)
+    check_bvh(p, -1)
+    looser = 0
+    for k in range(24):
+        gb, gi = p.g.instance_info(k)
+        ob, oi = p.o.instance_info(k)
+        want = world_box_of_vertices(*models[k % 3], xf[k])
+        assert np.array_equal(gb, ob) and np.array_equal(gi, oi) and np.array_equal(gb, want), k
+        lo, hi = models[k % 3][0]["position"][np.asarray(models[k % 3][1]).reshape(-1)].min(axis=0), models[k % 3][0]["position"][np.asarray(models[k % 3][1]).reshape(-1)].max(axis=0)
+        corners = np.array([[(hi if c & 1 else lo)[0], (hi if c & 2 else lo)[1], (hi if c & 4 else lo)[2]] for c in range(8)], np.float64)
+        m = xf[k].reshape(3, 4).astype(np.float64)
+        cw = corners @ m[:, :3].T + m[:, 3]
+        assert (gb[:3] >= cw.min(axis=0) - 1e-4).all() and (gb[3:] <= cw.max(axis=0) + 1e-4).all()
+        looser += int(np.prod(cw.max(axis=0) - cw.min(axis=0)) > 1.2 * np.prod((gb[3:] - gb[:3]).astype(np.float64)))
+    assert looser >= 8              # the blobs: a rotated box's box is much wider than the rotated mesh's
+    gb, _ = p.g.instance_info(24)   # the identity instance keeps the box of its BLAS
+    nodes = p.o.bvh(1)[0]
+    assert np.array_equal(gb[:3], nodes["bmin"][0]) and np.array_equal(gb[3:], nodes["bmax"][0])
+
+
 def test_sponza_class_full(gpu, oracle, capi):
     v, i = scenes.sponza_class()
     p = Pair(oracle, capi, gpu, [(v, i)], [(0, None)])

@@ -182,6 +182,23 @@ def test_lbvh_duplicates_and_tlas(oracle):
     assert np.array_equal(box[:3], nodes["bmin"][0]) and np.array_equal(box[3:], nodes["bmax"][0])
 
 
+def test_instance_world_box_is_the_box_of_the_transformed_vertices(oracle):
+    """oracle_bvh.h scene_build: a transformed instance's world box is the exact fp32 box of its triangles' transformed vertices"""
+    blob = scenes.blob_mesh(level=2)
+    xf = random_xforms(6, seed=4)
+    sc = oracle.Scene()
+    m = sc.add_model(*blob)
+    for x in xf:
+        sc.add_instance(m, x)
+    sc.build()
+    p = blob[0]["position"][np.asarray(blob[1]).reshape(-1)].astype(np.float32)
+    for k, x in enumerate(xf):
+        a = x.reshape(3, 4)
+        w = np.stack([((a[r, 0] * p[:, 0] + a[r, 1] * p[:, 1]) + a[r, 2] * p[:, 2]) + a[r, 3] for r in range(3)], axis=1)
+        box, _ = sc.instance_info(k)
+        assert np.array_equal(box, np.concatenate([w.min(axis=0), w.max(axis=0)]))
+
+
 def test_bvh_equals_brute_force(oracle):
     blob = scenes.blob_mesh(level=2)
     soup = triangle_soup(300, seed=2, extent=1.5, size=0.4)
