@@ -44,23 +44,59 @@ CASES = {
     "susanne_default": ({}, {}, {"scene": "susanne"}),
     "susanne_glass_uniform": ({"cosineHemisphereSampling": 0, "environmentStrength": 1.5}, {"type": 2, "roughness": 0.2, "reflectivity": 0.9}, {"scene": "susanne"}),
     "susanne_own_lights": ({}, {"type": 1, "roughness": 0.7}, {"scene": "susanne", "sun": (-0.2, -0.5, -1.0), "lamp": (0.6, 0.9, 1.4)}),
+    # (round 4) instance transforms: three rotated, scaled and shifted instances of the same mesh.  The oracle (like the kernels) takes
+    # the ray into each instance's object space and requires the instance's world box to pass; this restatement moves the VERTICES into
+    # world space and intersects there -- the two agree only if the inverse transform, the ray transform and "t is the same number
+    # in both spaces" are right.  Normals stay object-space vectors in both: the reference's shaders never apply ObjectToWorld.
+    "instances_default": ({}, {}, {"scene": "instances"}),
+    "instances_glass": ({"cosineHemisphereSampling": 0}, {"type": 2, "roughness": 0.3, "reflectivity": 0.8}, {"scene": "instances", "lamp": (0.0, 2.5, 2.0), "sun": (0.3, -1.0, -0.4)}),
 }
+
+
+def instance_transforms():
+    """three rigid-plus-scale transforms (3x4 row-major float32): rotations about y, x and z, scales 0.8 / 1.1 / 0.6, shifts apart"""
+    out = []
+    for a, axis, s, t in ((0.7, 1, 0.8, (-1.4, 0.0, 0.0)), (-0.5, 0, 1.1, (1.3, 0.2, -0.6)), (2.1, 2, 0.6, (0.0, 1.5, 0.4))):
+        c, sn = np.cos(a), np.sin(a)
+        r = np.eye(3)
+        i, j = [(1, 2), (2, 0), (0, 1)][axis]
+        r[i, i] = c; r[i, j] = -sn; r[j, i] = sn; r[j, j] = c
+        m = np.zeros((3, 4))
+        m[:, :3] = r * s
+        m[:, 3] = t
+        out.append(m.astype(np.float32).reshape(12))
+    return out
 
 
 def run_case(options, material, setup=None):
     from oracle import pyoracle as O
     setup = setup or {}
-    if setup.get("scene") == "susanne":
+    xforms = [None]
+    if setup.get("scene") in ("susanne", "instances"):
         v, tri = O.obj_load(os.path.join(HERE, "golden", "susanne.obj"))
         cam = np.array([1.2, 0.8, 3.6, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.7, W / H], np.float32)
+        if setup["scene"] == "instances":
+            xforms = instance_transforms()
+            cam = np.array([0.6, 1.4, 5.2, 0.0, 0.4, 0.0, 0.0, 1.0, 0.0, 0.8, W / H], np.float32)
     else:
         v, tri = O.obj_load(os.path.join(HERE, "golden", "cornell.obj"))
         c = scenes.cornell_camera()
         cam = np.array([*c["eye"], *c["at"], *c["up"], c["fov"], W / H], np.float32)
     sc = O.Scene()
-    sc.add_instance(sc.add_model(v, tri))
+    model = sc.add_model(v, tri)
+    for x in xforms:
+        sc.add_instance(model, x)
     sc.build()
-    nsc = NV.Scene(v["position"], v["normal"], tri)
+    # the second restatement sees ONE triangle list in world space: instance k's triangles are numbers k * n .. k * n + n - 1
+    pos, nrm, idx = [], [], []
+    for k, x in enumerate(xforms):
+        p = v["position"].astype(np.float32)
+        if x is not None:
+            m = x.reshape(3, 4)
+            p = (p @ m[:, :3].T + m[:, 3]).astype(np.float32)
+        pos.append(p); nrm.append(v["normal"]); idx.append(np.asarray(tri).reshape(-1, 3) + k * v.shape[0])
+    nsc = NV.Scene(np.concatenate(pos), np.concatenate(nrm), np.concatenate(idx))
+    n_tris = np.asarray(tri).reshape(-1, 3).shape[0]
     mat = T.default_material()
     for k, val in material.items():
         mat[k] = val
@@ -85,19 +121,29 @@ def run_case(options, material, setup=None):
         o = np.concatenate([o3, np.zeros((W * H, 1), np.float32)], axis=1)
         d = np.concatenate([d3, np.full((W * H, 1), 1.0e38, np.float32)], axis=1)
         h = sc.trace(o, d, flags=T.RAY_FLAG_CULL_BACK_FACING_TRIANGLES, mode=0)
-        want = np.where(h["inst"] == T.RT_NO_HIT, -1, h["prim"].astype(np.int64))
+        want = np.where(h["inst"] == T.RT_NO_HIT, -1, h["inst"].astype(np.int64) * n_tris + h["prim"].astype(np.int64))
         ids_equal = ids_equal and np.array_equal(want, prim)
     diff = acc2.astype(np.float64) - acc.astype(np.float64)
+    # pixels where a secondary or shadow ray met ANOTHER triangle in the two restatements (a grazing ray decided by the last bit of an
+    # intersection computed in object space by one and in world space by the other; only the instanced cases may have any)
+    flipped = np.abs(diff).max(axis=2) > 1e-3
     return {"rms": float(np.sqrt((diff ** 2).mean())), "max_abs": float(np.abs(diff).max()), "hit_ids_equal": bool(ids_equal),
-            "mean": float(acc[..., :3].mean())}
+            "mean": float(acc[..., :3].mean()), "flipped_pixels": int(flipped.sum()),
+            "rms_unflipped": float(np.sqrt((diff[~flipped] ** 2).mean()))}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_second_restatement_agrees_with_the_oracle(name):
     r = run_case(*CASES[name])
     assert r["hit_ids_equal"], "primary hit ids differ between the oracle's BVH walk and brute force"
-    assert r["rms"] <= 1e-5, r
     committed = json.load(open(os.path.join(HERE, "golden", "reference_assets.json")))["nversion_shading"][name]
+    if name.startswith("instances"):
+        # object-space against world-space intersection: a grazing secondary ray may fall on the other side of an edge; at most
+        # 6 of the 1024 pixels (measured: 1 and 4), and everything else within the tolerance
+        assert r["flipped_pixels"] <= 6 and r["rms_unflipped"] <= 1e-5, r
+        assert abs(r["mean"] - committed["mean"]) <= 1e-4, (r, committed)
+        return
+    assert r["rms"] <= 1e-5 and r["flipped_pixels"] == 0, r
     assert abs(r["mean"] - committed["mean"]) <= 1e-5 and r["rms"] <= max(10 * committed["rms"], 1e-6), (r, committed)
 
 
