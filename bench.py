@@ -585,11 +585,13 @@ def tiles_main(args, rank, world, local_rank, dev, capi, D, T, scenes, torch, di
     if world > 1:
         D.gather_tiles(acc.clone(), band)             # warm the collective
         dist.barrier()
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))       # (first use before the timed region, as in main())
+    ev[0].record(); ev[1].record()
     torch.cuda.synchronize()
+    ev[0].elapsed_time(ev[1])
     pipe.reset_totals()
     t0 = time.perf_counter()
     steps(Wu, Wu + K)
-    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     ev[0].record()
     if world > 1:
         D.gather_tiles(acc, band)
@@ -722,9 +724,16 @@ def main():
         pipeline and rendered in sets of per_set frames; the last, possibly partial, set is flushed before this returns"""
         per_set = S if per_set is None else per_set
         pipe.set_deferred(per_set if per_set > 1 else 0)
+        ta = time.perf_counter()
         for i in range(lo, hi):
             step(i)
+        tb = time.perf_counter()
         pipe.flush()
+        if os.environ.get("DXR_BENCH_TRACE"):          # where the host's time goes (diagnostic)
+            tc = time.perf_counter()
+            torch.cuda.synchronize()
+            sys.stderr.write("[bench] frames %d..%d: update+render calls %.2f ms, flush %.2f ms, sync %.2f ms\n"
+                             % (lo, hi, (tb - ta) * 1e3, (tc - tb) * 1e3, (time.perf_counter() - tc) * 1e3))
 
     if S > 1:
         pipe.reserve_batch(S)           # the work memory of a set of S frames: sized outside the timed region, like the output
@@ -740,7 +749,13 @@ def main():
     steps(0, Wu)
     if world > 1:                       # warm the collective too
         dist.all_reduce(torch.zeros_like(acc))
+    # ... and everything else the timed region calls for the first time in this process: on a box whose page cache is cold a first
+    # call into a library can cost tens of milliseconds of disk reads (one driver-form run of round 4 read 7.7 ms per step with
+    # normal per-kernel times; profiles/r04/preroll.txt)
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev[0].record(); ev[1].record()
     torch.cuda.synchronize()
+    ev[0].elapsed_time(ev[1])
     if not args.no_roofline:
         pipe.enable_timing(K)
     pipe.reset_totals()
@@ -750,7 +765,6 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     steps(Wu, Wu + K)
-    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     ev[0].record()
     if world > 1:
         mean, n_frames = D.reduce_accumulation(acc, Wu + K)
