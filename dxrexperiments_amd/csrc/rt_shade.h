@@ -184,7 +184,7 @@ template <class IO>
 RT_DEV f3 ambient_occlusion(const PipeDev &pd, IO &io, f3 P, f3 N, uint32_t pix)
 {
     float visibility = 0.0f;
-    uint32_t seed = init_rand(pix, pd.pfc.cameraParams.frameCount);
+    uint32_t seed = io.pixel_seed(pix);      // initRand(pixel, frameCount): the shaders re-seed in every shade() call of the pixel
     for (int i = 0; i < 4; ++i) {
         f3 dir; float NoL, pdf;
         if (pd.pfc.options.cosineHemisphereSampling) {
@@ -209,7 +209,7 @@ RT_DEV f3 shade(const PipeDev &pd, IO &io, const rt_material_params &mp, f3 P, f
     const rt_debug_options &opt = pd.pfc.options;
     if (opt.showAmbientOcclusionOnly) return ambient_occlusion(pd, io, P, N, pix);
 
-    uint32_t seed = init_rand(pix, pd.pfc.cameraParams.frameCount);
+    uint32_t seed = io.pixel_seed(pix);      // initRand(pixel, frameCount): the shaders re-seed in every shade() call of the pixel
 
     f3 direct = mk3(0.0f, 0.0f, 0.0f);
     if (opt.debug == 2) {
@@ -271,7 +271,7 @@ template <class IO>
 RT_DEV f3 shade_aov(const PipeDev &pd, IO &io, const rt_material_params &mp, f3 P, f3 N, f3 D, uint32_t depth, uint32_t pix,
                     f3 &aov_direct, f3 &aov_indirect)
 {
-    uint32_t seed = init_rand(pix, pd.pfc.cameraParams.frameCount);
+    uint32_t seed = io.pixel_seed(pix);      // initRand(pixel, frameCount): the shaders re-seed in every shade() call of the pixel
     f3 direct = mk3(0.0f, 0.0f, 0.0f);
     direct = direct + directional_light(pd, io, P, N, depth);
     direct = direct + point_light(pd, io, P, N, depth);
@@ -354,6 +354,7 @@ struct EmitIO {
     {
         shadow_origin = mk3(0.0f, 0.0f, 0.0f);
     }
+    RT_DEV uint32_t pixel_seed(uint32_t pix) const { return init_rand(pix, pd.pfc.cameraParams.frameCount); }
     // matters = false: whatever this ray finds is multiplied by zero by the caller
     RT_DEV float shadow(int s, f3 o, f3 d, float tmin, float tmax, uint32_t depth, bool matters)
     {
@@ -397,7 +398,11 @@ template <int L, int MAXL>
 struct ResolveIO {
     const PipeDev &pd;
     uint32_t idx, pix;
-    RT_DEV ResolveIO(const PipeDev &p, uint32_t i, uint32_t px) : pd(p), idx(i), pix(px) {}
+    uint32_t seed0;             // initRand(pixel, frameCount): every shade() of the pixel starts from it, so the 16 rounds run once per
+                                //   pixel and not once per level of the inline recursion (-10 % of k_resolve's instructions)
+    RT_DEV ResolveIO(const PipeDev &p, uint32_t i, uint32_t px) : pd(p), idx(i), pix(px), seed0(init_rand(px, p.pfc.cameraParams.frameCount)) {}
+    RT_DEV ResolveIO(const PipeDev &p, uint32_t i, uint32_t px, uint32_t seed) : pd(p), idx(i), pix(px), seed0(seed) {}
+    RT_DEV uint32_t pixel_seed(uint32_t) const { return seed0; }
     RT_DEV float shadow(int s, f3, f3, float, float, uint32_t depth, bool matters)
     {
         if (depth >= pd.max_shadow) return 1.0f;
@@ -416,7 +421,7 @@ struct ResolveIO {
             if (h.x == HIT_UNTRACED) return mk3(0.0f, 0.0f, 0.0f);
             RayD r;
             r.o = o; r.tmin = tmin; r.d = d; r.tmax = RAY_MAX_T;
-            ResolveIO<L + 1, MAXL> io(pd, pd.lv[L + 1].slot_j[slot], pix);
+            ResolveIO<L + 1, MAXL> io(pd, pd.lv[L + 1].slot_j[slot], pix, seed0);
             return closest_hit(pd, io, r, h.x, h.y, h.z, __float_as_uint(h.w), pd.lv[L + 1].inst[slot], depth + 1u, pix);
         }
     }
@@ -431,6 +436,7 @@ struct LevelResolveIO {
     int L;
     uint32_t idx;
     RT_DEV LevelResolveIO(const PipeDev &p, int level, uint32_t i) : pd(p), L(level), idx(i) {}
+    RT_DEV uint32_t pixel_seed(uint32_t pix) const { return init_rand(pix, pd.pfc.cameraParams.frameCount); }
     RT_DEV float shadow(int s, f3, f3, float, float, uint32_t depth, bool matters)
     {
         if (depth >= pd.max_shadow) return 1.0f;
