@@ -719,16 +719,22 @@ def main():
         pipe.update(pfcs[mine[i]])
         pipe.render()
 
+    host_ms = {}                # the host's side of the last steps() call: time inside the update() + render() calls, the slowest one, the flush
+
     def steps(lo, hi, per_set=None):
         """frames lo..hi-1 of this rank, one update() + render() each: rendered at once (per_set 1), or recorded by the deferred
         pipeline and rendered in sets of per_set frames; the last, possibly partial, set is flushed before this returns"""
         per_set = S if per_set is None else per_set
         pipe.set_deferred(per_set if per_set > 1 else 0)
         ta = time.perf_counter()
+        slowest = 0.0
         for i in range(lo, hi):
+            t1 = time.perf_counter()
             step(i)
+            slowest = max(slowest, time.perf_counter() - t1)
         tb = time.perf_counter()
         pipe.flush()
+        host_ms.update(calls=(tb - ta) * 1e3, slowest_call=slowest * 1e3, flush=(time.perf_counter() - tb) * 1e3)
         if os.environ.get("DXR_BENCH_TRACE"):          # where the host's time goes (diagnostic)
             tc = time.perf_counter()
             torch.cuda.synchronize()
@@ -753,9 +759,10 @@ def main():
     # call into a library can cost tens of milliseconds of disk reads (one driver-form run of round 4 read 7.7 ms per step with
     # normal per-kernel times; profiles/r04/preroll.txt)
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    ev[0].record(); ev[1].record()
+    span = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))     # the device's own clock around the K steps
+    ev[0].record(); ev[1].record(); span[0].record(); span[1].record()
     torch.cuda.synchronize()
-    ev[0].elapsed_time(ev[1])
+    ev[0].elapsed_time(ev[1]); span[0].elapsed_time(span[1])
     if not args.no_roofline:
         pipe.enable_timing(K)
     pipe.reset_totals()
@@ -764,13 +771,19 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    span[0].record()
     steps(Wu, Wu + K)
+    span[1].record()
+    timed_host_ms = dict(host_ms)
     ev[0].record()
     if world > 1:
         mean, n_frames = D.reduce_accumulation(acc, Wu + K)
     ev[1].record()
+    t_sync = time.perf_counter()
     torch.cuda.synchronize()
     mine_elapsed = time.perf_counter() - t0
+    timed_host_ms["wait_for_the_device"] = (time.perf_counter() - t_sync) * 1e3
+    timed_host_ms["device_span_of_the_steps"] = span[0].elapsed_time(span[1])       # first to last command of the K steps, by the device's events
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -814,6 +827,9 @@ def main():
             "reference_ray_budget_mrays_per_s": (rays_all + skipped_all) / elapsed / 1e6,
             "shadow_rays_not_traversed_per_frame": skipped_all / (K * world),
             "bvh_build_ms": build_ms, "bvh_rebuild_ms": rebuild_ms,
+            # the host's side of the timed region: time inside the K update() + render() calls (deferred mode: the last one enqueues the
+            # set), the slowest single call, the explicit flush, then the wait for the device.  Kernel time is in `stages`.
+            "timed_region_host_ms": timed_host_ms,
             "ranks": report,
         }
         if not args.no_roofline:
@@ -846,6 +862,24 @@ def main():
                                      "note": "the same update() + render() calls with deferred mode off (rt_pipeline_set_deferred(0)): every frame is rendered "
                                              "by its own set of launches before render() returns -- what an application that presents every frame gets; "
                                              "same frames, same bits; `value` above renders them %d per set of launches" % S}
+        if world == 1 and not args.no_sample_batches:
+            # the timed steps ONCE MORE, now that the process has rendered for a while: how much of `value` is the state the chip and
+            # the shadow cache are in when the K steps start right after W = 5 warm-up frames (say the spread in the line)
+            pipe.clear_output()
+            steps(0, Wu)
+            ctx.synchronize()
+            pipe.reset_totals()
+            tr0 = time.perf_counter()
+            steps(Wu, Wu + K)
+            ctx.synchronize()
+            tr = time.perf_counter() - tr0
+            totr = pipe.totals()
+            raysr = totr["rays_primary"] + totr["rays_secondary"] + totr["rays_shadow"] - totr["rays_shadow_skipped"]
+            out["repeat_of_timed_steps"] = {"ms_per_step": tr / K * 1e3, "Mrays_per_s": raysr / tr / 1e6, "value_over_repeat": (rays_all / elapsed) / (raysr / tr),
+                                            "note": "the same W warm-up and K timed steps again at the end of this run (same calls, same frames, same bits). "
+                                                    "`value` is the FIRST pass; measured over rounds 3 - 4 it reads 3 - 7 % below this one (chip power state "
+                                                    "after the idle set-up phase, a shadow cache still filling: profiles/r04/warmup_sensitivity.txt, preroll.txt) "
+                                                    "and varies +-1.5 % from box to box"}
         if world == 1 and args.hbm_frames > 0 and not args.no_roofline:
             del pipe, scene, model
             hb = HBM_SET if S > 1 else 1                       # like the headline: sets of frames

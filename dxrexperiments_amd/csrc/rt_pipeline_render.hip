@@ -182,6 +182,20 @@ int prepare_shadow_cache(rt_pipeline *p, const rt_per_frame_constants &pfc, cons
     return RT_OK;
 }
 
+// The scene as a set of n_frames frames over `cap` pixel slots walks it: which kernels (LDS stack rows) and the global stack rows
+// behind them -- (tree bound - LDS rows) x 4 B per thread of the largest launch, and the primary stage of a single-level scene runs
+// one thread per pixel slot: 4.3 GB for 20 frames of 1080p.  Insurance that is never touched on the bench scene, but an allocation:
+// rt_pipeline_reserve_batch makes it too (round 4: on some boxes that hipMalloc took 126 ms of the first set's render() call).
+int scene_for_set(rt_pipeline *p, uint32_t n_frames, size_t cap, SceneDev *out, bool *sets_kernels = nullptr)
+{
+    rt_context *ctx = p->ctx;
+    static const bool seven_waves_always = getenv("RT_SEVEN_WAVES_ALWAYS") && atoi(getenv("RT_SEVEN_WAVES_ALWAYS")) != 0;      // (experiment: single frames on the sets' kernels)
+    const bool set_rows = (n_frames > 1 || seven_waves_always) && !p->scene->two_level && ctx->lds_stack_rows != RT_LDS_STACK_ROWS_TEST && RT_LDS_STACK_ROWS_SETS != RT_LDS_STACK_ROWS;
+    const size_t resident = (size_t)ctx->cu_count * 16u * PBLOCK;
+    if (sets_kernels) *sets_kernels = set_rows;
+    return rt_scene_dev_for_launch(ctx, p->scene, set_rows ? RT_LDS_STACK_ROWS_SETS : rt_lds_stack_rows(ctx), cap > resident ? cap : resident, out);
+}
+
 }  // namespace
 
 extern "C" {
@@ -239,9 +253,8 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     }
     PipeDev pd;
     // (threads of the largest launch: the primary stage runs one thread per pixel slot, the persistent stages fewer)
-    static const bool seven_waves_always = getenv("RT_SEVEN_WAVES_ALWAYS") && atoi(getenv("RT_SEVEN_WAVES_ALWAYS")) != 0;      // (experiment: single frames on the sets' kernels)
-    const bool set_rows = (n_frames > 1 || seven_waves_always) && !p->scene->two_level && ctx->lds_stack_rows != RT_LDS_STACK_ROWS_TEST && RT_LDS_STACK_ROWS_SETS != RT_LDS_STACK_ROWS;
-    RT_TRY(rt_scene_dev_for_launch(ctx, p->scene, set_rows ? RT_LDS_STACK_ROWS_SETS : rt_lds_stack_rows(ctx), cap > ctx->cu_count * 16u * PBLOCK ? cap : ctx->cu_count * 16u * PBLOCK, &pd.sc));
+    bool set_rows = false;
+    RT_TRY(scene_for_set(p, n_frames, cap, &pd.sc, &set_rows));
     pd.pfc = frames[0];
     pd.n_frames = n_frames; pd.fcap = fcap;
     pd.pfcs = nullptr; pd.frame_lights = nullptr;
@@ -501,7 +514,9 @@ int rt_pipeline_reserve_batch(rt_pipeline *p, uint32_t width, uint32_t height, u
     if (worst_case_queue_bytes(cap, levels_now, p->max_shadow, ao_view ? 4u : 2u, !ao_view) > queue_budget(p)) RT_TRY(reserve_level_rays(p, 0, cap, levels_now > 1));
     else RT_TRY(reserve_worst_case(p, cap, levels_now, p->max_shadow, ao_view ? 4u : 2u, !ao_view));
     if (frames > 1) RT_TRY(p->batch_consts.reserve((sizeof(rt_per_frame_constants) + sizeof(LightRays)) * RT_MAX_BATCH));
-    if (p->scene) {                                    // the shadow cache's table as well
+    if (p->scene && p->scene->built) {                 // the traversal kernels' global stack rows and the shadow cache's table as well
+        SceneDev sc;
+        RT_TRY(scene_for_set(p, frames, cap, &sc));
         LightRays only_allocate = no_light_rays();
         only_allocate.on = 0xffffffffu;
         RT_TRY(prepare_shadow_cache(p, p->pfc, only_allocate));

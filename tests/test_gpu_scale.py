@@ -191,6 +191,12 @@ def test_bench_two_ranks_on_one_gpu():
     assert d1["config"]["queue_memory_bytes_per_frame"] > 0
     fb = d1["frame_by_frame"]
     assert fb["frames"] == 4 and fb["ms_per_frame"] > 0 and fb["Mrays_per_s"] > 0
+    # the host's side of the timed region and the same steps once more at the end of the run (the line states its own spread)
+    hm = d1["timed_region_host_ms"]
+    assert all(hm[k] >= 0.0 for k in ("calls", "slowest_call", "flush", "wait_for_the_device", "device_span_of_the_steps"))
+    assert hm["device_span_of_the_steps"] <= d1["ms_per_step"] * d1["steps"] * 1.05 + 0.5
+    rp = d1["repeat_of_timed_steps"]
+    assert rp["ms_per_step"] > 0 and 0.2 < rp["value_over_repeat"] < 5.0
     rl = d1["roofline"]
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "frames_per_launch", "memory_path", "algorithmic_bytes",
               "compulsory_bytes", "lane_utilisation"):
