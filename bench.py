@@ -581,6 +581,8 @@ def tiles_main(args, rank, world, local_rank, dev, capi, D, T, scenes, torch, di
             for i in range(lo, hi, S):
                 pipe.render_bands_batch(band, rank, world, pfcs[i:min(i + S, hi)])
 
+    if S > 1:                                         # the work memory of a full set of this rank's bands: outside the timed region
+        pipe.reserve_batch(min(S, K), rows=sum(1 for r in range(H) if (r // band) % world == rank))
     steps(0, Wu)
     if world > 1:
         D.gather_tiles(acc.clone(), band)             # warm the collective

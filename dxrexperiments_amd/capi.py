@@ -551,9 +551,10 @@ class Pipeline:
         _check(lib().rt_pipeline_get_free_sphere(self.h, C.byref(r)))
         return r.value
 
-    def reserve_batch(self, frames):
-        """Size the ray queues for sets of `frames` frames now (the first render_batch of that size then allocates nothing)."""
-        _check(lib().rt_pipeline_reserve_batch(self.h, self.width, self.height, int(frames)))
+    def reserve_batch(self, frames, rows=None):
+        """Reserve the work memory of sets of `frames` frames now (the first set of that size then allocates nothing); rows: the
+        packed rows of a rank's bands (render_bands_batch) instead of the whole height."""
+        _check(lib().rt_pipeline_reserve_batch(self.h, self.width, self.height if rows is None else int(rows), int(frames)))
 
     def render_bands(self, band_rows, rank, world):
         """One frame over this rank's interleaved row bands (tile-partitioned multi-GPU runs)."""
