@@ -5,6 +5,7 @@ shade() the GPU kernels are compared with, and the kernels were written by the s
 both would be invisible.  This file was written from the HLSL text alone --
 
     assets/shaders/ProgressiveRaytracing.hlsl:11-182   RayGen, shootSecondaryRay, evaluateIndirectDiffuse, shade, hit / miss shaders
+    assets/shaders/RealtimeRaytracing.hlsl:22-126      (round 4) the realtime pipeline's RayGen, shadeAOV, hit / miss shaders: two AOVs
     assets/shaders/RaytracingCommon.hlsli:53-159       interpolateVertexAttributes, shootShadowRay, evaluateAO, the two lights, env
     assets/shaders/RaytracingUtils.hlsli:22-130,209    M_PI, initRand, nextRand, perpendicular vector, the three samplers, Fresnel
 
@@ -340,3 +341,76 @@ def render_frame(scene, pfc, mat, W, H, prev, env_rgb=(0.5, 0.5, 0.5)):
     cnt = f32(cp["accumCount"])
     out = (cnt * prev + cur) / (cnt + f32(1.0))
     return out.astype(f32), np.where(hit, prim, -1)
+
+
+# ---- the realtime pipeline (RealtimeRaytracing.hlsl) --------------------------------------------------------------------
+
+class RealtimeFrame(Frame):
+    """shadeAOV instead of shade (:65-103): direct light and ONE Phong-lobe bounce, no indirect diffuse, no debug views;
+    PrimaryClosestHit / PrimaryMiss write the two AOVs (:105-126); the payload's AOVs of the depth-0 hit are what RayGen stores."""
+
+    def shade_aov(self, P, N, D, depth, active):
+        m = self.mat
+        rng = Rng(init_rand(self.pix, self.frame_count))
+        direct = self.directional(P, N, depth, active)
+        direct = direct + self.point(P, N, depth, active)
+        fresnel = np.zeros_like(P)
+        spec = np.zeros_like(P)
+        if m["type"] in (1, 2) and m["reflectivity"] > 0.001:
+            exponent = np.exp((f32(1.0) - f32(m["roughness"])) * f32(12.0), dtype=f32)
+            mirror = reflect(D, N)
+            s, pdf, brdf = phong_lobe(rng, mirror, exponent, None)
+            refl = self.secondary(P, s, depth, active)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                spec = spec + refl * brdf[..., None] / pdf[..., None]
+            fresnel = fresnel_schlick(D, N, m["specular"][:3].astype(f32)[None])
+        albedo = m["albedo"][:3].astype(f32)[None]
+        dl = albedo * direct / M_PI
+        isp = f32(m["reflectivity"]) * spec * fresnel
+        return dl + isp, dl, isp
+
+    def trace_radiance(self, o, d, tmin, depth, cull, active):
+        """TraceRay with the realtime hit group / miss shader: (rgb, distance); the AOVs of this call are left in self.aov"""
+        n = o.shape[0]
+        rgb = np.zeros((n, 3), f32)
+        dist = np.full(n, f32(-1.0))
+        aov_d = np.zeros((n, 3), f32)
+        aov_i = np.zeros((n, 3), f32)
+        idx = np.nonzero(active)[0]
+        if idx.size:
+            hit, prim, t, u, v = self.sc.closest(o[idx], d[idx], tmin[idx], np.full(idx.size, RAY_MAX_T), cull)
+            full_hit = np.zeros(n, bool)
+            full_hit[idx] = hit
+            fp = np.zeros(n, np.int64); ft = np.zeros(n, f32); fu = np.zeros(n, f32); fv = np.zeros(n, f32)
+            fp[idx], ft[idx], fu[idx], fv[idx] = np.maximum(prim, 0), t, u, v
+            miss = active & ~full_hit
+            rgb[miss] = self.env * f32(self.opt["environmentStrength"])            # PrimaryMiss: colour = environment,
+            aov_d[miss] = rgb[miss]                                                 #   aov.directLighting = colour, indirectSpecular = 0
+            b0 = f32(1.0) - fu - fv
+            nrm = self.sc.n0[fp] * b0[..., None] + self.sc.n1[fp] * fu[..., None] + self.sc.n2[fp] * fv[..., None]
+            P = o + ft[..., None] * d
+            col, dl, isp = self.shade_aov(P, normalize(nrm), d, depth, full_hit)     # (recursion below overwrites self.aov: saved after)
+            rgb[full_hit] = col[full_hit]
+            dist[full_hit] = ft[full_hit]
+            if depth == 0:
+                aov_d[full_hit] = dl[full_hit]
+                aov_i[full_hit] = isp[full_hit]
+        self.aov = (aov_d, aov_i)
+        return rgb, dist
+
+
+def render_frame_realtime(scene, pfc, mat, W, H, env_rgb=(0.5, 0.5, 0.5)):
+    """RealtimeRaytracing.hlsl RayGen over the whole image: (direct lighting float32[H, W, 4], indirect specular float32[H, W, 4],
+    primary hit prim int[H*W]); no accumulation, the jitter scaled by 10 (:33)."""
+    fr = RealtimeFrame(scene, pfc, mat, W, H, env_rgb)
+    n = W * H
+    cp = pfc["cameraParams"]
+    o, d = primary_rays(pfc, W, H)
+    jit = cp["jitters"].astype(f32) * f32(10.0)
+    o = np.broadcast_to(cp["worldEyePos"][:3].astype(f32) + np.array([jit[0], jit[1], 0.0], f32), (n, 3)).copy()
+    fr.trace_radiance(o, d, np.zeros(n, f32), 0, True, np.ones(n, bool))
+    aov_d, aov_i = fr.aov
+    hit, prim, _, _, _ = scene.closest(o, d, np.zeros(n, f32), np.full(n, RAY_MAX_T), True)
+    one = np.ones((n, 1), f32)
+    return (np.concatenate([np.maximum(aov_d, f32(0.0)), one], axis=1).reshape(H, W, 4),
+            np.concatenate([np.maximum(aov_i, f32(0.0)), one], axis=1).reshape(H, W, 4), np.where(hit, prim, -1))

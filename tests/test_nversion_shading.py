@@ -4,7 +4,7 @@ oracle/oracle_shade.h is the one restatement of RayGen -> PrimaryClosestHit -> s
 tests/golden/nversion_shade.py is a SECOND restatement, written from the HLSL text alone in float32 numpy: brute-force
 intersection instead of a BVH, numpy's own transcendentals instead of the polynomial kernels, no code shared with oracle/
 or the product.  Here both render the Cornell box (32 x 32, two accumulated frames) under option / material sets that
-exercise every branch of shade() -- and, since round 4, the reference's own susanne.obj under three more --; primary hit ids must be identical and the images must agree to RMS <= 1e-5 (north_star's
+exercise every branch of shade() -- and, since round 4, the reference's own susanne.obj under three more, three transformed instances of it under two, and the realtime pipeline's two AOVs under three --; primary hit ids must be identical and the images must agree to RMS <= 1e-5 (north_star's
 tolerance; ulp-level differences of the transcendentals are the only expected source).  The measured values of the
 authoring run are committed in tests/golden/reference_assets.json ("nversion_shading") and checked against as well, so a
 drift of either restatement shows."""
@@ -50,6 +50,11 @@ CASES = {
     # in both spaces" are right.  Normals stay object-space vectors in both: the reference's shaders never apply ObjectToWorld.
     "instances_default": ({}, {}, {"scene": "instances"}),
     "instances_glass": ({"cosineHemisphereSampling": 0}, {"type": 2, "roughness": 0.3, "reflectivity": 0.8}, {"scene": "instances", "lamp": (0.0, 2.5, 2.0), "sun": (0.3, -1.0, -0.4)}),
+    # (round 4) the realtime pipeline (RealtimeRaytracing.hlsl: RayGen with the x10 jitter, shadeAOV, the two AOVs RayGen stores, no
+    # accumulation): the Cornell box with the default (glossy) material and with a rough metal, susanne with a diffuse one (no bounce)
+    "realtime_default": ({}, {}, {"realtime": True}),
+    "realtime_rough_metal": ({"environmentStrength": 0.5}, {"type": 1, "roughness": 0.8, "reflectivity": 0.9, "specular": (0.9, 0.6, 0.3, 1.0)}, {"realtime": True}),
+    "realtime_susanne_diffuse": ({}, {"type": 0}, {"scene": "susanne", "realtime": True}),
 }
 
 
@@ -109,6 +114,22 @@ def run_case(options, material, setup=None):
     ids_equal = True
     for frame in range(2):
         pfc = host.update(cam, 0.0, frame + 1, W, H)
+        if setup.get("realtime"):
+            # two AOVs per frame, nothing accumulated: both frames' AOVs side by side are "the image" that is compared
+            od, oi, _ = sc.render_realtime(mat, pfc, W, H, env_constant=(0.5, 0.5, 0.5))
+            pf = np.frombuffer(pfc.tobytes(), T.PER_FRAME_CONSTANTS)[0]
+            nd, ni, prim = NV.render_frame_realtime(nsc, pf, mat, W, H)
+            _, d3 = NV.primary_rays(pf, W, H)
+            jit = pf["cameraParams"]["jitters"].astype(np.float32) * np.float32(10.0)              # RealtimeRaytracing.hlsl:33
+            o3 = np.broadcast_to(pf["cameraParams"]["worldEyePos"][:3].astype(np.float32) + np.array([jit[0], jit[1], 0.0], np.float32), d3.shape)
+            o = np.concatenate([o3, np.zeros((W * H, 1), np.float32)], axis=1)
+            d = np.concatenate([d3, np.full((W * H, 1), 1.0e38, np.float32)], axis=1)
+            h = sc.trace(o, d, flags=T.RAY_FLAG_CULL_BACK_FACING_TRIANGLES, mode=0)
+            want = np.where(h["inst"] == T.RT_NO_HIT, -1, h["inst"].astype(np.int64) * n_tris + h["prim"].astype(np.int64))
+            ids_equal = ids_equal and np.array_equal(want, prim)
+            acc = np.concatenate([od, oi], axis=1) if frame == 0 else np.concatenate([acc, od, oi], axis=1)
+            acc2 = np.concatenate([nd, ni], axis=1) if frame == 0 else np.concatenate([acc2, nd, ni], axis=1)
+            continue
         if "sun" in setup:                                     # (the oracle's host returns the 188 raw bytes)
             view = pfc.view(T.PER_FRAME_CONSTANTS)
             view["directionalLight"]["forwardDir"][0, :3] = setup["sun"]
