@@ -1,0 +1,67 @@
+"""N-version check of the DenoiseCompositor oracle.
+
+oracle/oracle_shade.h's denoiser is what the GPU kernels (rt_denoise.hip) are compared with bit for bit;
+tests/golden/nversion_denoise.py is a SECOND restatement of BilateralFilter.hlsli + DenoiseCommon.hlsli, written from the HLSL text
+alone in float32 numpy (vectorised shifts instead of per-pixel loops, no code shared with oracle/ or the product).  Both run on the
+reference's own mock inputs (crops of assets/textures/DirectLighting.PNG and IndirectSpecular.PNG, tests/golden/denoise_mock.npz)
+under parameter sets that reach every branch of the two passes: kernel sizes 0 ... 20 (the cache's MAX_EXTENT), the four debug views,
+tone map and gamma on and off.  Everything but the gamma's pow() is additions, multiplications and one division per pixel in a
+fixed order, so the two must agree BIT FOR BIT there; with gamma correction on, to 1e-6 (numpy's pow against the oracle's)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, os.path.dirname(HERE))
+
+import nversion_denoise as ND                            # noqa: E402
+
+CASES = {
+    "reference_defaults": {},
+    "kernel_3": {"maxKernelSize": 3},
+    "kernel_20_no_tonemap": {"maxKernelSize": 20, "tonemap": 0},
+    "kernel_0": {"maxKernelSize": 0},
+    "view_indirect_filtered": {"debugVisualize": 1},
+    "view_indirect_unfiltered": {"debugVisualize": 2},
+    "view_direct": {"debugVisualize": 3},
+    "exposure_2_5": {"exposure": 2.5, "tonemap": 0},
+    "gamma_2_2": {"gammaCorrect": 1},
+    "gamma_1_8_no_tonemap": {"gammaCorrect": 1, "gamma": 1.8, "tonemap": 0, "exposure": 0.7},
+}
+
+
+def inputs():
+    g = np.load(os.path.join(HERE, "golden", "denoise_mock.npz"))
+    direct = np.ones((144, 256, 4), np.float32)
+    indirect = np.ones((144, 256, 4), np.float32)
+    direct[..., :g["direct_rgba8"].shape[2]] = g["direct_rgba8"].astype(np.float32) / np.float32(255.0)
+    indirect[..., :g["indirect_rgba8"].shape[2]] = g["indirect_rgba8"].astype(np.float32) / np.float32(255.0)
+    return g, direct, indirect
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_second_restatement_of_the_denoiser_agrees_with_the_oracle(name):
+    from oracle import pyoracle as O
+    g, direct, indirect = inputs()
+    p = np.frombuffer(g["denoise_params"].tobytes(), O.DENOISE_PARAMS)[0].copy()
+    for k, v in CASES[name].items():
+        p[k] = v
+    oh, ov = O.denoise(direct, indirect, p)
+    nh, nv = ND.denoise(direct, indirect, p["exposure"], p["gamma"], p["tonemap"], p["gammaCorrect"], p["maxKernelSize"], p["debugVisualize"])
+    assert np.array_equal(oh, nh), "H pass: %d values differ" % int((oh != nh).sum())
+    if p["gammaCorrect"]:
+        assert np.abs(ov.astype(np.float64) - nv).max() <= 1e-6
+    else:
+        assert np.array_equal(ov, nv), "composite: %d values differ" % int((ov != nv).sum())
+    assert np.isfinite(ov).all() and ov[..., 3].min() == 1.0
+
+
+def test_the_weights_table_is_the_shader_s():
+    """BilateralFilter.hlsli:84-93 at the reference's default radius (12): taps 0..1 -> 1, then 0.9, 0.75, 0.6, 0.5 in steps of
+    12 * 0.8 / 5 = 1.92 taps, zero beyond the radius"""
+    w = ND.gaussian_weights(12.0)[ND.MAX_EXTENT:]
+    assert list(w[:13]) == [1.0, 1.0, 1.0, 1.0, np.float32(0.9), np.float32(0.9), np.float32(0.75), np.float32(0.75), np.float32(0.6), np.float32(0.6), 0.5, 0.5, 0.0]
+    assert (w[12:] == 0).all()
