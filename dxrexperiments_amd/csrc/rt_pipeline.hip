@@ -89,9 +89,10 @@ struct PrimarySinkT {
 
 // (see RT_LDS_STACK_ROWS_SETS: the single-level instantiations with that many stack rows are compiled for seven waves per SIMD,
 // the 18-row ones for the six their LDS allows (the any-hit kernel with the shadow cache would take 81 registers otherwise);
-// every other instantiation is left to the compiler -- a floor of 1 constrains nothing)
+// the two-level ones for five -- they take 88 - 96 registers by themselves, except the primary stage of a set (99: a fourth wave lost
+// for three registers; capped it fits 96 without scratch))
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU __attribute__((amdgpu_waves_per_eu(TWO_LEVEL ? 1 : STACK == RT_LDS_STACK_ROWS_SETS ? 7 : STACK == RT_LDS_STACK_ROWS ? 6 : 1)))
+#define RT_WAVES_PER_EU __attribute__((amdgpu_waves_per_eu(TWO_LEVEL ? 5 : STACK == RT_LDS_STACK_ROWS_SETS ? 7 : STACK == RT_LDS_STACK_ROWS ? 6 : 1)))
 #endif
 template <int STACK, bool TWO_LEVEL, bool BATCH>
 __global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_primary(PipeDev pd)
