@@ -223,9 +223,10 @@ int rt_pipeline_render(rt_pipeline *p, uint32_t width, uint32_t height);
  * afterwards the pipeline's constants are constants[n - 1].  Queue memory grows with the batch (1080p: at most 0.47 GB per frame;
  * rt_pipeline_set_queue_budget). */
 int rt_pipeline_render_batch(rt_pipeline *p, uint32_t width, uint32_t height, const rt_per_frame_constants *constants, uint32_t n);
-/* Sizes the ray queues for sets of `frames` frames of width x height now, so that the first rt_pipeline_render_batch of that size
- * does not allocate (the counterpart of createOutputResource for the per-frame work memory the reference's Fallback Layer keeps
- * inside DispatchRays).  Optional: queues also grow on demand. */
+/* Reserves everything a set of `frames` frames of width x height allocates -- ray / hit / shadow queues, the set's constants, the
+ * shadow cache's table and (scene built) the traversal kernels' global stack rows -- now, so that the first set of that size does
+ * not allocate (the counterpart of createOutputResource for the per-frame work memory the reference's Fallback Layer keeps inside
+ * DispatchRays).  width x height may be the packed rows of a rank's bands.  Optional: all of it also grows on demand. */
 int rt_pipeline_reserve_batch(rt_pipeline *p, uint32_t width, uint32_t height, uint32_t frames);
 /* same, restricted to pixel rectangle [x0,x1) x [y0,y1) (tile sharding) */
 int rt_pipeline_render_tile(rt_pipeline *p, uint32_t width, uint32_t height,
