@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""A two-level PROGRESSIVE scene in sets of frames: 1024 instances of two meshes at 1080p, sets of 16 through rt_pipeline_render_batch -- the one
+workload whose primary stage runs the two-level kernel of a set (profiles/r04/two_level_sets.txt).   usage (GPU box): python3 tools/two_level_sets.py"""
 import os, sys, time, numpy as np
 sys.path.insert(0, os.getcwd())
 from dxrexperiments_amd import capi, rtypes as T, scenes
