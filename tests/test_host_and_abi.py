@@ -98,6 +98,26 @@ def test_progressive_update_matches_oracle_and_fixture(capi, oracle):
     assert p0["pointLight"]["color"].tolist() == pytest.approx([0.2, 0.8, 0.6, 2.0])
 
 
+def test_jitter_stream_is_mt19937(capi, oracle):
+    """ProgressiveRaytracingPipeline.cpp:190-192 draws the two jitters from a std::mt19937 through a uniform_real_distribution<float>.
+    The generator is pinned by the C++ standard (the 10000th output of a default-seeded engine is 4123659995) and checked here against an
+    independent implementation -- numpy's MT19937 with the classic init_genrand seeding --; the mapping to [0, 1) is implementation
+    defined (MSVC and libstdc++ differ) and is this engine's own: the top 24 bits times 2^-24."""
+    bg = np.random.MT19937()
+    bg._legacy_seeding(5489)
+    raw = bg.random_raw(10000)
+    assert int(raw[-1]) == 4123659995                                  # [rand.predef]: the standard's own known answer
+    seed = 20240
+    bg._legacy_seeding(seed)
+    host, oh = capi.ProgressiveHost(seed), oracle.Progressive(seed)
+    cam = cam_array(scenes.cornell_camera(), 16 / 9)
+    for f in range(64):
+        u = [np.float32(int(bg.random_raw()) >> 8) * np.float32(1.0 / 16777216.0) for _ in range(2)]
+        want = [(u[0] - np.float32(0.5)) / np.float32(1920), (u[1] - np.float32(0.5)) / np.float32(1080)]
+        for pfc in (host.update(cam, 0.0, f + 1, 1920, 1080), np.frombuffer(oh.update(cam, 0.0, f + 1, 1920, 1080).tobytes(), T.PER_FRAME_CONSTANTS)[0]):
+            assert pfc["cameraParams"]["jitters"].tolist() == [float(want[0]), float(want[1])], f
+
+
 def test_progressive_flags_and_reset(capi):
     host = capi.ProgressiveHost(5)
     cam = cam_array(scenes.cornell_camera(), 1.0)
