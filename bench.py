@@ -821,7 +821,9 @@ def main():
                        "shadow_cache_cells_per_side": pipe.shadow_cache(),
                        "entry_point": "rt_pipeline_update + rt_pipeline_render per frame" + (" (deferred mode: rt_pipeline_set_deferred(%d) renders the "
                                       "recorded frames through shared sets of launches, the same image bit for bit)" % S if S > 1 else ""),
-                       "queue_memory_bytes_per_frame": pipe.queue_memory()[0] / max(S, 1)},
+                       "queue_memory_bytes_per_frame": pipe.queue_memory()[0] / max(S, 1),
+                       # (the traversal kernels' global stack rows behind the LDS rows: reserved with the queues, never touched by this scene's rays)
+                       "global_stack_rows_bytes_per_frame": ctx.stack_memory() / max(S, 1)},
             "primary_mrays_per_s": primary_all / elapsed / 1e6,
             "frames_per_s": K * world / elapsed,
             "rays_per_frame": rays_all / (K * world),

@@ -62,6 +62,7 @@ SIGNATURES = {
     "rt_context_create_on_stream": (_i, [_i, _p, _pp]),
     "rt_context_destroy": (_i, [_p]),
     "rt_context_synchronize": (_i, [_p]),
+    "rt_context_get_stack_memory": (_i, [_p, _p]),
     "rt_context_get_stream": (_i, [_p, _pp]),
     "rt_context_get_device": (_i, [_p, C.POINTER(_i)]),
     "rt_device_alloc": (_i, [_p, _sz, _pp]),
@@ -245,6 +246,12 @@ class Context:
 
     def synchronize(self):
         _check(lib().rt_context_synchronize(self.h))
+
+    def stack_memory(self):
+        """bytes of the traversal kernels' global stack rows held by the context"""
+        n = C.c_size_t(0)
+        _check(lib().rt_context_get_stack_memory(self.h, C.byref(n)))
+        return n.value
 
     def pci_bus_id(self):
         """PCI bus id of the context's device ("0000:c1:00.0"): what tells two ranks on one GPU apart from two GPUs"""

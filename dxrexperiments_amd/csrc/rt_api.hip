@@ -208,6 +208,13 @@ int rt_context_synchronize(rt_context *ctx)
     return RT_OK;
 }
 
+int rt_context_get_stack_memory(rt_context *ctx, size_t *bytes)
+{
+    RT_REQUIRE(ctx && bytes, "null argument");
+    *bytes = ctx->deep_stack.bytes;
+    return RT_OK;
+}
+
 int rt_context_get_stream(rt_context *ctx, void **hip_stream_out)
 {
     RT_REQUIRE(ctx && hip_stream_out, "null argument");

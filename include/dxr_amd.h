@@ -56,6 +56,10 @@ int rt_context_destroy(rt_context *ctx);
 int rt_context_synchronize(rt_context *ctx);
 int rt_context_get_stream(rt_context *ctx, void **hip_stream_out);
 int rt_context_get_device(rt_context *ctx, int *device_out);
+/* Bytes of the traversal kernels' global stack rows the context holds (the part of a walk's stack beyond the LDS rows: sized by the
+ * largest launch so far, shared by every pipeline of the context; the bench scenes never touch them).  No reference counterpart:
+ * the Fallback Layer keeps its traversal stack inside DispatchRays (RtContext.cpp:218-221). */
+int rt_context_get_stack_memory(rt_context *ctx, size_t *bytes);
 
 /* Plain device buffers on the context's GPU (CreateBuffer / AllocateUploadBuffer of
  * Helpers/DirectXRaytracingHelper.h:187-208): for callers that feed device pointers to

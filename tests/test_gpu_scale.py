@@ -188,7 +188,7 @@ def test_bench_two_ranks_on_one_gpu():
     # deferred pipeline), the same calls with deferred mode off beside it, and a roofline whose fraction is achieved / peak of the same unit
     assert d1["config"]["frames_per_launch_set"] == 4 and d1["config"]["launch_sets"] == 1
     assert d1["config"]["entry_point"].startswith("rt_pipeline_update + rt_pipeline_render per frame") and "rt_pipeline_set_deferred(4)" in d1["config"]["entry_point"]
-    assert d1["config"]["queue_memory_bytes_per_frame"] > 0
+    assert d1["config"]["queue_memory_bytes_per_frame"] > 0 and d1["config"]["global_stack_rows_bytes_per_frame"] >= 0
     fb = d1["frame_by_frame"]
     assert fb["frames"] == 4 and fb["ms_per_frame"] > 0 and fb["Mrays_per_s"] > 0
     # the host's side of the timed region and the same steps once more at the end of the run (the line states its own spread)
