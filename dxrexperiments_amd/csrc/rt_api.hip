@@ -218,7 +218,10 @@ int rt_context_get_stack_memory(rt_context *ctx, size_t *bytes)
 int rt_context_get_stream(rt_context *ctx, void **hip_stream_out)
 {
     RT_REQUIRE(ctx && hip_stream_out, "null argument");
+    // (a caller that asks for the stream is about to order its own work behind "everything submitted": the frames a deferred
+    // pipeline still holds go onto the stream first -- ADVICE r4)
     *hip_stream_out = (void *)ctx->stream;
+    if (!ctx->deferred.empty()) { RT_TRY(use_device(ctx)); RT_TRY(rt_context_flush_deferred(ctx)); }
     return RT_OK;
 }
 
@@ -263,6 +266,7 @@ int rt_device_download(rt_context *ctx, void *host_dst, const void *device_src, 
 {
     RT_REQUIRE(ctx && (bytes == 0 || (host_dst && device_src)), "null argument");
     RT_TRY(use_device(ctx));
+    RT_TRY(rt_context_flush_deferred(ctx));          // (device_src may be an output a deferred pipeline still owes frames to)
     if (bytes) HIP_TRY(hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RT_OK;

@@ -47,12 +47,14 @@ int rt_pipeline_create(rt_context *ctx, uint32_t kind, rt_pipeline **out)
 int rt_pipeline_destroy(rt_pipeline *p)
 {
     if (!p) return RT_OK;
-    {   // frames accepted and not rendered yet die with the pipeline (nothing could read them any more)
+    (void)hipSetDevice(p->ctx->device);
+    {   // Frames accepted and not rendered yet: an output in caller memory (rt_pipeline_bind_output) outlives the pipeline, so
+        // they are rendered into it first; with an output of its own nothing could read them any more and they die here.
+        if (!p->pending.empty() && p->accum && p->accum != p->accum_own.as<float4>()) (void)rt_pipeline_flush_pending(p);
         std::vector<rt_pipeline *> &reg = p->ctx->deferred;
         for (size_t k = 0; k < reg.size(); k++) if (reg[k] == p) { reg.erase(reg.begin() + (long)k); break; }
         p->pending.clear();
     }
-    (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     DevBuf *all[] = {&p->d_mats, &p->d_env, &p->accum_own, &p->aov_own, &p->counters, &p->half_out, &p->totals, &p->work, &p->batch_consts, &p->shadow_cache,
                      &p->sh_hits, &p->sh_O, &p->sh_D, &p->sh_vis};

@@ -89,12 +89,13 @@ public:
         if (n) mConstants = constants[n - 1];
     }
 
-    // Sets of frames behind update() + render() (rt_pipeline_set_deferred; ON by default here, 32 frames): render() records the
-    // frame, the recorded frames go through one set of launches when 32 have gathered or when anything reads or changes what
-    // they produce -- getOutputResource() / readOutput() / saveCheckpoint(), a material or scene change, RtContext::synchronize.
-    // Bit for bit the image of rendering every frame at once; an application that presents every frame (the reference's
-    // OnRender copies the output each frame, src/DXRExperimentsApp.cpp:194-214) flushes every frame and loses nothing.
-    // 0 or 1: render() renders.
+    // Sets of frames behind update() + render() (rt_pipeline_set_deferred).  OFF by default (round 5): render() renders,
+    // as the reference's does (src/DXRExperimentsApp.cpp:194: DispatchRays, then the copy of the output, every frame), so a caller
+    // that fetched getOutputResource() once and synchronises its own stream always sees the frame it asked for.  A headless
+    // accumulation opts in with setDeferredFrames(n <= 32): render() then records the frame, and the recorded frames go through
+    // one set of launches when n have gathered or when anything reads or changes what they produce -- getOutputResource() /
+    // readOutput() / saveCheckpoint(), a material or scene change, RtContext::synchronize, rt_context_get_stream,
+    // rt_device_download, the pipeline's destruction.  Bit for bit the image of rendering every frame at once.  0 or 1: off.
     void setDeferredFrames(UINT frames) { DXRFramework::ThrowIfFailed(rt_pipeline_set_deferred(mPipeline, frames)); }
     UINT getDeferredFrames() const { uint32_t m = 0; rt_pipeline_get_deferred(mPipeline, &m, nullptr); return m; }
     UINT getPendingFrames() const { uint32_t n = 0; rt_pipeline_get_deferred(mPipeline, nullptr, &n); return n; }
@@ -187,7 +188,6 @@ private:
         mRtState->setMaxAttributeSize(8);
         mRtState->setMaxPayloadSize(20);
         ThrowIfFailed(rt_pipeline_create(context->getHandle(), RT_PIPELINE_PROGRESSIVE, &mPipeline));
-        ThrowIfFailed(rt_pipeline_set_deferred(mPipeline, 32));       // sets of frames behind update() + render(): setDeferredFrames()
         ThrowIfFailed(rt_progressive_host_create(rngSeed, &mHost));
         rt_debug_options *opt = nullptr;
         ThrowIfFailed(rt_progressive_host_options(mHost, &opt));

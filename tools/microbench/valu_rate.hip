@@ -169,6 +169,47 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float s)
                          "v_cvt_f32_ubyte3 %0, %0\n v_fma_f32 %1, %1, %8, %8\n v_max_f32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
                          "v_cndmask_b32_e64 %4, %4, %8, %9\n v_fmac_f32 %5, %8, %8\n v_sub_f32 %6, %6, %8\n v_lshlrev_b32 %7, 6, %7\n"
                          : REGS : "v"(s), "s"(m) : "s20", "s21", "s22", "s23");
+        } else if (MODE == 39) {      // round 5: the packed-f16 candidates for the node step's culling planes (VERDICT r4 task 1)
+#define OP(n) "v_pk_fma_f16 %" #n ", %" #n ", %8, %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 40) {
+#define OP(n) "v_pk_max_f16 %" #n ", %" #n ", %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 41) {
+#define OP(n) "v_pk_min_f16 %" #n ", %" #n ", %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 42) {
+#define OP(n) "v_pk_add_f16 %" #n ", %" #n ", %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 43) {
+#define OP(n) "v_cvt_pkrtz_f16_f32 %" #n ", %" #n ", %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 44) {      // low half + high half of one register (the (lo, -hi) pair of a child): SDWA word selects
+#define OP(n) "v_add_f16_sdwa %" #n ", %" #n ", %" #n " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n"
+            asm volatile(R8(OP) : REGS : "v"(s));
+#undef OP
+        } else if (MODE == 45) {
+#define OP(n) "v_cmp_le_f16_e64 s[20:21], %" #n ", %8\n"
+            asm volatile(R8(OP) : REGS : "v"(s) : "s20", "s21");
+#undef OP
+        } else if (MODE == 46) {      // 4 x (v_perm_b32 ; v_pk_fma_f16): two planes per pair of instructions
+            asm volatile("v_perm_b32 %0, %0, %8, %8\n v_pk_fma_f16 %1, %1, %8, %8\n v_perm_b32 %2, %2, %8, %8\n v_pk_fma_f16 %3, %3, %8, %8\n"
+                         "v_perm_b32 %4, %4, %8, %8\n v_pk_fma_f16 %5, %5, %8, %8\n v_perm_b32 %6, %6, %8, %8\n v_pk_fma_f16 %7, %7, %8, %8\n" : REGS : "v"(s));
+        } else if (MODE == 47) {      // one child of a packed-f16 step: 3 perm, 3 pk_fma, 3 pk_max, sdwa add, cmp (11 instructions)
+            asm volatile("v_perm_b32 %0, %0, %8, %8\n v_pk_fma_f16 %0, %0, %8, %8\n v_perm_b32 %1, %1, %8, %8\n v_pk_fma_f16 %1, %1, %8, %8\n"
+                         "v_perm_b32 %2, %2, %8, %8\n v_pk_fma_f16 %2, %2, %8, %8\n v_pk_max_f16 %3, %0, %1\n v_pk_max_f16 %4, %2, %8\n v_pk_max_f16 %5, %3, %4\n"
+                         "v_add_f16_sdwa %6, %5, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n v_cmp_le_f16_e64 s[20:21], %6, %8\n"
+                         : REGS : "v"(s) : "s20", "s21");
+        } else if (MODE == 48) {      // the same child in today's f32 form: 6 cvt, 6 fma, max3, max, min3, min, mul, cmp (18 instructions)
+            asm volatile("v_cvt_f32_ubyte0 %0, %7\n v_fma_f32 %0, %0, %8, %8\n v_cvt_f32_ubyte1 %1, %7\n v_fma_f32 %1, %1, %8, %8\n v_cvt_f32_ubyte2 %2, %7\n v_fma_f32 %2, %2, %8, %8\n"
+                         "v_cvt_f32_ubyte3 %3, %7\n v_fma_f32 %3, %3, %8, %8\n v_cvt_f32_ubyte0 %4, %7\n v_fma_f32 %4, %4, %8, %8\n v_cvt_f32_ubyte1 %5, %7\n v_fma_f32 %5, %5, %8, %8\n"
+                         "v_max3_f32 %0, %0, %1, %2\n v_max_f32 %0, %0, %8\n v_min3_f32 %3, %3, %4, %5\n v_min_f32 %3, %3, %8\n v_mul_f32 %3, 0x3f800080, %3\n v_cmp_le_f32_e64 s[20:21], %0, %3\n"
+                         : REGS : "v"(s) : "s20", "s21");
         } else if (MODE == 24) {
             asm volatile("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
                          : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(s2));
@@ -199,16 +240,18 @@ int main(int argc, char **argv)
     const char *names[] = {"v_mul_f32", "v_pk_mul_f32", "v_min_f32", "v_min3_f32", "v_cndmask_b32 vcc", "v_cndmask_b32 sgpr", "v_sub_f32", "v_fma_f32",
                            "v_add_u32", "v_cmp_lt_f32 vcc", "v_cmp_lt_f32 sgpr", "v_max_f32", "v_lshl_or_b32", "v_mov_b32", "v_med3_f32", "v_mul_f32 literal", "cmp+add+cndmask (x3)", "v_fmac_f32 (VOP2)", "v_pk_fma_f32", "v_cvt_f32_ubyte1", "v_add_f32", "v_and_b32",
                            "v_max3_f32", "v_min_u32", "v_pk_add_f32", "v_perm_b32", "v_fma_mix_f32", "v_bfe_u32", "v_and_or_b32", "v_lshl_add_u32", "v_cvt_f32_u32", "v_lshrrev_b32",
-                           "mixed fma+mul", "mixed cvt+fma", "mixed cndmask+max3", "mixed step-like", "dependent fma chain", "dependent mul chain", "traversal-kernel mix"};
-    float ms[39] = {run<0>(d, blocks, iters), run<1>(d, blocks, iters), run<2>(d, blocks, iters), run<3>(d, blocks, iters), run<4>(d, blocks, iters),
+                           "mixed fma+mul", "mixed cvt+fma", "mixed cndmask+max3", "mixed step-like", "dependent fma chain", "dependent mul chain", "traversal-kernel mix",
+                           "v_pk_fma_f16", "v_pk_max_f16", "v_pk_min_f16", "v_pk_add_f16", "v_cvt_pkrtz_f16_f32", "v_add_f16 sdwa w0+w1", "v_cmp_le_f16 sgpr", "mixed perm+pk_fma_f16", "one child, packed f16 (11)", "one child, f32 (18)"};
+    float ms[49] = {run<0>(d, blocks, iters), run<1>(d, blocks, iters), run<2>(d, blocks, iters), run<3>(d, blocks, iters), run<4>(d, blocks, iters),
                     run<5>(d, blocks, iters), run<6>(d, blocks, iters), run<7>(d, blocks, iters), run<8>(d, blocks, iters), run<9>(d, blocks, iters),
                     run<10>(d, blocks, iters), run<11>(d, blocks, iters), run<12>(d, blocks, iters), run<13>(d, blocks, iters), run<14>(d, blocks, iters),
                     run<15>(d, blocks, iters), run<16>(d, blocks, iters), run<17>(d, blocks, iters), run<18>(d, blocks, iters), run<19>(d, blocks, iters),
                     run<20>(d, blocks, iters), run<21>(d, blocks, iters), run<22>(d, blocks, iters), run<23>(d, blocks, iters), run<24>(d, blocks, iters),
                     run<25>(d, blocks, iters), run<26>(d, blocks, iters), run<27>(d, blocks, iters), run<28>(d, blocks, iters), run<29>(d, blocks, iters), run<30>(d, blocks, iters), run<31>(d, blocks, iters),
-                    run<32>(d, blocks, iters), run<33>(d, blocks, iters), run<34>(d, blocks, iters), run<35>(d, blocks, iters), run<36>(d, blocks, iters), run<37>(d, blocks, iters), run<38>(d, blocks, iters)};
-    for (int m = 0; m < 39; m++) {
-        const int per = (m == 1 || m == 18 || m == 24) ? 4 : (m == 38 ? 32 : 8);
+                    run<32>(d, blocks, iters), run<33>(d, blocks, iters), run<34>(d, blocks, iters), run<35>(d, blocks, iters), run<36>(d, blocks, iters), run<37>(d, blocks, iters), run<38>(d, blocks, iters),
+                    run<39>(d, blocks, iters), run<40>(d, blocks, iters), run<41>(d, blocks, iters), run<42>(d, blocks, iters), run<43>(d, blocks, iters), run<44>(d, blocks, iters), run<45>(d, blocks, iters), run<46>(d, blocks, iters), run<47>(d, blocks, iters), run<48>(d, blocks, iters)};
+    for (int m = 0; m < 49; m++) {
+        const int per = (m == 1 || m == 18 || m == 24) ? 4 : (m == 38 ? 32 : m == 47 ? 11 : m == 48 ? 18 : 8);
         const double wave_insts = (double)blocks * 4 * iters * per;
         printf("%-20s %8.3f ms  %.3f ns per wave64 instruction per SIMD\n", names[m], ms[m], ms[m] * 1e6 / (wave_insts / 1024.0));
     }
