@@ -146,6 +146,7 @@ SIGNATURES = {
     "rt_pipeline_set_queue_budget": (_i, [_p, _sz]),
     "rt_pipeline_get_queue_memory": (_i, [_p, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]),
     "rt_debug_set_alloc_limit": (_i, [_sz]),
+    "rt_debug_set_option": (_i, [_p, C.c_char_p, C.c_char_p]),
     "rt_debug_read_secondary_ray": (_i, [_p, _u32, _p, _p]),
     "rt_camera_look": (_i, [_p, _p, _p, _p, _p]),
     "rt_camera_basis": (_i, [_p, _p, _f, _f, _p, _p, _p]),
@@ -246,6 +247,10 @@ class Context:
 
     def synchronize(self):
         _check(lib().rt_context_synchronize(self.h))
+
+    def set_option(self, name, value):
+        """rt_debug_set_option: the context's experiment / test knobs (include/dxr_amd.h lists them)"""
+        _check(lib().rt_debug_set_option(self.h, str(name).encode(), str(value).encode()))
 
     def stack_memory(self):
         """bytes of the traversal kernels' global stack rows held by the context"""

@@ -107,6 +107,37 @@ int rt_device_count(void)
     return n;
 }
 
+// ---- experiment / test knobs ------------------------------------------------------
+
+extern "C" int rt_debug_set_option(rt_context *c, const char *name, const char *value)
+{
+    RT_REQUIRE(c && name && value, "null argument");
+    const std::string n(name);
+    const long iv = atol(value);
+    const double fv = atof(value);
+    auto bad = [&]() { rt_set_error("rt_debug_set_option: value '%s' out of range for '%s'", value, name); return RT_ERR_INVALID_ARG; };
+    if (n == "lds_top") c->lds_top = iv != 0;
+    else if (n == "lds_stack_rows") { if (iv != 0 && iv != RT_LDS_STACK_ROWS && iv != RT_LDS_STACK_ROWS_TEST) return bad(); c->lds_stack_rows = (uint32_t)iv; }
+    else if (n == "persistent_blocks_per_cu") { if (iv < 0 || iv > 16) return bad(); c->blocks_per_cu_override = (uint32_t)iv; }
+    else if (n == "fast_bvh") { if (strcmp(value, "lbvh") != 0 && strcmp(value, "ploc") != 0) return bad(); c->use_ploc = strcmp(value, "ploc") == 0; }
+    else if (n == "build_batch") { if (iv < 0 || iv > 64) return bad(); c->build_batch = (uint32_t)iv; }
+    else if (n == "leaf_max") { if (iv < 1 || iv > 8) return bad(); c->leaf_max = (uint32_t)iv; }
+    else if (n == "wide_sah") c->wide_sah = iv != 0;
+    else if (n == "sah_node") { if (!(fv > 0.0)) return bad(); c->sah_node = (float)fv; }
+    else if (n == "sah_prim") { if (!(fv > 0.0)) return bad(); c->sah_prim = (float)fv; }
+    else if (n == "verbose") c->verbose = iv != 0;
+    else if (n == "shadow_cache_res") { if (iv < -1 || iv > 8192) return bad(); c->opt_shadow_cache_res = (int)iv; }
+    else if (n == "shadow_cache_pixels") { if (iv < -1 || iv > 1) return bad(); c->opt_shadow_cache_pixels = (int)iv; }
+    else if (n == "primary_persistent") { if (iv < -1 || iv > 1) return bad(); c->opt_primary_persistent = (int)iv; }
+    else if (n == "seven_waves_always") c->opt_seven_waves_always = iv != 0;
+    else if (n == "free_radius") c->opt_free_radius = iv != 0;
+    else if (n == "batch_max") { if (iv < 0 || iv > 32) return bad(); c->opt_batch_max = (uint32_t)iv; }
+    else if (n == "queue_budget_mb") { if (iv < 0) return bad(); c->opt_queue_budget_mb = (size_t)iv; }
+    else if (n == "dist_check_seconds") { if (!(fv >= 0.0)) return bad(); c->opt_dist_check_seconds = fv; }
+    else { rt_set_error("rt_debug_set_option: unknown option '%s'", name); return RT_ERR_INVALID_ARG; }
+    return RT_OK;
+}
+
 // ---- context -------------------------------------------------------------------
 
 static int context_create(int device, void *stream, bool own, rt_context **out)
@@ -137,26 +168,24 @@ static int context_create(int device, void *stream, bool own, rt_context **out)
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         c->cu_count = (uint32_t)prop.multiProcessorCount;
     if (hipHostMalloc((void **)&c->pinned, RT_PINNED_WORDS * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) c->pinned = nullptr;
-    const char *lt = getenv("RT_LDS_TOP");
-    if (lt && atoi(lt) == 0) c->lds_top = false;
-    const char *sr = getenv("RT_LDS_STACK_ROWS");
-    if (sr) c->lds_stack_rows = (uint32_t)atoi(sr);
-    const char *pb = getenv("RT_PERSISTENT_BLOCKS_PER_CU");
-    if (pb && atoi(pb) >= 1 && atoi(pb) <= 16) c->blocks_per_cu_override = (uint32_t)atoi(pb);
-    const char *fb = getenv("RT_FAST_BVH");
-    if (fb && strcmp(fb, "lbvh") == 0) c->use_ploc = false;
-    const char *bb = getenv("RT_BUILD_BATCH");
-    if (bb && atoi(bb) >= 1 && atoi(bb) <= 64) c->build_batch = (uint32_t)atoi(bb);
-    const char *lm = getenv("RT_LEAF_MAX");
-    if (lm) {
-        int v = atoi(lm);
-        if (v >= 1 && v <= 8) c->leaf_max = (uint32_t)v;
+    // the one environment variable the library reads for its behaviour: RT_DEBUG_OPTIONS="name=value,name=value" 
+    if (const char *env = getenv("RT_DEBUG_OPTIONS")) {
+        std::string all(env);
+        size_t at = 0;
+        while (at < all.size()) {
+            size_t end = all.find(',', at);
+            if (end == std::string::npos) end = all.size();
+            const std::string item = all.substr(at, end - at);
+            const size_t eq = item.find('=');
+            if (eq != std::string::npos && rt_debug_set_option(c, item.substr(0, eq).c_str(), item.substr(eq + 1).c_str()) != RT_OK) {
+                const std::string why = rt_last_error();
+                rt_set_error("RT_DEBUG_OPTIONS: %s", why.c_str());
+                rt_context_release(c);
+                return RT_ERR_INVALID_ARG;
+            }
+            at = end + 1;
+        }
     }
-    const char *wd = getenv("RT_WIDE_SAH");               // 1: surface-area-optimal collapse instead of the area-greedy one
-    if (wd) c->wide_sah = atoi(wd) != 0;
-    const char *cn = getenv("RT_SAH_NODE"), *cp = getenv("RT_SAH_PRIM");
-    if (cn && atof(cn) > 0.0) c->sah_node = (float)atof(cn);
-    if (cp && atof(cp) > 0.0) c->sah_prim = (float)atof(cp);
     *out = c;
     return RT_OK;
 }

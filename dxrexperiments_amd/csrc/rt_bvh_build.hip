@@ -410,7 +410,7 @@ int rt_build_blas(rt_context *ctx, rt_model *m)
     BuildTemps bt;
     DevBuf &boxes = bt.boxes, &enc = bt.enc, &bounds = bt.bounds, &tkeys = bt.tkeys, &tsort = bt.tsort, &tenc = bt.tenc, &tdepth = bt.tdepth;
     int rc = RT_OK;
-    const bool verbose = getenv("RT_VERBOSE") != nullptr;
+    const bool verbose = ctx->verbose;
     auto t_prev = std::chrono::steady_clock::now();
     auto mark = [&](const char *what) {          // RT_VERBOSE: wall time of each build phase (synchronises: diagnostics only)
         if (!verbose) return;
@@ -444,7 +444,7 @@ int rt_build_blas(rt_context *ctx, rt_model *m)
             break;
         }
         // production traversal layout: re-cluster the same leaves with PLOC (rt_bvh_ploc.hip), then collapse the binary
-        // tree into wide quantised nodes (rt_bvh_wide.hip); tiny meshes and RT_FAST_BVH=lbvh collapse the LBVH itself
+        // tree into wide quantised nodes (rt_bvh_wide.hip); tiny meshes and option fast_bvh=lbvh collapse the LBVH itself
         mark("gather");
         bool ploc_done = false;
         if (ctx->use_ploc) {
@@ -632,7 +632,7 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
         uint32_t canon = s->tlas.max_depth;
         for (uint32_t i = 0; i < n; i++) canon = s->inst[i].model->blas.max_depth > canon ? s->inst[i].model->blas.max_depth : canon;
         if (canon >= 127) { rt_set_error("acceleration structure %u levels deep: the limit is 126", canon); rc = RT_ERR_UNSUPPORTED; break; }
-        if (getenv("RT_VERBOSE"))
+        if (ctx->verbose)
             fprintf(stderr, "[dxr_amd] TLAS %u instances depth %u; deepest BLAS layout depth %u (%s); stack need %u; %s walk\n", n,
                     s->tlas.max_depth, deepest, ctx->use_ploc ? "PLOC" : "LBVH", s->stack_need, s->two_level ? "two-level" : "single-level");
     } while (0);

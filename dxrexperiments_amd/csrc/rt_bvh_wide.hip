@@ -1,7 +1,7 @@
 // rt_bvh_wide.hip -- the eight-wide, quantised traversal layout (WNode, rt_internal.h).
 //
 // Input: a binary tree over the sorted leaves (the PLOC tree of rt_bvh_ploc.hip, or the canonical LBVH for a TLAS,
-// tiny meshes and RT_FAST_BVH=lbvh).  Output: nodes with up to EIGHT children in one 128-B-aligned record of which the
+// tiny meshes and option fast_bvh=lbvh).  Output: nodes with up to EIGHT children in one 128-B-aligned record of which the
 // traversal reads the first 96 B.  Why eight (round 3, profiles/r03/slab_fetch.txt): the L2 line and every fabric / HBM
 // request are 128 B, so a 64-B node already moved 128 B per miss (TCC_EA0_RDREQ_128B = 99.7 % of the reads on the 10 M
 // triangle scene); from HBM a lane's 128-B block costs exactly what its 64-B half costs (291 vs 292 ns per wave step per

@@ -119,10 +119,9 @@ std::string rendezvous_path(const void *id128, int rank)
 int check_one_device_per_rank(const rt_context *ctx, int rank, int world, const void *id128, std::string *mine)
 {
     // how long a rank waits for the others' entries: ranks of one launcher arrive within milliseconds of each other, a rank on
-    // another node never does -- so a few seconds by default (RT_DIST_CHECK_SECONDS; a rank that is not seen in time is simply
+    // another node never does -- so a few seconds by default (rt_debug_set_option "dist_check_seconds"; a rank that is not seen in time is simply
     // not checked), and no wait at all beyond the ranks the launcher says are local (LOCAL_WORLD_SIZE)
-    double limit = 5.0;
-    if (const char *e = getenv("RT_DIST_CHECK_SECONDS")) limit = atof(e);
+    const double limit = ctx->opt_dist_check_seconds;
     if (world < 2 || !(limit > 0.0)) return RT_OK;
     char bus[64] = {0};
     if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, ctx->device) != hipSuccess) return RT_OK;       // nothing to compare

@@ -180,25 +180,36 @@ struct rt_context {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_trace_ms = 0.0f;
-    uint32_t leaf_max = 2;       // triangles per collapsed leaf in the traversal layout (RT_LEAF_MAX; 2 measured best: 1 4.05, 2 3.69, 3 3.80, 4 3.87, 8 4.23 ms/frame)
-    bool use_ploc = true;        // RT_FAST_BVH=lbvh keeps the canonical LBVH as the traversal layout
-    bool wide_sah = false;       // RT_WIDE_SAH=1: the collapse into wide nodes minimises the surface-area cost (rt_bvh_wide.hip); default: area-greedy
+    uint32_t leaf_max = 2;       // triangles per collapsed leaf in the traversal layout (option leaf_max; 2 measured best: 1 4.05, 2 3.69, 3 3.80, 4 3.87, 8 4.23 ms/frame)
+    bool use_ploc = true;        // option fast_bvh=lbvh keeps the canonical LBVH as the traversal layout
+    bool wide_sah = false;       // option wide_sah=1: the collapse into wide nodes minimises the surface-area cost (rt_bvh_wide.hip); default: area-greedy
                                  //   (measured, profiles/r03/wide8_experiment.md: no faster on either layout)
-    float sah_node = 1.0f, sah_prim = 0.5f;     // cost of one wide-node step / one triangle test (RT_SAH_NODE, RT_SAH_PRIM)
+    float sah_node = 1.0f, sah_prim = 0.5f;     // cost of one wide-node step / one triangle test (options sah_node, sah_prim)
     uint32_t cu_count = 256;     // compute units of the device
     size_t device_mem_total = 0; // bytes of device memory (asked once, when a pipeline first sizes its queues)
-    uint32_t blocks_per_cu_override = 0;    // RT_PERSISTENT_BLOCKS_PER_CU: 0 = ask the occupancy API per kernel
-    bool lds_top = true;                    // RT_LDS_TOP=0: every node comes from global memory
-    uint32_t lds_stack_rows = 0;            // RT_LDS_STACK_ROWS=6: the small-stack instantiation (tests of the deep-stack path)
+    uint32_t blocks_per_cu_override = 0;    // option persistent_blocks_per_cu: 0 = ask the occupancy API per kernel
+    bool lds_top = true;                    // option lds_top=0: every node comes from global memory
+    uint32_t lds_stack_rows = 0;            // option lds_stack_rows=6: the small-stack instantiation (tests of the deep-stack path)
     DevBuf pool;                 // ray-pool counters of rt_trace_batch
     DevBuf deep_stack;           // global stack rows of the traversal kernels (rt_scene_dev_for_launch)
-    uint32_t build_batch = 0;    // test hook (RT_BUILD_BATCH): PLOC rounds / collapse levels launched between two looks at the
+    uint32_t build_batch = 0;    // test hook (option build_batch): PLOC rounds / collapse levels launched between two looks at the
                                  //   device-side state; 0 = the builders' own estimates
     uint32_t *pinned = nullptr;  // RT_PINNED_WORDS of page-locked host memory: small device-to-host read-backs without staging
                                  // (words 0..63: whoever synchronises next; RT_PINNED_LBVH..+6: depth and bounds of an LBVH in flight)
     DevBuf build_arena;          // temporaries of the acceleration-structure builds: one allocation, sliced (hipMalloc
                                  // and hipFree synchronise the device and cost more than the kernels of a small build)
     DevBuf scratch[8];           // staging for host-pointer batch calls
+    // Experiment / test knobs (rt_debug_set_option, include/dxr_amd.h; the one environment variable RT_DEBUG_OPTIONS="name=value,..." is
+    // applied once, when the context is created).  Nothing else in the library reads the environment for its behaviour.
+    bool verbose = false;                   // verbose=1: build phases and structure depths on stderr
+    int opt_shadow_cache_res = -1;          // shadow_cache_res: cells per side for pipelines that have not been told (-1: by triangle count, 0: off)
+    int opt_shadow_cache_pixels = -1;       // shadow_cache_pixels: per-pixel entries (-1: two-level scenes only)
+    int opt_primary_persistent = -1;        // primary_persistent: the primary stage as a persistent launch (-1: two-level scenes only)
+    bool opt_seven_waves_always = false;    // seven_waves_always=1: single frames on the sets' kernels
+    bool opt_free_radius = true;            // free_radius=0: no free sphere around the point light
+    uint32_t opt_batch_max = 0;             // batch_max: frames per set of launches (0: RT_MAX_BATCH)
+    size_t opt_queue_budget_mb = 0;         // queue_budget_mb: worst-case queue bytes a set may reserve up front (0: a quarter of the device)
+    double opt_dist_check_seconds = 5.0;    // dist_check_seconds: how long rt_dist_create waits for the other ranks' device ids
     std::vector<struct rt_pipeline *> deferred;      // pipelines holding frames that render() has accepted and not rendered yet
                                  //   (rt_pipeline_set_deferred): whatever changes what those frames would see flushes them first
 };
@@ -280,7 +291,7 @@ size_t rt_wide_lbvh_temp_bytes(uint32_t n);
 int rt_build_wide_layout(rt_context *ctx, BvhDev &bv, uint32_t n, uint32_t root, const uint32_t *left, const uint32_t *right, const uint32_t *parent,
                          const float *box6, const uint32_t *size, const uint32_t *offset, const uint32_t *leaf_prim, uint32_t leaf_max,
                          void *tmp, size_t tmp_bytes);
-// the same from the canonical LBVH arrays of bv (TLAS, tiny meshes, RT_FAST_BVH=lbvh)
+// the same from the canonical LBVH arrays of bv (TLAS, tiny meshes, option fast_bvh=lbvh)
 int rt_build_wide_from_lbvh(rt_context *ctx, BvhDev &bv, bool tlas, uint32_t leaf_max);
 
 // rt_trace.hip
@@ -309,7 +320,7 @@ static inline unsigned rt_persistent_grid(const rt_context *ctx, K kernel, int b
 #define RT_LDS_STACK_ROWS 18            // LDS stack rows of the traversal kernels; with the 8-row top table (top of the BLAS for
 #endif                                  // single-level walks, top of the TLAS for two-level ones) 26 KiB per 256-thread block = 6 blocks per CU.
                                         // Bench-scene rays: 98.1 % never hold more than 8 entries, 99.97 % not more than 12, none more than 17.
-#define RT_LDS_STACK_ROWS_TEST 6        // second instantiation (env RT_LDS_STACK_ROWS=6): tests force rays onto the global rows
+#define RT_LDS_STACK_ROWS_TEST 6        // second instantiation (option lds_stack_rows=6): tests force rays onto the global rows
 // Sets of frames (rt_pipeline_render_batch) run long launches whose ramp and drain no longer matter, and there a seventh wave
 // per SIMD pays (-3.5 % on the bench scene; frame by frame it costs 2 %, the drain grows with the resident waves:
 // profiles/r03/seven_waves.txt): their single-level kernels keep 14 stack rows in LDS (22 KiB per block = 7 blocks per CU) and

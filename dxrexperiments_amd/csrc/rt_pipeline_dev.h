@@ -182,13 +182,18 @@ struct rt_pipeline {
     // queues: every render call asks each buffer for what its launches need (DevBuf::reserve keeps what it has when that is
     // enough), so there is no second book of capacities that could disagree with the allocations after a failed growth
     size_t queue_budget = 0;           // worst-case queue bytes a set of launches may reserve up front; above it the levels are sized by
-                                       //   count (0: a quarter of the device's memory, or RT_QUEUE_BUDGET_MB)
+                                       //   count (0: a quarter of the device's memory, or the option queue_budget_mb)
     bool counted_queues = false;       // what the last set of launches did
     // Deferred rendering (rt_pipeline_set_deferred, progressive pipeline): render() only records the frame's constants; the
     // frames go through ONE set of launches when `deferred_max` of them have gathered or when anything asks for -- or changes --
     // what they produce.  Bit for bit the image of immediate rendering (rt_pipeline_render_batch's guarantee).
     uint32_t deferred_max = 0;         // 0 / 1: render() renders
     std::vector<rt_per_frame_constants> pending;
+    // A flush that some OTHER call set off (rt_scene_add_model, rt_context_synchronize, ...: rt_context_flush_deferred) and that failed
+    // does not abort that call: the frames are lost, the error waits here and is returned -- once -- by the next call on THIS
+    // pipeline that renders, flushes or reads (round 5)
+    int deferred_error = RT_OK;
+    std::string deferred_error_msg;
     struct LevelBuf { DevBuf O, D, hit, inst, slot_j, jlist, pix, color; } lv[MAXD + 1];
     DevBuf sh_hits, sh_O, sh_D, sh_vis;      // the shared shadow queue (PipeDev::sh_*)
     DevBuf counters;
@@ -200,7 +205,7 @@ struct rt_pipeline {
     int ring_frames = 0;               // 0 = timing off
     // the shadow cache (ShadowCacheDev): table, the scene it was filled from, the bounds its directional cells span
     DevBuf shadow_cache;
-    int shadow_cache_res = -1;         // rt_pipeline_set_shadow_cache: -1 automatic (env RT_SHADOW_CACHE_RES, else by triangle count), 0 off, n cells per side
+    int shadow_cache_res = -1;         // rt_pipeline_set_shadow_cache: -1 automatic (the option shadow_cache_res, else by triangle count), 0 off, n cells per side
     uint32_t shadow_cache_gen = 0xffffffffu;
     float shadow_cache_centre[3] = {0, 0, 0}, shadow_cache_radius = 1.0f;
     ShadowCacheDev shadow_cache_dev = {};      // what the next shadow launches get (table == nullptr: off)

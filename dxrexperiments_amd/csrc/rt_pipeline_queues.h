@@ -100,8 +100,7 @@ inline size_t worst_case_queue_bytes(size_t cap, uint32_t levels, uint32_t max_s
 inline size_t queue_budget(rt_pipeline *p)
 {
     if (p->queue_budget) return p->queue_budget;
-    static const char *const env = getenv("RT_QUEUE_BUDGET_MB");
-    if (env) { const long long mb = atoll(env); if (mb > 0) return (size_t)mb << 20; }
+    if (p->ctx->opt_queue_budget_mb) return p->ctx->opt_queue_budget_mb << 20;
     if (p->ctx->device_mem_total == 0) {         // asked once per context: hipMemGetInfo is a driver round trip, this runs per frame
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) { (void)hipGetLastError(); total_b = (size_t)64 << 30; }

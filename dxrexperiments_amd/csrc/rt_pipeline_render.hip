@@ -112,9 +112,8 @@ int prepare_shadow_cache(rt_pipeline *p, const rt_per_frame_constants &pfc, cons
         n_tris_all += si.model->n_tris;
     }
     int want = p->shadow_cache_res;
-    if (want < 0) {                         // not set through the API: the environment, else by the size of the triangles
-        const char *e = getenv("RT_SHADOW_CACHE_RES");
-        want = e ? atoi(e) : -1;
+    if (want < 0) {                         // not set through the API: the context's option, else by the size of the triangles
+        want = p->ctx->opt_shadow_cache_res;
         if (want == 0) return RT_OK;
     }
     if (want < 0) {
@@ -131,9 +130,9 @@ int prepare_shadow_cache(rt_pipeline *p, const rt_per_frame_constants &pfc, cons
     // (+ two entries per pixel slot of the output for the primary hits' rays: ShadowCacheDev::px_base.  Measured, profiles/r04/
     // shadow_cache_pixels.txt: two-level scenes -7 % on the any-hit stage (4096 instances: 4.52 -> 4.40 ms); single-level scenes +3 % --
     // their primary hits' rays no longer seed the light-space cells the secondary hits' rays read.  So: on for two-level scenes;
-    // RT_SHADOW_CACHE_PIXELS=0 / 1 overrides)
-    static const int per_pixel_env = getenv("RT_SHADOW_CACHE_PIXELS") ? atoi(getenv("RT_SHADOW_CACHE_PIXELS")) : -1;
-    const bool per_pixel = per_pixel_env < 0 ? s->two_level : per_pixel_env != 0;
+    // the option shadow_cache_pixels = 0 / 1 overrides)
+    const int per_pixel_opt = p->ctx->opt_shadow_cache_pixels;
+    const bool per_pixel = per_pixel_opt < 0 ? s->two_level : per_pixel_opt != 0;
     const size_t cells = (size_t)res * res + 6u * (size_t)(res / 2) * (res / 2);
     const size_t px_slots = per_pixel ? (size_t)((p->width + 7u) / 8u) * ((p->height + 7u) / 8u) * 64u : 0;
     const size_t entries = cells + 2 * px_slots, entry_bytes = s->two_level ? 8 : 4;
@@ -189,7 +188,7 @@ int prepare_shadow_cache(rt_pipeline *p, const rt_per_frame_constants &pfc, cons
 int scene_for_set(rt_pipeline *p, uint32_t n_frames, size_t cap, SceneDev *out, bool *sets_kernels = nullptr)
 {
     rt_context *ctx = p->ctx;
-    static const bool seven_waves_always = getenv("RT_SEVEN_WAVES_ALWAYS") && atoi(getenv("RT_SEVEN_WAVES_ALWAYS")) != 0;      // (experiment: single frames on the sets' kernels)
+    const bool seven_waves_always = ctx->opt_seven_waves_always;      // (experiment: single frames on the sets' kernels)
     const bool set_rows = (n_frames > 1 || seven_waves_always) && !p->scene->two_level && ctx->lds_stack_rows != RT_LDS_STACK_ROWS_TEST && RT_LDS_STACK_ROWS_SETS != RT_LDS_STACK_ROWS;
     const size_t resident = (size_t)ctx->cu_count * 16u * PBLOCK;
     if (sets_kernels) *sets_kernels = set_rows;
@@ -260,7 +259,7 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     pd.pfcs = nullptr; pd.frame_lights = nullptr;
     pd.shadow_compact = ao_view ? 0u : 1u;          // the AO view's four rays have random directions
     // (the light buffer is keyed by the two lights: the AO view's random rays do not use it)
-    const bool free_on = !(getenv("RT_FREE_RADIUS") && atoi(getenv("RT_FREE_RADIUS")) == 0);
+    const bool free_on = ctx->opt_free_radius;
     {
         const float lp0[3] = {frames[0].pointLight.worldPos.x, frames[0].pointLight.worldPos.y, frames[0].pointLight.worldPos.z};
         pd.point_free = free_on ? free_radius(p, pd, lp0) : 0.0f;
@@ -309,9 +308,8 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     // The primary stage as a persistent launch that refills its lanes from a pool of tiles (instead of one tile per wave, dealt by the
     // hardware): pays where the rays of a tile part ways early -- two-level scenes, whose primary waves run at 0.48 of their lanes
     // (4096 instances at 4K: 1.39 -> 1.31 ms) -- and costs 13 % where they stay together (the single-level bench scene: 0.69 of the lanes
-    // as it is).  RT_PRIMARY_PERSISTENT=0 / 1 overrides.  profiles/r04/c4_variants.txt, primary_persistent.txt
-    static const int primary_persistent_env = getenv("RT_PRIMARY_PERSISTENT") ? atoi(getenv("RT_PRIMARY_PERSISTENT")) : -1;
-    pd.primary_persistent = (primary_persistent_env < 0 ? p->scene->two_level : primary_persistent_env != 0) ? 1u : 0u;
+    // as it is).  The option primary_persistent = 0 / 1 overrides.  profiles/r04/c4_variants.txt, primary_persistent.txt
+    pd.primary_persistent = (ctx->opt_primary_persistent < 0 ? p->scene->two_level : ctx->opt_primary_persistent != 0) ? 1u : 0u;
     pd.accum = p->accum;
     pd.aov_direct = p->accum;                       // realtime: output 0 = direct lighting, output 1 = indirect specular
     pd.aov_indirect = p->aov_own.as<float4>();
@@ -344,7 +342,7 @@ static int render_frames(rt_pipeline *p, uint32_t width, uint32_t height, const 
         if (band_count == 0) n = 0;             // more ranks than bands: nothing to render here (the constants still become current)
     }
     uint32_t batch_max = RT_MAX_BATCH;
-    if (const char *e = getenv("RT_BATCH_MAX")) { const int v = atoi(e); if (v >= 1 && v <= (int)RT_MAX_BATCH) batch_max = (uint32_t)v; }
+    if (p->ctx->opt_batch_max >= 1 && p->ctx->opt_batch_max <= RT_MAX_BATCH) batch_max = p->ctx->opt_batch_max;
     // frames RayGen would leave at once (accumCount >= maxIterations, ProgressiveRaytracing.hlsl:14-16) are dropped here;
     // frames that disagree on what sizes the queues (the ambient-occlusion view) do not share a set of launches
     std::vector<rt_per_frame_constants> run;
@@ -372,9 +370,9 @@ static int render_frames(rt_pipeline *p, uint32_t width, uint32_t height, const 
 
 }  // extern "C"
 
-int rt_pipeline_flush_pending(rt_pipeline *p)
+static int flush_pending_now(rt_pipeline *p)
 {
-    if (!p || p->pending.empty()) return RT_OK;
+    if (p->pending.empty()) return RT_OK;
     std::vector<rt_per_frame_constants> frames;
     frames.swap(p->pending);                    // (whatever happens, the frames are not rendered twice)
     std::vector<rt_pipeline *> &reg = p->ctx->deferred;
@@ -385,10 +383,31 @@ int rt_pipeline_flush_pending(rt_pipeline *p)
     return rc;
 }
 
+// every entry point of the pipeline that renders, reads or changes what recorded frames would see calls this first
+int rt_pipeline_flush_pending(rt_pipeline *p)
+{
+    if (!p) return RT_OK;
+    if (p->deferred_error != RT_OK) {           // a flush behind somebody else's call failed: this pipeline's caller hears of it here, once
+        const int rc = p->deferred_error;
+        rt_set_error("deferred frames were lost: %s", p->deferred_error_msg.c_str());
+        p->deferred_error = RT_OK;
+        p->deferred_error_msg.clear();
+        return rc;
+    }
+    return flush_pending_now(p);
+}
+
+// Calls that are not about one pipeline (scene changes, rt_context_synchronize, the collectives) render what every deferred
+// pipeline of the context still holds.  A failure there belongs to the pipeline, not to the caller's own work: it is parked on
+// the pipeline (see deferred_error) and the call goes on.
 int rt_context_flush_deferred(rt_context *ctx)
 {
     if (!ctx) return RT_OK;
-    while (!ctx->deferred.empty()) RT_TRY(rt_pipeline_flush_pending(ctx->deferred.back()));      // (a flush takes the pipeline off the list)
+    while (!ctx->deferred.empty()) {
+        rt_pipeline *p = ctx->deferred.back();
+        const int rc = flush_pending_now(p);      // (a flush takes the pipeline off the list)
+        if (rc != RT_OK && p->deferred_error == RT_OK) { p->deferred_error = rc; p->deferred_error_msg = rt_last_error(); }
+    }
     return RT_OK;
 }
 
@@ -507,6 +526,11 @@ int rt_pipeline_reserve_batch(rt_pipeline *p, uint32_t width, uint32_t height, u
     // (a set whose worst case is over the budget sizes its levels by count as it goes: only the pixel slots are known now)
     const uint32_t levels_now = frame_levels(p);
     const size_t cap = (size_t)fcap * frames;
+    // Any buffer this call grows is a buffer the last frame's replay calls (count_work, count_walk, read_primary_hits, ...) still hold
+    // pointers to in last_pd: a reservation therefore ends what was "rendered" (the calls then refuse instead of
+    // launching on freed memory).  Frames a deferred pipeline still holds are rendered first: they own the queues as they are.
+    RT_TRY(rt_pipeline_flush_pending(p));
+    p->rendered = false;
     if (p->counters.bytes < POOL_OFFSET_WORDS * 4 + POOL_BYTES + PRIMARY_POOL_WORDS * 4) {
         RT_TRY(p->counters.reserve(POOL_OFFSET_WORDS * 4 + POOL_BYTES + PRIMARY_POOL_WORDS * 4));
         HIP_TRY(hipMemsetAsync(p->counters.p, 0, p->counters.bytes, p->ctx->stream));

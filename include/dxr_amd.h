@@ -201,7 +201,7 @@ int rt_pipeline_set_skip_unlit_shadow_rays(rt_pipeline *p, int on);
  * point and the light; the triangle that last answered that for rays at the same place in light space (the cell of the origin
  * projected along the directional light, the cube-map texel of the direction from the point light) is tested first, and the
  * walk only starts if it does not occlude.  The visibility -- and the image -- are the same bit for bit; the time is not
- * (bench scene: shadow stage -19 %).  cells_per_side: -1 automatic (by triangle count; env RT_SHADOW_CACHE_RES overrides),
+ * (bench scene: shadow stage -19 %).  cells_per_side: -1 automatic (by triangle count; the option shadow_cache_res overrides),
  * 0 off, else 16..8192 (the table takes 10 * cells^2 bytes, 20 * cells^2 for scenes of several instances). */
 int rt_pipeline_set_shadow_cache(rt_pipeline *p, int cells_per_side);
 /* cells per side the last rendered frame used (0: it ran without the cache -- AO view, or switched off) */
@@ -255,7 +255,7 @@ int rt_pipeline_set_deferred(rt_pipeline *p, uint32_t max_frames);
 int rt_pipeline_get_deferred(const rt_pipeline *p, uint32_t *max_frames, uint32_t *pending);      /* either may be NULL */
 int rt_pipeline_flush(rt_pipeline *p);
 /* Queue memory.  A set of launches reserves the worst case of its ray / hit / shadow queues up front when that fits `bytes`
- * (0: the default, a quarter of the device's memory, or env RT_QUEUE_BUDGET_MB); above it every radiance level is sized by the
+ * (0: the default, a quarter of the device's memory, or the option queue_budget_mb); above it every radiance level is sized by the
  * count the compaction before it has produced (one 4-byte read-back per level and set).  get: bytes reserved now, and whether
  * the last set of launches sized its levels by count. */
 int rt_pipeline_set_queue_budget(rt_pipeline *p, size_t bytes);
@@ -389,6 +389,27 @@ int rt_debug_math(rt_context *ctx, int fn, const float *x, const float *y, float
 int rt_debug_sample(rt_context *ctx, int kind, const uint32_t *seeds, const float *vec3_in, float exponent,
                     float *vec3_out, float *pdf_brdf, uint32_t *seeds_out, size_t n);
 int rt_debug_read_secondary_ray(rt_pipeline *p, uint32_t index, float origin_tmin[4], float dir_tmax[4]);   /* tools/longest_walk.py */
+/* Experiment and test knobs of a context, in ONE place (round 5; rounds 1 - 4 read 19 environment variables where they were used).
+ * Defaults are the measured best; nothing here changes a result bit -- only which kernels and layouts produce it.  The library
+ * reads exactly one environment variable for its behaviour, once, in rt_context_create: RT_DEBUG_OPTIONS="name=value,name=value",
+ * applied through this function (an unknown name or a value out of range fails the creation).  (rt_dist also reads the
+ * launcher's LOCAL_WORLD_SIZE.)  The reference has no counterpart: its knobs are ImGui widgets (src/ProgressiveRaytracingPipeline.cpp:249-312).
+ *   lds_top=0|1              traversal kernels read the top of the tree from LDS (1)
+ *   lds_stack_rows=0|6|18    6: the small-stack instantiation of the traversal kernels (tests of the overflow path); 0 / 18: default
+ *   persistent_blocks_per_cu=0..16   grid of the persistent launches (0: the occupancy API's answer)
+ *   fast_bvh=ploc|lbvh       traversal layout collapsed from the PLOC tree (default) or from the canonical LBVH; set before building
+ *   build_batch=0..64        PLOC rounds / collapse levels launched between two looks at the device-side state (0: the builders' estimates)
+ *   leaf_max=1..8            triangles per collapsed leaf (2)
+ *   wide_sah=0|1, sah_node=x, sah_prim=x   surface-area-optimal collapse and its costs (off; 1.0, 0.5)
+ *   verbose=0|1              build phases and structure depths on stderr
+ *   shadow_cache_res=-1|0|16..8192   cells per side for pipelines that were not told by rt_pipeline_set_shadow_cache (-1: by triangle count)
+ *   shadow_cache_pixels=-1|0|1, primary_persistent=-1|0|1   (-1: on for two-level scenes only)
+ *   seven_waves_always=0|1   single frames on the sets' kernels
+ *   free_radius=0|1          the free sphere around the point light (1)
+ *   batch_max=0..32          frames per set of launches (0: 32)
+ *   queue_budget_mb=n        worst-case queue bytes a set may reserve up front (0: a quarter of the device's memory)
+ *   dist_check_seconds=x     how long rt_dist_create waits for the other ranks' device ids (5) */
+int rt_debug_set_option(rt_context *ctx, const char *name, const char *value);
 /* test hook: device allocations of more than `bytes` bytes fail with RT_ERR_OOM as if the device were full (0: no limit) */
 int rt_debug_set_alloc_limit(size_t bytes);
 int rt_debug_sample_cube(rt_context *ctx, const float *faces_rgba32f, uint32_t size, uint32_t filter, const float *dirs, float *out, size_t n);

@@ -283,10 +283,7 @@ def test_free_sphere_against_the_oracle(gpu, oracle, capi, scene):
     """rt_pipeline_get_free_sphere: the point light's shadow rays stop at a sphere no triangle reaches into.  The radius arrives
     behind the first frame (a device pass, never waited for), is a lower bound of the light's distance from every vertex, is none
     when the light touches geometry, follows the light -- and the image stays the oracle's bit for bit, frame by frame and in sets."""
-    import os
     from test_gpu_pipeline import make_oracle_scene
-    if os.environ.get("RT_FREE_RADIUS") == "0":
-        pytest.skip("the free sphere is switched off in this environment")
     W, H = 64, 40
     if scene == "atrium":
         models = [scenes.sponza_class(seed=42)]

@@ -152,13 +152,13 @@ def test_wide_node_culling_stays_conservative_in_hard_places(gpu, oracle, capi):
 
 def test_small_lds_stack_spills_to_global_rows():
     """The production kernels keep 24 stack rows per lane in LDS and continue in global memory beyond them
-    (rt_trace_wave.h); real scenes rarely get there, so the 6-row instantiation (RT_LDS_STACK_ROWS=6) re-runs
+    (rt_trace_wave.h); real scenes rarely get there, so the 6-row instantiation (option lds_stack_rows=6) re-runs
     the deep-tree parity tests with most rays spilling."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, RT_LDS_STACK_ROWS="6")
+    env = dict(os.environ, RT_DEBUG_OPTIONS="lds_stack_rows=6")
     sel = ["test_gpu_trace.py::test_soup_with_tmin_tmax_windows", "test_gpu_trace.py::test_instanced_two_level",
            "test_gpu_pipeline.py::test_instanced_scene_materials_and_misses", "test_gpu_pipeline.py::test_material_types_and_depth_limits"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + [os.path.join(here, s) for s in sel],

@@ -88,17 +88,13 @@ def test_single_instance_tlas(gpu, capi):
 @pytest.mark.parametrize("batch", ["1", "3"])
 def test_short_build_batches_give_the_same_tree(gpu, capi, batch):
     """The builders launch PLOC rounds and collapse levels in batches sized by an estimate and continue with another batch
-    when the device-side state says the estimate was short.  RT_BUILD_BATCH forces batches of 1 / 3 rounds, so every
+    when the device-side state says the estimate was short.  The option build_batch forces batches of 1 / 3 rounds, so every
     build goes through that continuation many times; node numbering comes from prefix sums, so the tree must come out
     bit for bit the same as with one batch."""
-    import os
     v, i = triangle_soup(40000, seed=4242)
     want_nodes, want_root, want_recs = build(capi, gpu, [(v, i)], [(0, None)]).wide_read(0)
-    os.environ["RT_BUILD_BATCH"] = batch
-    try:
-        ctx2 = capi.Context(0)
-    finally:
-        del os.environ["RT_BUILD_BATCH"]
+    ctx2 = capi.Context(0)
+    ctx2.set_option("build_batch", batch)
     sc = build(capi, ctx2, [(v, i)], [(0, None)])
     nodes, root, recs = sc.wide_read(0)
     assert root == want_root and np.array_equal(nodes, want_nodes) and np.array_equal(recs.view(np.uint32), want_recs.view(np.uint32))
@@ -180,7 +176,7 @@ def test_axes_that_cannot_be_quantised_never_cull(gpu, capi):
 
 
 def test_surface_area_collapse_option(gpu, capi):
-    """RT_WIDE_SAH=1 (rt_bvh_wide.hip: the collapse that minimises the surface-area cost, Ylitie et al. 2017, instead of the
+    """The option wide_sah=1 (rt_bvh_wide.hip: the collapse that minimises the surface-area cost, Ylitie et al. 2017, instead of the
     area-greedy default) builds a different tree over the same triangles: same invariants, same hits bit for bit."""
     import os
     from util import random_rays
@@ -188,11 +184,8 @@ def test_surface_area_collapse_option(gpu, capi):
     want = build(capi, gpu, [(v, i)], [(0, None)])
     O, D = random_rays(30000, 6, np.full(3, -10.0), np.full(3, 10.0))
     h0 = want.trace(O, D)
-    os.environ["RT_WIDE_SAH"] = "1"
-    try:
-        ctx2 = capi.Context(0)
-    finally:
-        del os.environ["RT_WIDE_SAH"]
+    ctx2 = capi.Context(0)
+    ctx2.set_option("wide_sah", 1)
     sc = build(capi, ctx2, [(v, i)], [(0, None)])
     st, nodes, root = check_blas(sc, 0, v, i)
     n0 = want.wide_read(0)[0]

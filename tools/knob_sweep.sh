@@ -7,7 +7,7 @@ print('$1', round(d['ms_per_step'],4), {k:round(v['avg_ms'],4) for k,v in d['sta
 for rep in 1 2; do
   unset DXR_AMD_LIB
   run "default"
-  for l in 1 3; do RT_LEAF_MAX=$l run "RT_LEAF_MAX=$l"; done
-  for r in 2048 8192; do RT_SHADOW_CACHE_RES=$r run "RT_SHADOW_CACHE_RES=$r"; done
+  for l in 1 3; do RT_DEBUG_OPTIONS=leaf_max=$l run "RT_LEAF_MAX=$l"; done
+  for r in 2048 8192; do RT_DEBUG_OPTIONS=shadow_cache_res=$r run "RT_SHADOW_CACHE_RES=$r"; done
   for v in c32 c128 t64; do DXR_AMD_LIB=$PWD/dxrexperiments_amd/lib/variants/lib$v.so run "lib=$v"; done
 done
