@@ -65,46 +65,73 @@ def test_c5_ten_million_triangles(gpu, oracle, capi):
     one = pipe.read_output()
     ref, _ = p.o.render(mat, pfc, W, H, env_faces=scenes.sky_cubemap(32), tile=tile, max_radiance_depth=4, max_shadow_depth=2, nthreads=8)
     assert np.array_equal(one[tile[1]:tile[3], tile[0]:tile[2]], ref[tile[1]:tile[3], tile[0]:tile[2]])
-    # (round 4) ... and the WHOLE 3840 x 2160 frame, four bounces -- about 55 M rays through the oracle -- with its ray counts, when the
-    # box grants the host cores for it (16 on the driver's boxes: ~10 s)
+    # (round 4) ... and the WHOLE 3840 x 2160 frame, four bounces -- about 55 M rays through the oracle -- with its ray counts.
+    # Round 5: on every box, whatever cores it grants (16 on the driver's boxes: ~10 s; fewer cores take longer, they do not
+    # shrink the comparison to the window above without saying so)
     import os
     cores = len(os.sched_getaffinity(0))
-    if cores >= 12:
-        quarter = (0, 0, W, H)
-        ref, ost = p.o.render(mat, pfc, W, H, env_faces=scenes.sky_cubemap(32), max_radiance_depth=4, max_shadow_depth=2, nthreads=cores)
-        assert np.array_equal(one, ref), "%d pixels of the 4K frame differ" % int((one != ref).any(axis=2).sum())
-        pipe.clear_output()
-        pipe.render(tile=quarter)
-        gst = pipe.stats()
-        for key in ("rays_primary", "rays_secondary", "rays_shadow", "primary_hits", "secondary_hits"):
-            assert gst[key] == ost[key], (key, gst[key], ost[key])
+    quarter = (0, 0, W, H)
+    ref, ost = p.o.render(mat, pfc, W, H, env_faces=scenes.sky_cubemap(32), max_radiance_depth=4, max_shadow_depth=2, nthreads=cores)
+    assert np.array_equal(one, ref), "%d pixels of the 4K frame differ" % int((one != ref).any(axis=2).sum())
+    pipe.clear_output()
+    pipe.render(tile=quarter)
+    gst = pipe.stats()
+    for key in ("rays_primary", "rays_secondary", "rays_shadow", "primary_hits", "secondary_hits"):
+        assert gst[key] == ost[key], (key, gst[key], ost[key])
     rays = st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]
     print("\nC5: generate %.1fs, build both %.1fs (GPU BVH build %.1f ms), 4K frame %.2f ms = %.0f Mrays/s" % (
         t1 - t0, t2 - t1, p.g.build_ms(), st["ms_total"], rays / st["ms_total"] / 1e3))
 
 
-def test_c4_many_instances_realtime_denoise_4k(gpu, oracle, capi):
-    """BASELINE config 4 at its stated size: a TLAS over 4096 instances of TWO distinct BLASes -- the reference's own
-    assets/models/susanne.obj (968 triangles, ingested by the product's OBJ reader from the committed re-emission) and a
-    second mesh -- at 3840x2160 through RealtimeRaytracingPipeline (src/RealtimeRaytracingPipeline.cpp:201-235) and
-    DenoiseCompositor (src/DenoiseCompositor.cpp:109-148).  Both AOVs and the denoised composite of the WHOLE 4K frame
-    are compared with the oracle, bit for bit."""
+def _multi_mesh_fbx(path, verts, tris, parts, shift):
+    """Writes (verts, tris) as a binary FBX of `parts` Geometry nodes (tests/fbx_tools.py's writer), the triangles dealt to them
+    in runs, every mesh but the first under a Model with an Lcl Translation of k * shift: what the reference's importer
+    concatenates and pre-transforms into ONE RtModel (libs/DXRFramework/RtModel.cpp:26, :36-56)."""
+    import fbx_tools as F
+    meshes = []
+    per = (tris.shape[0] + parts - 1) // parts
+    for k in range(parts):
+        t = tris[k * per:(k + 1) * per]
+        m = dict(positions=verts["position"].astype(np.float64), polygons=[list(map(int, x)) for x in t],
+                 normals=verts["normal"][t.reshape(-1)].astype(np.float64), mapping="ByPolygonVertex")
+        if k:
+            m["translation"] = tuple(float(k) * np.asarray(shift, np.float64))
+        meshes.append(m)
+    F.write(path, meshes, version=7500 if parts % 2 else 7400, compress=bool(parts % 2))
+    return F.ingest(path)
+
+
+def test_c4_many_instances_realtime_denoise_4k(gpu, oracle, capi, tmp_path):
+    """BASELINE config 4 at its stated size and in its stated form ("FBX multi-mesh scene"): a TLAS over 4096 instances of TWO
+    distinct BLASes plus a ground plane, every BLAS ingested by the product's FBX reader through rt_model_create_from_file
+    (round 5) -- the reference's own assets/models/susanne.obj mesh written as a TWO-mesh binary FBX, a second mesh as a THREE-mesh
+    one (32-bit records, uncompressed arrays), and the reference's own ground.fbx (the committed re-emission) -- at 3840x2160
+    through RealtimeRaytracingPipeline (src/RealtimeRaytracingPipeline.cpp:201-235) and DenoiseCompositor
+    (src/DenoiseCompositor.cpp:109-148).  Both AOVs and the denoised composite of the WHOLE 4K frame are compared with the
+    oracle, bit for bit."""
     import os
     from util import GOLDEN
     sus = oracle.obj_load(os.path.join(GOLDEN, "susanne.obj"))
     assert sus[1].shape[0] == 968
     blob = scenes.blob_mesh(level=3)                              # 1280 triangles
+    fa, fb, fg = str(tmp_path / "susanne_two_meshes.fbx"), str(tmp_path / "blob_three_meshes.fbx"), os.path.join(GOLDEN, "ground.fbx")
+    ia = _multi_mesh_fbx(fa, sus[0], sus[1], 2, (0.0, 0.35, 0.0))
+    ib = _multi_mesh_fbx(fb, blob[0], blob[1], 3, (0.15, 0.0, 0.1))
     xf = scenes.instance_grid(64, spacing=3.0)                    # 4096 instances
     inst = [(k % 2, xf[k]) for k in range(xf.shape[0])]
-    p = Pair(oracle, capi, gpu, [sus, blob], inst)
-    # the product's own OBJ reader gives the arrays the pair was built from
-    gm = capi.Model(gpu, path=os.path.join(GOLDEN, "susanne.obj"))
-    gv, gi = gm.geometry()
-    assert np.array_equal(gv, sus[0]) and np.array_equal(gi, sus[1])
+    ground = np.array([0.3, 0, 0, 0, 0, 0.3, 0, -2.5, 0, 0, 0.3, 0], np.float32)      # the 400 x 400 plane scaled under the grid
+    inst.append((2, ground))
+    p = Pair(oracle, capi, gpu, [fa, fb, fg], inst)
+    # what the product's FBX reader handed over is what the independent parser reads from the same files
+    for gm, (iv, ii) in zip(p.gmodels, (ia, ib, None)):
+        gv, gi = gm.geometry()
+        if iv is not None:
+            assert np.array_equal(np.concatenate([gv["position"], gv["normal"]], 1), iv) and np.array_equal(gi, ii)
+    assert p.gmodels[0].geometry()[1].shape[0] == 968 and p.gmodels[1].geometry()[1].shape[0] == 1280 and p.gmodels[2].geometry()[1].shape[0] == 800
     gn, gk, gp, gd = p.g.bvh(-1)
     on, ok, op, od = p.o.bvh(-1)
     assert np.array_equal(gk, ok) and nodes_equal(gn, on) and np.array_equal(gp, op) and gd == od
-    for which in (0, 1):                                          # both BLASes (instance 0 uses model 0, instance 1 model 1)
+    for which in (0, 1, 4096):                                    # all three BLASes (instance 0 uses model 0, instance 1 model 1, the last the plane)
         gn, gk, gp, gd = p.g.bvh(which)
         on, ok, op, od = p.o.bvh(which)
         assert np.array_equal(gk, ok) and nodes_equal(gn, on) and np.array_equal(gp, op) and gd == od

@@ -270,3 +270,14 @@ def test_product_fbx_reader_on_the_reference_model(capi, pins):
     import fbx_tools as F
     iv, ii = F.ingest(REF + "/models/ground.fbx")           # the independent parser again, live
     assert sha(iv) == p["verts_sha256"] and sha(ii) == p["indices_sha256"]
+
+
+def test_product_fbx_reader_on_the_committed_ground_fixture(capi, pins):
+    """tests/golden/ground.fbx (make_ground_fbx.py: the reference's ground.fbx re-emitted by the independent writer) ingests to the
+    digests pinned on the reference's own file -- the fixture BASELINE configs[3]'s test builds a BLAS from on the GPU box."""
+    import os
+    from util import GOLDEN
+    p = pins["ground.fbx"]
+    v, i = capi.fbx_read(os.path.join(GOLDEN, "ground.fbx"))
+    assert v.shape[0] == p["vertices"] and i.shape[0] == p["triangles"]
+    assert sha(flat(v)) == p["verts_sha256"] and sha(i) == p["indices_sha256"]

@@ -51,13 +51,20 @@ class Pair:
     """The same scene on the oracle and on the GPU."""
 
     def __init__(self, oracle, capi, ctx, models, instances):
-        """models: list of (verts, idx); instances: list of (model_index, xform or None)."""
+        """models: list of (verts, idx), or of file paths the PRODUCT ingests (rt_model_create_from_file: .obj / .fbx) -- the
+        oracle then gets the arrays the product read; instances: list of (model_index, xform or None)."""
         self.o = oracle.Scene()
         self.g = capi.Scene(ctx)
         self.gmodels = []
-        for v, i in models:
+        for m in models:
+            if isinstance(m, str):
+                gm = capi.Model(ctx, path=m)
+                v, i = gm.geometry()
+            else:
+                v, i = m
+                gm = capi.Model(ctx, v, i)
             self.o.add_model(v, i)
-            self.gmodels.append(capi.Model(ctx, v, i))
+            self.gmodels.append(gm)
         for mi, x in instances:
             self.o.add_instance(mi, x)
             self.g.add_model(self.gmodels[mi], x)
