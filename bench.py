@@ -94,12 +94,28 @@ def parse(argv=None):
                     help="eye and look-at point for --obj (default: a view from outside the mesh's bounding box towards its centre)")
     ap.add_argument("--fov", type=float, default=None, help="vertical field of view in radians for --obj (default pi/4, src/utils/Camera.h:141-144)")
     ap.add_argument("--workload", choices=("c2", "c5"), default="c2", help="c5: ONLY the 10 M-triangle workload (profiling passes)")
+    ap.add_argument("--total-frames", type=int, default=None, metavar="T",
+                    help="BASELINE configs[2] as written: T frames IN ALL (256 spp) sharded over the --gpus ranks, each rank's ceil(T / N) in deferred "
+                         "sets, ONE all-reduce: that fixed-total run becomes the line's value (\"scaling\": \"strong\") and the K-frames-per-GPU run "
+                         "moves to \"weak_scaling\".  Without the flag the line is the weak one and carries the 256-frame run as \"strong_scaling\"")
+    ap.add_argument("--no-strong", action="store_true", help="skip the fixed-total pass")
     ap.add_argument("--partition", choices=("samples", "tiles"), default="samples",
                     help="samples (default, the headline): frames sharded over the GPUs, one all-reduce.  tiles: BASELINE configs[4], the "
                          "10 M-triangle 4K 4-bounce frame split into interleaved 16-row bands over the GPUs, one all-gather of the bands")
     args = ap.parse_args(argv)
     args.batch_given = any(a == "--batch" or a.startswith("--batch=") for a in (sys.argv[1:] if argv is None else argv))
     return args
+
+
+def fixed_total_plan(rank, world, total_frames, batch):
+    """Host logic of the fixed-total (strong-scaling) pass, BASELINE configs[2]: the frames of ONE global sequence rank `rank` renders
+    ({f : f mod world == rank}: dxrexperiments_amd.distributed.shard_frames = rt_shard_frame_count), the sets of launches they go
+    through and the frames per set (at most 32, sets of almost equal size)."""
+    mine = list(range(rank, total_frames, world))
+    per = max(1, min(batch, 32))
+    sets = (len(mine) + per - 1) // per
+    per_set = (len(mine) + sets - 1) // sets if sets else 1
+    return mine, sets, per_set
 
 
 def relaunch_distributed(args):
@@ -743,6 +759,67 @@ def main():
             sys.stderr.write("[bench] frames %d..%d: update+render calls %.2f ms, flush %.2f ms, sync %.2f ms\n"
                              % (lo, hi, (tb - ta) * 1e3, (tc - tb) * 1e3, (time.perf_counter() - tc) * 1e3))
 
+    def fixed_total(T_all):
+        """BASELINE configs[2] as it is written -- "256 spp accumulated, sample batches sharded across 8 MI355X with RCCL accum-buffer
+        reduce": T_all frames IN ALL.  Rank r renders the frames {f : f mod N == r} of ONE global sequence through update() + render()
+        in deferred sets of up to 32, then ONE all-reduce of the SUM image closes the timed region: strong scaling (the work is fixed,
+        a rank's share shrinks as N grows), the collective inside the time.  Every rank calls this (it is a collective)."""
+        host_s = capi.ProgressiveHost(4321)
+        host_s.options["maxIterations"] = max(1024, T_all + 1)
+        pf = [host_s.update(cam11, 0.0, f + 1, W, H) for f in range(T_all)]
+        mine_s, sets_s, S_s = fixed_total_plan(rank, world, T_all, args.batch)
+        assert mine_s == D.shard_frames(rank, world, T_all)
+        pipe.set_deferred(0)
+        pipe.clear_output()
+        pipe.set_accumulation_mode(T.ACCUM_SUM if world > 1 else T.ACCUM_RUNNING_MEAN)
+        if S_s > 1:
+            pipe.reserve_batch(S_s)
+        pipe.reset_totals()
+        evs = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0s = time.perf_counter()
+        pipe.set_deferred(S_s if S_s > 1 else 0)
+        for f in mine_s:
+            pipe.update(pf[f])
+            pipe.render()
+        pipe.flush()
+        evs[0].record()
+        total = len(mine_s)
+        if world > 1:
+            _, total = D.reduce_accumulation(acc, len(mine_s))
+        evs[1].record()
+        torch.cuda.synchronize()
+        mine_s_elapsed = time.perf_counter() - t0s
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0s
+        pipe.set_deferred(0)
+        ts = pipe.totals()
+        r_ = torch.tensor([el, float(ts["rays_primary"] + ts["rays_secondary"] + ts["rays_shadow"] - ts["rays_shadow_skipped"]), float(len(mine_s)),
+                           float(evs[0].elapsed_time(evs[1])), mine_s_elapsed], dtype=torch.float64, device=dev)
+        if world > 1:
+            mx_ = r_.clone()
+            mn_ = r_.clone()
+            dist.all_reduce(mx_, op=dist.ReduceOp.MAX)
+            dist.all_reduce(mn_, op=dist.ReduceOp.MIN)
+            dist.all_reduce(r_, op=dist.ReduceOp.SUM)
+            el = float(mx_[0].item())
+            coll, frames_max, rank_s = float(mx_[3].item()), int(mx_[2].item()), (float(mn_[4].item()), float(mx_[4].item()))
+        else:
+            coll, frames_max, rank_s = float(r_[3].item()), len(mine_s), (mine_s_elapsed, mine_s_elapsed)
+        assert total == T_all and int(round(float(r_[2].item()))) == T_all, "the ranks' shards do not add up to the total"
+        return {"metric": "Mrays/s (all traced rays), 1080p progressive, %d frames IN ALL sharded over the ranks + one all-reduce" % T_all,
+                "value": float(r_[1].item()) / el / 1e6, "unit": "Mrays/s", "scaling": "strong", "n_gpus": world,
+                "total_frames": T_all, "steps": T_all, "ms_per_step": el / T_all * 1e3, "elapsed_s": el, "frames_per_s": T_all / el,
+                "frames_per_rank_max": frames_max, "frames_per_launch_set": S_s, "launch_sets_per_rank": sets_s,
+                "collective_ms_max": coll, "collective_bytes": int(acc.numel() * 4) if world > 1 else 0,
+                "rank_elapsed_s_min_max": list(rank_s),
+                "accumulation": "sum + one all-reduce, mean = sum / %d" % T_all if world > 1 else "running mean",
+                "note": "BASELINE configs[2] as written; the time includes the collective.  At N = 1 this is the headline's own work in sets of %d "
+                        "(compare ms_per_step with repeat_of_timed_steps: both run late in the process)" % S_s}
+
     if S > 1:
         pipe.reserve_batch(S)           # the work memory of a set of S frames: sized outside the timed region, like the output
     if os.environ.get("DXR_BENCH_PREROLL"):       # experiment (profiles/r03/shadow_cache_coarse_level.txt): frames on ANOTHER pipeline first
@@ -884,6 +961,23 @@ def main():
                                                     "`value` is the FIRST pass; measured over rounds 3 - 4 it reads 3 - 7 % below this one (chip power state "
                                                     "after the idle set-up phase, a shadow cache still filling: profiles/r04/warmup_sensitivity.txt, preroll.txt) "
                                                     "and varies +-1.5 % from box to box"}
+    # the fixed-total form of configs[2] (every rank: it ends in a collective); at N = 1 after the extras above, which replay the timed frames
+    strong = None
+    if not args.no_strong:
+        strong = fixed_total(args.total_frames if args.total_frames else 256)
+    if rank == 0:
+        if strong is not None:
+            if args.total_frames:           # --total-frames: the strong line IS the line, the K-frames-per-GPU run rides along
+                weak = {k: out[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "scaling", "frames_per_s")}
+                out["weak_scaling"] = weak
+                for k in ("metric", "value", "steps", "ms_per_step", "scaling", "frames_per_s"):
+                    out[k] = strong[k]
+                out["config"]["total_frames"] = strong["total_frames"]
+                out["config"]["parallelism"] = ("sample-sharded x%d: %d frames in all, ceil(T / N) per rank in deferred sets, one RCCL all-reduce of the fp32 "
+                                                "accumulation buffer inside the timed region" % (world, strong["total_frames"])) if world > 1 else "single GPU"
+                out["strong_scaling"] = {k: v for k, v in strong.items() if k not in ("metric", "value", "unit", "steps", "ms_per_step", "scaling", "frames_per_s")}
+            else:
+                out["strong_scaling"] = strong
         if world == 1 and args.hbm_frames > 0 and not args.no_roofline:
             del pipe, scene, model
             hb = HBM_SET if S > 1 else 1                       # like the headline: sets of frames

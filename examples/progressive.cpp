@@ -50,9 +50,12 @@ int main(int argc, char **argv)
         pipeline->buildAccelerationStructures();
 
         const auto t0 = std::chrono::steady_clock::now();
-        // Default: one update() + render() per frame as the reference's app loop issues them (src/DXRExperimentsApp.cpp:162-165, :194);
-        // the pipeline records the frames and renders them in sets of 32 (deferred mode: the same image bit for bit, a quarter
-        // less time) -- DXR_DEFERRED=n changes the set size, 0 renders every frame at once.  DXR_SETS=n: the explicit form, renderBatch.
+        // One update() + render() per frame as the reference's app loop issues them (src/DXRExperimentsApp.cpp:162-165, :194).  This
+        // program looks at the image once, at the end, so it opts into deferred mode: the pipeline records the frames and renders
+        // them in sets of 32 (the same image bit for bit, a quarter less time) -- DXR_DEFERRED=n changes the set size, 0 renders
+        // every frame at once (the mirror's default, what an application that presents every frame wants).  DXR_SETS=n: the
+        // explicit form, renderBatch.
+        pipeline->setDeferredFrames(32);
         if (const char *d = std::getenv("DXR_DEFERRED")) pipeline->setDeferredFrames((UINT)std::atoi(d));
         const char *sets_env = std::getenv("DXR_SETS");
         const UINT per_set = sets_env ? (UINT)std::atoi(sets_env) : 1u;

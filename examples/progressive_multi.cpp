@@ -81,6 +81,7 @@ static int rank_main(int rank, int world, int id_in, int id_out, char **argv)
         void *image_dev = pipeline->getOutputResource(0);
 
         if (!tiles) ThrowIfFailed(rt_pipeline_set_accumulation_mode(p, RT_ACCUM_SUM));
+        if (!tiles) pipeline->setDeferredFrames(32);          // a headless accumulation: nobody looks at the image before the collective
         ThrowIfFailed(rt_context_synchronize(context->getHandle()));
         const auto t0 = std::chrono::steady_clock::now();
         uint32_t mine = 0;
@@ -94,7 +95,7 @@ static int rank_main(int rank, int world, int id_in, int id_out, char **argv)
         } else {
             for (UINT frame = 1; frame <= frames; ++frame) {
                 // every rank advances the SAME host state for every frame and renders its share of the frames (the pipeline records them
-                // and renders them in sets of up to 32: deferred mode, the mirror's default; the collective below flushes the last set)
+                // and renders them in sets of up to 32: deferred mode, opted into above; the collective below flushes the last set)
                 pipeline->update(0.0f, frame, (frame + 2) % 3, frame % 3, width, height);
                 if ((frame - 1) % (UINT)world == (UINT)rank) {
                     pipeline->render(frame % 3, width, height);
@@ -118,7 +119,27 @@ static int rank_main(int rank, int world, int id_in, int id_out, char **argv)
             ThrowIfFailed(rt_shard_frame_count(rank, world, frames, &expect));
             if (expect != mine) { std::fprintf(stderr, "rank %d rendered %u frames, expected %u\n", rank, mine, expect); return 5; }
         }
+        // every rank's traced rays, summed over the ranks by the same collective (a three-float device buffer)
+        double rays_all = 0.0;
+        {
+            rt_stats st;
+            ThrowIfFailed(rt_pipeline_get_totals(p, &st));
+            float mine_rays[4] = {float(double(st.rays_primary) / 1e6), float(double(st.rays_secondary) / 1e6), float((double(st.rays_shadow) - double(st.rays_shadow_skipped)) / 1e6), 0.0f};
+            void *d = nullptr;
+            ThrowIfFailed(rt_device_alloc(context->getHandle(), sizeof mine_rays, &d));
+            ThrowIfFailed(rt_device_upload(context->getHandle(), d, mine_rays, sizeof mine_rays));
+            ThrowIfFailed(rt_dist_all_reduce_sum(dist, d, 4));
+            ThrowIfFailed(rt_device_download(context->getHandle(), mine_rays, d, sizeof mine_rays));
+            ThrowIfFailed(rt_device_free(context->getHandle(), d));
+            rays_all = (double(mine_rays[0]) + mine_rays[1] + mine_rays[2]) * 1e6;
+        }
         if (rank == 0) {
+            // the line bench.py --total-frames prints for the same run (BASELINE configs[2]: a fixed total, the collective inside the time)
+            std::printf("{\"metric\": \"Mrays/s (all traced rays), progressive, %u frames IN ALL over the ranks + one %s\", \"value\": %.3f, \"unit\": \"Mrays/s\", "
+                        "\"n_gpus\": %d, \"steps\": %u, \"ms_per_step\": %.6f, \"higher_is_better\": true, \"scaling\": \"strong\", \"total_frames\": %u, "
+                        "\"frames_per_s\": %.3f, \"config\": {\"workload\": \"%s, %ux%u\", \"parallelism\": \"%s x%d\"}}\n",
+                        frames, tiles ? "all-gather" : "all-reduce", rays_all / s / 1e6, world, frames, s / frames * 1e3, frames, frames / s, argv[1], width, height,
+                        tiles ? "tile bands" : "sample shards", world);
             std::vector<float> image(size_t(width) * height * 4);
             pipeline->readOutput(image.data(), image.size() * sizeof(float));
             if (!tiles) for (float &v : image) v /= float(frames);     // SUM of all ranks' frames -> mean

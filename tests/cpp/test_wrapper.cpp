@@ -36,12 +36,15 @@ int main(int argc, char **argv)
         pipeline->createOutputResource(RT_FORMAT_R32G32B32A32_FLOAT, W, H);
         pipeline->buildAccelerationStructures();
         if (pipeline->getNumOutputs() != 1 || std::string(pipeline->getName()) != "Progressive Ray Tracing Pipeline") return 3;
+        // (round 5) render() renders unless the caller opts in: a fresh pipeline holds no frames back
+        if (static_cast<ProgressiveRaytracingPipeline *>(pipeline.get())->getDeferredFrames() != 0) return 18;
+        static_cast<ProgressiveRaytracingPipeline *>(pipeline.get())->setDeferredFrames(32);
         for (UINT frame = 1; frame <= 4; ++frame) {
             pipeline->update(0.0f, frame, 0, 0, W, H);
             pipeline->render(0, W, H);
         }
-        // (round 4) the mirror records the frames and renders them in sets behind update() + render(): four frames are held
-        // until something reads them
+        // (round 4) opted in, the mirror records the frames and renders them in sets behind update() + render(): four frames are
+        // held until something reads them
         if (static_cast<ProgressiveRaytracingPipeline *>(pipeline.get())->getDeferredFrames() != 32 ||
             static_cast<ProgressiveRaytracingPipeline *>(pipeline.get())->getPendingFrames() != 4) return 14;
         std::vector<float> image(size_t(W) * H * 4);

@@ -123,7 +123,7 @@ def test_c4_many_instances_realtime_denoise_4k(gpu, oracle, capi, tmp_path):
     inst.append((2, ground))
     p = Pair(oracle, capi, gpu, [fa, fb, fg], inst)
     # what the product's FBX reader handed over is what the independent parser reads from the same files
-    for gm, (iv, ii) in zip(p.gmodels, (ia, ib, None)):
+    for gm, (iv, ii) in zip(p.gmodels, (ia, ib, (None, None))):
         gv, gi = gm.geometry()
         if iv is not None:
             assert np.array_equal(np.concatenate([gv["position"], gv["normal"]], 1), iv) and np.array_equal(gi, ii)
@@ -205,6 +205,11 @@ def test_bench_two_ranks_on_one_gpu():
     assert len(rk["pci_bus_ids"]) == 2 and rk["pci_bus_ids"][0] == rk["pci_bus_ids"][1] and rk["distinct_devices"] == 1
     assert len(set(rk["pids"])) == 2 and all(ms > 0.0 for ms in rk["collective_ms"])
     assert 0.0 < rk["elapsed_s_min"] <= rk["elapsed_s_max"]
+    # (round 5) ... and carries BASELINE configs[2] as written beside the weak line: 256 frames IN ALL over the two ranks, one all-reduce
+    sg = d["strong_scaling"]
+    assert sg["scaling"] == "strong" and sg["n_gpus"] == 2 and sg["total_frames"] == 256 and sg["frames_per_rank_max"] == 128
+    assert sg["frames_per_launch_set"] == 32 and sg["launch_sets_per_rank"] == 4 and sg["value"] > 0 and sg["collective_ms_max"] > 0
+    assert sg["collective_bytes"] == 480 * 270 * 16
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--width", "480", "--height", "270",
                           "--cpu-seconds", "0", "--no-live-pmc", "--hbm-frames", "0"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-3000:]
@@ -234,6 +239,16 @@ def test_bench_two_ranks_on_one_gpu():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert key in d1 and key in d, key
     assert json.loads(json.dumps(d1)) == d1          # (no NaN / Infinity in the line)
+    s1 = d1["strong_scaling"]
+    assert s1["scaling"] == "strong" and s1["n_gpus"] == 1 and s1["total_frames"] == 256 and s1["collective_bytes"] == 0
+    # the fixed-total form as the line itself: --total-frames T
+    st = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--width", "480", "--height", "270", "--total-frames", "48",
+                         "--cpu-seconds", "0", "--no-live-pmc", "--hbm-frames", "0", "--no-roofline", "--no-frame-by-frame"], cwd=root, stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, text=True, timeout=600)
+    assert st.returncode == 0, st.stderr[-3000:]
+    d2 = json.loads([l for l in st.stdout.splitlines() if l.startswith("{")][-1])
+    assert d2["scaling"] == "strong" and d2["steps"] == 48 and d2["config"]["total_frames"] == 48 and d2["weak_scaling"]["scaling"] == "weak" and d2["weak_scaling"]["steps"] == 4
+    assert abs(d2["value"] * d2["ms_per_step"] * 48 / (d2["weak_scaling"]["value"] * d2["weak_scaling"]["ms_per_step"] * 4) - 12.0) < 0.5      # rays of 48 frames : rays of 4
 
 
 def test_tile_partition_two_ranks_on_one_gpu():

@@ -294,6 +294,50 @@ def test_sample_sharding_over_gloo_world2(tmp_path, oracle):
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists(), r.stdout[-2000:]
 
 
+STRONG_WORKER = r'''
+import importlib.util, os, sys
+import numpy as np, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root)
+from dxrexperiments_amd import distributed as D
+spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+def frame(f):          # a stand-in for frame f of the global sequence: every rank can make any frame, renders only its own
+    return np.random.default_rng(1000 + f).random((24, 32, 4), dtype=np.float32)
+for T_all, batch in ((256, 32), (7, 32), (1, 32), (61, 8)):
+    mine, sets, per_set = bench.fixed_total_plan(rank, world, T_all, batch)
+    assert mine == D.shard_frames(rank, world, T_all) and len(mine) == D.frames_per_rank(world, T_all)[rank]
+    assert per_set <= min(batch, 32) and sets * per_set >= len(mine) and (sets == 0 or (sets - 1) * per_set < len(mine))
+    acc = np.zeros((24, 32, 4), np.float32)
+    for f in mine:                           # RT_ACCUM_SUM: the rank's frames added in its own order
+        acc = acc + frame(f)
+    mean, total = D.reduce_accumulation(torch.from_numpy(acc), len(mine))      # ONE all-reduce (+ the frame count)
+    assert total == T_all
+    run = np.zeros((24, 32, 4), np.float32)  # the single-GPU running mean of ALL frames in order (ProgressiveRaytracing.hlsl:36-38)
+    for f in range(T_all):
+        run = (np.float32(f) * run + frame(f)) / np.float32(f + 1)
+    rms = float(np.sqrt(np.mean((mean.numpy().astype(np.float64) - run) ** 2)))
+    assert rms <= 1e-5, (T_all, rms)
+dist.barrier(); dist.destroy_process_group()
+open(os.path.join(sys.argv[2], "strong_ok_%d" % rank), "w").write("ok")
+'''
+
+
+def test_fixed_total_strong_scaling_over_gloo_world2(tmp_path):
+    """bench.py --total-frames (BASELINE configs[2] as written: 256 frames IN ALL over the ranks, one all-reduce): the host logic of the
+    pass -- shards, sets of launches, SUM + all-reduce + mean -- on two CPU processes over gloo; ragged totals included."""
+    script = tmp_path / "strong_worker.py"
+    script.write_text(STRONG_WORKER)
+    port = 29300 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script), ROOT, str(tmp_path)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert (tmp_path / "strong_ok_0").exists() and (tmp_path / "strong_ok_1").exists(), r.stdout[-2000:]
+
+
 def test_shard_helpers(capi):
     """The partitions are host logic of the C ABI (rt_shard_frame_count, rt_tile_bands, rt_tile_gather_layout)."""
     from dxrexperiments_amd import distributed as D
