@@ -70,10 +70,11 @@ bool read_array(const Reader &r, size_t &p, char type, Prop &out)
     std::vector<unsigned char> raw((size_t)count * es);
     if (enc == 0) {
         if (clen != raw.size()) return false;
-        memcpy(raw.data(), r.d + p, raw.size());
+        if (!raw.empty()) memcpy(raw.data(), r.d + p, raw.size());      // (an empty array has no storage: memcpy(nullptr, ., 0) is undefined by the letter -- found by tests/test_sanitized_parsers.py)
     } else if (enc == 1) {
         uLongf dl = (uLongf)raw.size();
-        if (uncompress(raw.data(), &dl, r.d + p, clen) != Z_OK || dl != raw.size()) return false;
+        unsigned char none = 0;
+        if (uncompress(raw.empty() ? &none : raw.data(), &dl, r.d + p, clen) != Z_OK || dl != raw.size()) return false;
     } else return false;
     p += clen;
     out.nums.resize(count);

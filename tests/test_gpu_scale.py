@@ -131,9 +131,9 @@ def test_c4_many_instances_realtime_denoise_4k(gpu, oracle, capi, tmp_path):
     gn, gk, gp, gd = p.g.bvh(-1)
     on, ok, op, od = p.o.bvh(-1)
     assert np.array_equal(gk, ok) and nodes_equal(gn, on) and np.array_equal(gp, op) and gd == od
-    for which in (0, 1, 4096):                                    # all three BLASes (instance 0 uses model 0, instance 1 model 1, the last the plane)
+    for which, model in ((0, 0), (1, 1), (4096, 2)):              # all three BLASes (instance 0 uses model 0, instance 1 model 1, the last the plane)
         gn, gk, gp, gd = p.g.bvh(which)
-        on, ok, op, od = p.o.bvh(which)
+        on, ok, op, od = p.o.bvh(model)
         assert np.array_equal(gk, ok) and nodes_equal(gn, on) and np.array_equal(gp, op) and gd == od
     O, D = random_rays(200000, 22, [-100, -3, -100], [100, 3, 100])
     for flags in (0, CULL):
