@@ -90,6 +90,10 @@ def parse(argv=None):
                     "per frame, which the default run also measures and reports as `frame_by_frame`")
     ap.add_argument("--obj", default=None, help="render this Wavefront OBJ instead of the procedural atrium (e.g. the real Sponza); "
                     "config.workload then names the file and its triangle count")
+    ap.add_argument("--scene", choices=("atrium", "stadium", "stadium2m"), default="atrium",
+                    help="atrium: BASELINE configs[1], the headline (default).  stadium / stadium2m: the stress scene with real-asset triangle "
+                         "statistics (scenes.stadium_class: huge quads under dense detail, slivers, log-normal areas; ~272 k / ~2.2 M triangles) -- "
+                         "a comparison line, not the headline")
     ap.add_argument("--camera", type=float, nargs=6, default=None, metavar=("EX", "EY", "EZ", "AX", "AY", "AZ"),
                     help="eye and look-at point for --obj (default: a view from outside the mesh's bounding box towards its centre)")
     ap.add_argument("--fov", type=float, default=None, help="vertical field of view in radians for --obj (default pi/4, src/utils/Camera.h:141-144)")
@@ -359,7 +363,7 @@ def headline_roofline(args, stages, dom, n_t, n_sets, S, live, W, H, ms_per_step
     d = stages[dom]
     prof_name = "c2" if S == 1 else ("c2s" if S <= 24 and committed_profile("c2s") else "c2b")
     # (the committed counters are those of the default workload: they stand in for live ones only when this run is that workload)
-    default_workload = (W, H) == (1920, 1080) and not args.obj and not args.camera
+    default_workload = (W, H) == (1920, 1080) and not args.obj and not args.camera and args.scene == "atrium"
     prof = committed_profile(prof_name).get("kernels", {}).get(d["kernel"], {}) if default_workload else {}
     lv = live.get("c2", {}).get(d["kernel"], {})
     # a launch covers a set of frames: stage times are per frame (stage_table), hardware counters per launch
@@ -524,6 +528,10 @@ def headline_workload(args, capi, scenes, np):
         eye, at = (args.camera[:3], args.camera[3:]) if args.camera else (centre + np.array([0.35, 0.2, 1.0]) * ext, centre)
         cam = dict(eye=tuple(float(x) for x in eye), at=tuple(float(x) for x in at), up=(0.0, 1.0, 0.0),
                    fov=args.fov if args.fov else float(np.float32(np.pi / 4)))
+    elif getattr(args, "scene", "atrium") != "atrium":
+        verts, tris = scenes.stadium_class(seed=5, scale=8.0 if args.scene == "stadium2m" else 1.0)
+        workload = "stress scene with real-asset triangle statistics (scenes.stadium_class, seed 5, %d triangles; NOT the headline workload)" % tris.shape[0]
+        cam = scenes.stadium_camera()
     else:
         verts, tris = scenes.sponza_class(seed=42)
         workload = "BASELINE configs[1]: Sponza-class procedural atrium (seed 42, %d triangles)" % tris.shape[0]

@@ -314,6 +314,120 @@ def displaced_grid(n_side, seed=7, extent=40.0):
 
 
 # ---------------------------------------------------------------------------
+# Stress scene with real-asset triangle statistics ("teapot in a stadium", round 5, VERDICT r4 task 6)
+# ---------------------------------------------------------------------------
+
+def stadium_class(seed=5, scale=1.0):
+    """A hall of a FEW huge quads with dense detail standing on them, cables and slats of 20:1 ... 2000:1 slivers through the air, and a
+    debris field whose triangle areas are log-normal over four decades: what a scanned or modelled asset looks like to a BVH builder and
+    what no uniformly tessellated procedural mesh does (every timed scene of rounds 1 - 4; the reference's default scene is a real
+    asset, src/DXRExperimentsApp.cpp:91, Machines.fbx, not in the checkout).  scale = 1 -> about 262 k triangles (the headline
+    scene's count), scale = 8 -> about 2 M.  Hall: x in [-30, 30], z in [-20, 20], floor y = -4, roof y = 14.
+    Composition at scale 1: 16 hall triangles (floor, four walls, two roof halves with a slot of sky between them: 600 - 2400 m^2 each);
+    ~110 k triangles in 7 'teapots' (displaced icospheres of 2 - 80 k triangles, 0.3 - 2 m across, mm- to cm-sized triangles) on the floor
+    and on 3 plinth boxes; ~12 k in 1500 cables (strips 15 - 55 m long, 6 - 30 mm wide, four segments each: slivers of ~1000:1) and ~30 k
+    in two slatted fences and a grandstand of long steps (slats 20:1 ... 60:1); ~110 k debris triangles, log-normal edge length with
+    sigma = 1.15 (areas over four decades, 1 mm^2 ... 10 m^2), 70 % of them in eight clusters, isotropic orientation, each with a
+    random 1:1 ... 20:1 aspect."""
+    rng = np.random.default_rng(seed)
+    mb = MeshBuilder()
+    X0, X1, Z0, Z1, Y0, Y1 = -30.0, 30.0, -20.0, 20.0, -4.0, 14.0
+
+    def quad(a, b, c, d):                  # two triangles, front face = cross(b - a, c - a)
+        p = np.array([a, b, c, d], np.float64)
+        n = np.cross(p[1] - p[0], p[2] - p[0])
+        mb.add(p, [[0, 1, 2], [0, 2, 3]], np.tile(n / np.linalg.norm(n), (4, 1)))
+    # the hall: huge quads, normals into the room
+    quad((X0, Y0, Z1), (X1, Y0, Z1), (X1, Y0, Z0), (X0, Y0, Z0))                      # floor (+y)
+    quad((X0, Y0, Z0), (X1, Y0, Z0), (X1, Y1, Z0), (X0, Y1, Z0))                      # -z wall (+z)
+    quad((X1, Y0, Z1), (X0, Y0, Z1), (X0, Y1, Z1), (X1, Y1, Z1))                      # +z wall (-z)
+    quad((X0, Y0, Z1), (X0, Y0, Z0), (X0, Y1, Z0), (X0, Y1, Z1))                      # -x wall (+x)
+    quad((X1, Y0, Z0), (X1, Y0, Z1), (X1, Y1, Z1), (X1, Y1, Z0))                      # +x wall (-x)
+    quad((X0, Y1, Z0), (X1, Y1, Z0), (X1, Y1, -3.0), (X0, Y1, -3.0))                  # roof halves (-y), a 6 m slot of sky between them
+    quad((X0, Y1, 3.0), (X1, Y1, 3.0), (X1, Y1, Z1), (X0, Y1, Z1))
+
+    # plinths (large quads under dense detail) and the 'teapots' on them / on the floor
+    plinths = [((-14.0, Y0, -6.0), (-8.0, Y0 + 1.2, 0.0)), ((4.0, Y0, 5.0), (9.0, Y0 + 0.8, 10.0)), ((14.0, Y0, -12.0), (22.0, Y0 + 2.0, -5.0))]
+    for lo, hi in plinths:
+        mb.box(lo, hi)
+    lv_hi = 6 if scale >= 1.0 else 5
+    pots = [(-11.0, Y0 + 1.2, -3.0, 1.0, lv_hi), (6.5, Y0 + 0.8, 7.5, 0.8, 5), (18.0, Y0 + 2.0, -8.5, 0.9, 5), (-2.0, Y0, 3.0, 0.45, 4),
+            (-20.0, Y0, 12.0, 0.3, 4), (24.0, Y0, 14.0, 0.35, 3), (0.0, Y0, -14.0, 0.15, 3)]
+    reps = max(1, int(round(scale)))
+    for rep in range(reps):
+        for k, (cx, cy, cz, r, lv) in enumerate(pots):
+            sp, sf = icosphere(lv)
+            ph = 1.7 * k + 0.31 * rep
+            d = 1.0 + 0.2 * np.sin(5.0 * sp[:, 0] + ph) * np.sin(4.0 * sp[:, 1] + 2.0 * ph) + 0.08 * np.sin(17.0 * sp[:, 2] + ph) * np.cos(13.0 * sp[:, 0])
+            off = np.array([0.0, 0.0, 0.0]) if rep == 0 else np.array([rng.uniform(-3.0, 3.0), 0.0, rng.uniform(-3.0, 3.0)])
+            mb.add(sp * (d * r)[:, None] * np.array([1.0, 0.8, 1.0]) + np.array([cx, cy + 0.8 * r * 0.82, cz]) + off, sf)
+
+    # cables: long thin strips through the air (four segments each, ~1000:1 slivers), sagging a little
+    n_cab = int(1500 * scale)
+    a = np.stack([rng.uniform(X0 + 1, X1 - 1, n_cab), rng.uniform(Y0 + 3.0, Y1 - 0.5, n_cab), rng.uniform(Z0 + 1, Z1 - 1, n_cab)], 1)
+    dirn = rng.normal(size=(n_cab, 3)) * np.array([1.0, 0.12, 0.7])
+    dirn /= np.linalg.norm(dirn, axis=1, keepdims=True)
+    length = rng.uniform(15.0, 55.0, n_cab)
+    width = rng.uniform(0.006, 0.03, n_cab)
+    side = np.cross(dirn, np.array([0.0, 1.0, 0.0]))
+    side /= np.linalg.norm(side, axis=1, keepdims=True)
+    t = np.linspace(-0.5, 0.5, 5)
+    for k in range(n_cab):
+        c = a[k] + dirn[k] * (t * length[k])[:, None]
+        c[:, 1] -= 0.6 * (1.0 - (2.0 * t) ** 2)                      # sag
+        c = np.clip(c, [X0 + 0.05, Y0 + 0.05, Z0 + 0.05], [X1 - 0.05, Y1 - 0.05, Z1 - 0.05])
+        p = np.concatenate([c - 0.5 * width[k] * side[k], c + 0.5 * width[k] * side[k]])
+        tri = [[i, i + 1, 6 + i] for i in range(4)] + [[i, 6 + i, 5 + i] for i in range(4)]
+        mb.add(p, tri)
+
+    # slatted fences (20:1 ... 60:1 slats) and a grandstand of long steps
+    for zc, n_slats in ((-16.0, int(700 * scale)), (15.0, int(500 * scale))):
+        for xs in np.linspace(X0 + 2.0, X1 - 2.0, n_slats):
+            h = 1.2 + 1.8 * _hash01(np.array([int(xs * 1000)]), seed + 3)[0]
+            mb.box((xs - 0.025, Y0, zc - 0.02), (xs + 0.025, Y0 + h, zc + 0.02))
+    for k in range(int(40 * min(scale, 2.0))):
+        y = Y0 + 0.25 * k
+        z = Z0 + 0.5 + 0.3 * k
+        mb.box((X0 + 3.0, y, z), (X1 - 3.0, y + 0.25, z + 0.3))
+
+    # debris: log-normal edge lengths (sigma 1.15 -> areas over ~4 decades), clustered, isotropic, aspect 1:1 ... 20:1
+    n_deb = int(110000 * scale)
+    centres = np.stack([rng.uniform(X0 + 4, X1 - 4, 8), rng.uniform(Y0, Y0 + 6.0, 8), rng.uniform(Z0 + 4, Z1 - 4, 8)], 1)
+    which = rng.integers(0, 8, n_deb)
+    clustered = rng.random(n_deb) < 0.7
+    c = np.where(clustered[:, None], centres[which] + rng.normal(size=(n_deb, 3)) * np.array([2.5, 1.2, 2.5]),
+                 np.stack([rng.uniform(X0 + 0.5, X1 - 0.5, n_deb), rng.uniform(Y0 + 0.05, Y1 - 0.5, n_deb), rng.uniform(Z0 + 0.5, Z1 - 0.5, n_deb)], 1))
+    edge = np.clip(np.exp(rng.normal(np.log(0.06), 1.15, n_deb)), 0.0015, 4.5)
+    aspect = np.exp(rng.uniform(0.0, np.log(20.0), n_deb))
+    u = rng.normal(size=(n_deb, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    w = np.cross(u, rng.normal(size=(n_deb, 3))); w /= np.linalg.norm(w, axis=1, keepdims=True)
+    p0 = c - 0.5 * edge[:, None] * u
+    p1 = c + 0.5 * edge[:, None] * u
+    p2 = c + (edge / aspect)[:, None] * w + (rng.uniform(-0.5, 0.5, n_deb) * edge)[:, None] * u
+    pts = np.clip(np.stack([p0, p1, p2], 1), [X0 + 0.02, Y0 + 0.02, Z0 + 0.02], [X1 - 0.02, Y1 - 0.02, Z1 - 0.02]).reshape(-1, 3)
+    fn = np.cross(pts[1::3] - pts[0::3], pts[2::3] - pts[0::3])
+    ln = np.linalg.norm(fn, axis=1, keepdims=True)
+    ln[ln == 0] = 1.0
+    mb.add(pts, np.arange(3 * n_deb, dtype=np.uint32).reshape(-1, 3), np.repeat(fn / ln, 3, axis=0))
+    return mb.finish()
+
+
+def stadium_camera():
+    """From a corner of the hall, 2.5 m above the floor, across the plinths and the debris clusters towards the far corner: the frame holds
+    the floor and two walls (a few huge triangles), the dense meshes, cables against the roof slot's sky."""
+    return dict(eye=(-26.0, -1.5, 16.0), at=(8.0, -1.0, -6.0), up=(0.0, 1.0, 0.0), fov=float(np.float32(np.pi / 4)))
+
+
+def triangle_statistics(verts, tris):
+    """(areas, aspect) per triangle: area, and longest edge^2 / (2 * area) -- 1.15 for an equilateral triangle, ~L / h for a sliver."""
+    p = verts["position"].astype(np.float64)
+    a, b, c = p[tris[:, 0]], p[tris[:, 1]], p[tris[:, 2]]
+    area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    longest = np.maximum(np.maximum(((b - a) ** 2).sum(1), ((c - b) ** 2).sum(1)), ((a - c) ** 2).sum(1))
+    return area, longest / np.maximum(2.0 * area, 1e-300)
+
+
+# ---------------------------------------------------------------------------
 # OBJ writer (fixtures) and a procedural sky cube map
 # ---------------------------------------------------------------------------
 
