@@ -317,7 +317,7 @@ def displaced_grid(n_side, seed=7, extent=40.0):
 # Stress scene with real-asset triangle statistics ("teapot in a stadium", round 5, VERDICT r4 task 6)
 # ---------------------------------------------------------------------------
 
-def stadium_class(seed=5, scale=1.0):
+def stadium_class(seed=5, scale=1.0, parts=("hall", "pots", "cables", "slats", "debris")):
     """A hall of a FEW huge quads with dense detail standing on them, cables and slats of 20:1 ... 2000:1 slivers through the air, and a
     debris field whose triangle areas are log-normal over four decades: what a scanned or modelled asset looks like to a BVH builder and
     what no uniformly tessellated procedural mesh does (every timed scene of rounds 1 - 4; the reference's default scene is a real
@@ -328,7 +328,7 @@ def stadium_class(seed=5, scale=1.0):
     and on 3 plinth boxes; ~12 k in 1500 cables (strips 15 - 55 m long, 6 - 30 mm wide, four segments each: slivers of ~1000:1) and ~30 k
     in two slatted fences and a grandstand of long steps (slats 20:1 ... 60:1); ~110 k debris triangles, log-normal edge length with
     sigma = 1.15 (areas over four decades, 1 mm^2 ... 10 m^2), 70 % of them in eight clusters, isotropic orientation, each with a
-    random 1:1 ... 20:1 aspect."""
+    random 1:1 ... 20:1 aspect.  parts: which of the components to build (experiments: what each one costs a builder)."""
     rng = np.random.default_rng(seed)
     mb = MeshBuilder()
     X0, X1, Z0, Z1, Y0, Y1 = -30.0, 30.0, -20.0, 20.0, -4.0, 14.0
@@ -347,13 +347,15 @@ def stadium_class(seed=5, scale=1.0):
     quad((X0, Y1, 3.0), (X1, Y1, 3.0), (X1, Y1, Z1), (X0, Y1, Z1))
 
     # plinths (large quads under dense detail) and the 'teapots' on them / on the floor
+    if "hall" not in parts:
+        mb = MeshBuilder()
     plinths = [((-14.0, Y0, -6.0), (-8.0, Y0 + 1.2, 0.0)), ((4.0, Y0, 5.0), (9.0, Y0 + 0.8, 10.0)), ((14.0, Y0, -12.0), (22.0, Y0 + 2.0, -5.0))]
     for lo, hi in plinths:
         mb.box(lo, hi)
     lv_hi = 6 if scale >= 1.0 else 5
     pots = [(-11.0, Y0 + 1.2, -3.0, 1.0, lv_hi), (6.5, Y0 + 0.8, 7.5, 0.8, 5), (18.0, Y0 + 2.0, -8.5, 0.9, 5), (-2.0, Y0, 3.0, 0.45, 4),
             (-20.0, Y0, 12.0, 0.3, 4), (24.0, Y0, 14.0, 0.35, 3), (0.0, Y0, -14.0, 0.15, 3)]
-    reps = max(1, int(round(scale)))
+    reps = max(1, int(round(scale))) if "pots" in parts else 0
     for rep in range(reps):
         for k, (cx, cy, cz, r, lv) in enumerate(pots):
             sp, sf = icosphere(lv)
@@ -363,7 +365,7 @@ def stadium_class(seed=5, scale=1.0):
             mb.add(sp * (d * r)[:, None] * np.array([1.0, 0.8, 1.0]) + np.array([cx, cy + 0.8 * r * 0.82, cz]) + off, sf)
 
     # cables: long thin strips through the air (four segments each, ~1000:1 slivers), sagging a little
-    n_cab = int(1500 * scale)
+    n_cab = int(1500 * scale) if "cables" in parts else 0
     a = np.stack([rng.uniform(X0 + 1, X1 - 1, n_cab), rng.uniform(Y0 + 3.0, Y1 - 0.5, n_cab), rng.uniform(Z0 + 1, Z1 - 1, n_cab)], 1)
     dirn = rng.normal(size=(n_cab, 3)) * np.array([1.0, 0.12, 0.7])
     dirn /= np.linalg.norm(dirn, axis=1, keepdims=True)
@@ -381,17 +383,17 @@ def stadium_class(seed=5, scale=1.0):
         mb.add(p, tri)
 
     # slatted fences (20:1 ... 60:1 slats) and a grandstand of long steps
-    for zc, n_slats in ((-16.0, int(700 * scale)), (15.0, int(500 * scale))):
+    for zc, n_slats in ((-16.0, int(700 * scale)), (15.0, int(500 * scale))) if "slats" in parts else ():
         for xs in np.linspace(X0 + 2.0, X1 - 2.0, n_slats):
             h = 1.2 + 1.8 * _hash01(np.array([int(xs * 1000)]), seed + 3)[0]
             mb.box((xs - 0.025, Y0, zc - 0.02), (xs + 0.025, Y0 + h, zc + 0.02))
-    for k in range(int(40 * min(scale, 2.0))):
+    for k in range(int(40 * min(scale, 2.0)) if "slats" in parts else 0):
         y = Y0 + 0.25 * k
         z = Z0 + 0.5 + 0.3 * k
         mb.box((X0 + 3.0, y, z), (X1 - 3.0, y + 0.25, z + 0.3))
 
     # debris: log-normal edge lengths (sigma 1.15 -> areas over ~4 decades), clustered, isotropic, aspect 1:1 ... 20:1
-    n_deb = int(110000 * scale)
+    n_deb = int(110000 * scale) if "debris" in parts else 1
     centres = np.stack([rng.uniform(X0 + 4, X1 - 4, 8), rng.uniform(Y0, Y0 + 6.0, 8), rng.uniform(Z0 + 4, Z1 - 4, 8)], 1)
     which = rng.integers(0, 8, n_deb)
     clustered = rng.random(n_deb) < 0.7

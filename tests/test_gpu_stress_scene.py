@@ -23,7 +23,8 @@ def test_stadium_statistics_are_those_of_an_asset():
     assert (aspect > 20.0).mean() > 0.05 and (aspect > 200.0).mean() > 0.02                 # slats and cables
     sv, st = scenes.sponza_class()
     sa, sasp = scenes.triangle_statistics(sv, st)
-    assert np.log10(np.percentile(sa, 99.9) / np.percentile(sa, 1.0)) < 2.5 and (sasp > 20.0).mean() < 0.001       # ... which the headline scene has not
+    # ... which the headline scene has not: 98 % of its triangles within 1.5 decades of area, no slivers
+    assert np.log10(np.percentile(sa, 99.0) / np.percentile(sa, 1.0)) < 2.0 and (sasp > 20.0).mean() < 0.001
 
 
 def test_stadium_bvh_walk_and_whole_frame_against_the_oracle(gpu, oracle, capi):
