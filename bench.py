@@ -907,8 +907,11 @@ def main():
                        "entry_point": "rt_pipeline_update + rt_pipeline_render per frame" + (" (deferred mode: rt_pipeline_set_deferred(%d) renders the "
                                       "recorded frames through shared sets of launches, the same image bit for bit)" % S if S > 1 else ""),
                        "queue_memory_bytes_per_frame": pipe.queue_memory()[0] / max(S, 1),
-                       # (the traversal kernels' global stack rows behind the LDS rows: reserved with the queues, never touched by this scene's rays)
-                       "global_stack_rows_bytes_per_frame": ctx.stack_memory() / max(S, 1)},
+                       # (the traversal kernels' global stack rows behind the LDS rows, never touched by this scene's rays.  Round 5: rows for the
+                       #  resident threads of the persistent launches only -- one allocation per context whatever the set's size; the
+                       #  one-tile-per-wave primary launch keeps none (k_primary_retry).  Rounds 1 - 4: 224 MB per frame of a set.)
+                       "global_stack_rows_bytes_per_frame": ctx.stack_memory() / max(S, 1),
+                       "global_stack_rows_bytes_per_context": ctx.stack_memory()},
             "primary_mrays_per_s": primary_all / elapsed / 1e6,
             "frames_per_s": K * world / elapsed,
             "rays_per_frame": rays_all / (K * world),

@@ -131,6 +131,7 @@ extern "C" int rt_debug_set_option(rt_context *c, const char *name, const char *
     else if (n == "primary_persistent") { if (iv < -1 || iv > 1) return bad(); c->opt_primary_persistent = (int)iv; }
     else if (n == "seven_waves_always") c->opt_seven_waves_always = iv != 0;
     else if (n == "free_radius") c->opt_free_radius = iv != 0;
+    else if (n == "primary_retry_cap") { if (iv < 0 || iv > (1 << 24)) return bad(); c->opt_primary_retry_cap = (uint32_t)iv; }
     else if (n == "batch_max") { if (iv < 0 || iv > 32) return bad(); c->opt_batch_max = (uint32_t)iv; }
     else if (n == "queue_budget_mb") { if (iv < 0) return bad(); c->opt_queue_budget_mb = (size_t)iv; }
     else if (n == "dist_check_seconds") { if (!(fv >= 0.0)) return bad(); c->opt_dist_check_seconds = fv; }

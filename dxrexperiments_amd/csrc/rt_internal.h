@@ -208,6 +208,7 @@ struct rt_context {
     bool opt_seven_waves_always = false;    // seven_waves_always=1: single frames on the sets' kernels
     bool opt_free_radius = true;            // free_radius=0: no free sphere around the point light
     uint32_t opt_batch_max = 0;             // batch_max: frames per set of launches (0: RT_MAX_BATCH)
+    uint32_t opt_primary_retry_cap = 0;     // primary_retry_cap: entries of the primary launch's retry list (0: 2^20; tests: a few, so that the list overflows)
     size_t opt_queue_budget_mb = 0;         // queue_budget_mb: worst-case queue bytes a set may reserve up front (0: a quarter of the device)
     double opt_dist_check_seconds = 5.0;    // dist_check_seconds: how long rt_dist_create waits for the other ranks' device ids
     std::vector<struct rt_pipeline *> deferred;      // pipelines holding frames that render() has accepted and not rendered yet
@@ -329,8 +330,10 @@ static inline unsigned rt_persistent_grid(const rt_context *ctx, K kernel, int b
 #define RT_LDS_STACK_ROWS_SETS 14
 #endif
 
-// The scene as the traversal kernels see it, with the global stack rows a launch of `threads` threads whose
-// kernels keep `lds_rows` rows in LDS may need: the tree bounds a walk to stack_need (+1 speculative) entries.
+// The scene as the traversal kernels see it, with the global stack rows a PERSISTENT launch of `threads` threads whose
+// kernels keep `lds_rows` rows in LDS may need: the tree bounds a walk to stack_need (+1 speculative) entries.  (Round 5: the only launch
+// that is not persistent, the one-tile-per-wave primary stage -- one thread per pixel slot: 224 MB of rows per 1080p frame of a set in
+// rounds 1 - 4 -- keeps none: rt_trace_wave.h NO_DEEP.)
 static inline int rt_scene_dev_for_launch(rt_context *ctx, const rt_scene *s, uint32_t lds_rows, size_t threads, SceneDev *out)
 {
     *out = s->dev();

@@ -74,8 +74,31 @@ struct PrimarySrcT {
         r = primary_ray(pd, px, py);
         return valid;
     }
+    // (NO_DEEP launches, rt_trace_wave.h) the walk of pixel slot q would need a stack row beyond the LDS ones: k_primary_retry takes it from here
+    RT_DEV void overflow(uint32_t q) const
+    {
+        const uint32_t k = atomicAdd(&pd.retry[0], 1u);
+        if (k < pd.retry_cap) pd.retry[2u + k] = q;
+    }
 };
 typedef PrimarySrcT<true> PrimarySrc;        // (the counting kernels)
+// The pixel slots the one-tile-per-wave primary launch gave up (PipeDev::retry), as a ray source for a persistent launch WITH rows beyond
+// LDS; a list that overflowed stands for every slot.  Slots come in any order here: every lane finds its own frame.
+struct PrimaryRetrySrc {
+    const PipeDev &pd;
+    RT_DEV uint32_t count() const { const uint32_t n = pd.retry[0]; return n <= pd.retry_cap ? n : pd.cap; }
+    RT_DEV uint32_t flags() const { return RT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES; }
+    RT_DEV bool load(uint32_t i, RayD &r, uint32_t &ticket) const
+    {
+        const uint32_t q = pd.retry[0] <= pd.retry_cap ? pd.retry[2u + i] : i;
+        ticket = q;
+        uint32_t px, py, ql;
+        const uint32_t f = slot_frame(pd, q, ql);
+        const bool valid = pix_xy(pd, ql, px, py);
+        r = pd.n_frames > 1u ? primary_ray(pd, pd.pfcs[f].cameraParams, px, py) : primary_ray(pd, px, py);
+        return valid;
+    }
+};
 template <bool BATCH>
 struct PrimarySinkT {
     const PipeDev &pd;
@@ -94,7 +117,10 @@ struct PrimarySinkT {
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU __attribute__((amdgpu_waves_per_eu(TWO_LEVEL ? 5 : STACK == RT_LDS_STACK_ROWS_SETS ? 7 : STACK == RT_LDS_STACK_ROWS ? 6 : 1)))
 #endif
-template <int STACK, bool TWO_LEVEL, bool BATCH>
+// PERSIST = false: one 8x8 tile per wave, dealt by the hardware dispatcher -- one thread per pixel slot, so this launch keeps NO stack rows
+// beyond LDS (NO_DEEP: a ray that would need one goes to PipeDev::retry and k_primary_retry walks it); true: a persistent launch that refills
+// its lanes from a pool of tiles (two-level scenes), with rows by resident thread like the other persistent launches
+template <int STACK, bool TWO_LEVEL, bool BATCH, bool PERSIST>
 __global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_primary(PipeDev pd)
 {
     __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
@@ -104,8 +130,20 @@ __global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_primary(PipeDev pd)
         for (uint32_t i = threadIdx.x; i < (uint32_t)(POOL_OFFSET_WORDS + POOL_BYTES / 4); i += PBLOCK) pd.counters[i] = 0u;
     PrimarySrcT<BATCH> src = {pd};
     PrimarySinkT<BATCH> sink = {pd};
-    // one 8x8 tile per wave, dealt by the hardware dispatcher -- or (experiment) a persistent launch that refills its lanes from a pool of tiles
-    trace_wave<STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, pd.primary_persistent ? pd.pools + POOL_BYTES / 4 : nullptr, smem, nullptr);
+    if (PERSIST) trace_wave<STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, pd.pools + POOL_BYTES / 4, smem, nullptr);
+    else trace_wave<STACK, PBLOCK, TWO_LEVEL, 64u, false, false, true>(pd.sc, src, sink, nullptr, smem, nullptr);
+}
+
+// the pixel slots k_primary<.., PERSIST = false> gave up, walked from the start by a persistent launch with rows beyond LDS (static deal of
+// the list: there is next to nothing on it -- on the bench scenes nothing: the launch returns before it touches its LDS)
+template <int STACK, bool TWO_LEVEL>
+__global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_primary_retry(PipeDev pd)
+{
+    __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
+    if (pd.retry[0] == 0u) return;
+    PrimaryRetrySrc src = {pd};
+    PrimarySinkT<true> sink = {pd};
+    trace_wave<STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, nullptr, smem, nullptr);
 }
 
 // Compaction of the hits of level L (they get shaded).  Level 0 runs over the pixel slots, level 1 over its two batches,
@@ -121,6 +159,8 @@ __global__ void __launch_bounds__(CBLOCK) k_compact_level(PipeDev pd, int L)
     uint32_t total_items, n = 0;
     if (L == 0) total_items = pd.cap;
     else { n = pd.counters[C_NHIT + L - 1]; total_items = (L == 1 ? 2u : 1u) * n; }
+    if (L == 0 && pd.retry && blockIdx.x == 0 && threadIdx.x == 0) { pd.retry[1] = pd.retry[0]; pd.retry[0] = 0u; }      // (the retry launch in front of this one has used it;
+                                                                                                                           //  [1]: the set's count, for the host's choice of primary launch)
     const uint32_t first = blockIdx.x * (uint32_t)(CTILES * CBLOCK);
     if (first >= total_items) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -668,8 +708,15 @@ int launch_frame(rt_pipeline *p, PipeDev &pd, uint32_t shadow_slots, bool counte
     if (T) record(ev[0], st);
     // primary rays are coherent: one 8x8 tile per wave, scheduled by the hardware dispatcher
     if (pd.primary_persistent) HIP_TRY(hipMemsetAsync(pd.pools + POOL_BYTES / 4, 0, PRIMARY_POOL_WORDS * 4, st));      // (its own first block cannot clear it: the others already draw from it)
-    if (pd.n_frames > 1u) k_primary<STACK, TWO_LEVEL, true><<<pd.primary_persistent ? rt_persistent_grid(ctx, k_primary<STACK, TWO_LEVEL, true>, PBLOCK, cap) : blocks(cap), PBLOCK, 0, st>>>(pd);
-    else k_primary<STACK, TWO_LEVEL, false><<<pd.primary_persistent ? rt_persistent_grid(ctx, k_primary<STACK, TWO_LEVEL, false>, PBLOCK, cap) : blocks(cap), PBLOCK, 0, st>>>(pd);
+    if (pd.primary_persistent) {
+        if (pd.n_frames > 1u) k_primary<STACK, TWO_LEVEL, true, true><<<rt_persistent_grid(ctx, k_primary<STACK, TWO_LEVEL, true, true>, PBLOCK, cap), PBLOCK, 0, st>>>(pd);
+        else k_primary<STACK, TWO_LEVEL, false, true><<<rt_persistent_grid(ctx, k_primary<STACK, TWO_LEVEL, false, true>, PBLOCK, cap), PBLOCK, 0, st>>>(pd);
+    } else {
+        if (pd.n_frames > 1u) k_primary<STACK, TWO_LEVEL, true, false><<<blocks(cap), PBLOCK, 0, st>>>(pd);
+        else k_primary<STACK, TWO_LEVEL, false, false><<<blocks(cap), PBLOCK, 0, st>>>(pd);
+        // the rays that would have needed a stack row beyond LDS (none on the bench scenes: the launch returns at once)
+        if (pd.retry) k_primary_retry<STACK, TWO_LEVEL><<<rt_persistent_grid(ctx, k_primary_retry<STACK, TWO_LEVEL>, PBLOCK, cap), PBLOCK, 0, st>>>(pd);
+    }
     k_compact_level<<<(cap + CTILES * CBLOCK - 1) / (CTILES * CBLOCK), CBLOCK, 0, st>>>(pd, 0);
     if (T) record(ev[1], st);
     RT_TRY(size_next(0, true, levels >= 1));

@@ -120,6 +120,11 @@ struct PipeDev {
     float4 *accum;
     float4 *aov_direct, *aov_indirect;  // realtime pipeline outputs (RealtimeRaytracing.hlsl:3-4)
     uint32_t *counters;
+    // The one-tile-per-wave primary launch has no stack rows beyond LDS (round 5): retry[0] counts the pixel slots whose ray would have
+    // needed one, retry[2 + k], k < retry_cap, lists them (a count above retry_cap: the list is incomplete and k_primary_retry walks every
+    // slot again).  Cleared by the compaction behind the retry launch.  nullptr: the tree fits the LDS rows / the primary stage is persistent.
+    uint32_t *retry;
+    uint32_t retry_cap;
     unsigned long long *totals;         // running sums over frames (rt_pipeline_get_totals); updated by the frame's last kernel
     float point_free;           // LightRays::point_free of pfc's point light
     // ONE shadow queue for the hits of every level (round 4; before: a queue per level, five loaders and five sinks unrolled into
@@ -197,6 +202,7 @@ struct rt_pipeline {
     struct LevelBuf { DevBuf O, D, hit, inst, slot_j, jlist, pix, color; } lv[MAXD + 1];
     DevBuf sh_hits, sh_O, sh_D, sh_vis;      // the shared shadow queue (PipeDev::sh_*)
     DevBuf counters;
+    DevBuf retry;                      // PipeDev::retry (2 + capacity words)
     DevBuf half_out;
     std::vector<hipEvent_t> ring;      // EV_COUNT events per remembered frame
     std::vector<uint8_t> ring_levels;  // radiance levels each remembered frame ran
@@ -221,6 +227,20 @@ struct rt_pipeline {
         float asked_size = 0.0f;           // the largest coordinate of the scene's bounds when the pass was queued
         bool in_flight = false;
     } free_sphere;
+    // How the primary stage runs on a single-level scene (round 5): one tile per wave without stack rows beyond LDS + the retry launch, unless
+    // the retry list says that this scene's primary rays outgrow the LDS rows in numbers (the 10 M-triangle mesh: every retried ray is
+    // walked twice, the second time out of order -- primary stage 1.03 -> 2.2 ms); then as a persistent launch with rows, like a two-level
+    // scene's.  The list's count of a set of launches comes back through a page-locked word behind the set (never waited for); the first
+    // sets of a scene are sampled, the decision holds until the scene changes.  Same image either way.
+    struct PrimaryMode {
+        uint32_t *h_count = nullptr;       // page-locked landing place of PipeDev::retry[0]
+        hipEvent_t landed = nullptr;
+        bool in_flight = false;
+        uint32_t asked_slots = 0;          // pixel slots of the launch whose count is in flight
+        uint32_t gen = 0xffffffffu;        // scene generation the samples belong to
+        int samples = 0;                   // sets sampled so far for this scene
+        bool persistent = false;           // the decision
+    } primary_mode;
     uint64_t ring_pos = 0;             // frames recorded since enable / reset
     DevBuf totals, work;
     PipeDev last_pd;

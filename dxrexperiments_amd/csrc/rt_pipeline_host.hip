@@ -65,6 +65,9 @@ int rt_pipeline_destroy(rt_pipeline *p)
     }
     for (hipEvent_t e : p->ring) if (e) (void)hipEventDestroy(e);
     if (p->free_sphere.landed) (void)hipEventDestroy(p->free_sphere.landed);
+    if (p->primary_mode.landed) (void)hipEventDestroy(p->primary_mode.landed);
+    if (p->primary_mode.h_count) (void)hipHostFree(p->primary_mode.h_count);
+    p->retry.release();
     if (p->free_sphere.h_min) (void)hipHostFree(p->free_sphere.h_min);
     p->free_sphere.d_min.release();
     if (p->scene) rt_scene_destroy(p->scene);

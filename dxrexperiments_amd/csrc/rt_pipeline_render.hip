@@ -190,9 +190,12 @@ int scene_for_set(rt_pipeline *p, uint32_t n_frames, size_t cap, SceneDev *out, 
     rt_context *ctx = p->ctx;
     const bool seven_waves_always = ctx->opt_seven_waves_always;      // (experiment: single frames on the sets' kernels)
     const bool set_rows = (n_frames > 1 || seven_waves_always) && !p->scene->two_level && ctx->lds_stack_rows != RT_LDS_STACK_ROWS_TEST && RT_LDS_STACK_ROWS_SETS != RT_LDS_STACK_ROWS;
-    const size_t resident = (size_t)ctx->cu_count * 16u * PBLOCK;
+    // (round 5: rows for the threads of the PERSISTENT launches only -- at most eight 256-thread workgroups per CU fit their LDS, sixteen
+    // is the option's limit; the one-tile-per-wave primary launch, one thread per pixel slot, keeps none: PipeDev::retry)
+    const size_t resident = (size_t)ctx->cu_count * (ctx->blocks_per_cu_override > 8u ? ctx->blocks_per_cu_override : 8u) * PBLOCK;
+    (void)cap;
     if (sets_kernels) *sets_kernels = set_rows;
-    return rt_scene_dev_for_launch(ctx, p->scene, set_rows ? RT_LDS_STACK_ROWS_SETS : rt_lds_stack_rows(ctx), cap > resident ? cap : resident, out);
+    return rt_scene_dev_for_launch(ctx, p->scene, set_rows ? RT_LDS_STACK_ROWS_SETS : rt_lds_stack_rows(ctx), resident, out);
 }
 
 }  // namespace
@@ -309,7 +312,27 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     // hardware): pays where the rays of a tile part ways early -- two-level scenes, whose primary waves run at 0.48 of their lanes
     // (4096 instances at 4K: 1.39 -> 1.31 ms) -- and costs 13 % where they stay together (the single-level bench scene: 0.69 of the lanes
     // as it is).  The option primary_persistent = 0 / 1 overrides.  profiles/r04/c4_variants.txt, primary_persistent.txt
-    pd.primary_persistent = (ctx->opt_primary_persistent < 0 ? p->scene->two_level : ctx->opt_primary_persistent != 0) ? 1u : 0u;
+    {   // (single-level scenes: one tile per wave, unless this scene's retry lists said otherwise -- rt_pipeline::PrimaryMode)
+        rt_pipeline::PrimaryMode &pm = p->primary_mode;
+        if (pm.gen != p->scene->generation) { pm.gen = p->scene->generation; pm.samples = 0; pm.persistent = false; pm.in_flight = false; }
+        if (pm.in_flight && hipEventQuery(pm.landed) == hipSuccess) {
+            pm.in_flight = false;
+            pm.samples++;
+            if ((double)*pm.h_count > 0.002 * (double)pm.asked_slots) pm.persistent = true;       // more than 0.2 % of the primary rays
+        }
+        pd.primary_persistent = (ctx->opt_primary_persistent < 0 ? (p->scene->two_level || pm.persistent) : ctx->opt_primary_persistent != 0) ? 1u : 0u;
+    }
+    pd.retry = nullptr;
+    pd.retry_cap = 0;
+    if (pd.sc.deep_stack && !pd.primary_persistent) {      // the primary launch keeps no rows beyond LDS: the list of the rays that would need one
+        const uint32_t want = ctx->opt_primary_retry_cap ? ctx->opt_primary_retry_cap : (1u << 20);
+        if (p->retry.bytes < (2 + (size_t)want) * 4) {
+            RT_TRY(p->retry.reserve((2 + (size_t)want) * 4));
+            HIP_TRY(hipMemsetAsync(p->retry.p, 0, 8, st));
+        }
+        pd.retry = p->retry.as<uint32_t>();
+        pd.retry_cap = want;
+    }
     pd.accum = p->accum;
     pd.aov_direct = p->accum;                       // realtime: output 0 = direct lighting, output 1 = indirect specular
     pd.aov_indirect = p->aov_own.as<float4>();
@@ -324,6 +347,18 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     pd.totals = p->totals.as<unsigned long long>();
     RT_TRY(rt_frame_launch(p, pd, shadow_slots, counted, set_rows));
     HIP_TRY(hipGetLastError());
+    if (pd.retry && !p->primary_mode.in_flight && p->primary_mode.samples < 8 && ctx->opt_primary_persistent < 0) {
+        // this set's retry count, for the next sets' choice of primary launch (the set's compaction has cleared retry[0] and left the count in retry[1])
+        rt_pipeline::PrimaryMode &pm = p->primary_mode;
+        if (!pm.h_count) {
+            if (hipHostMalloc((void **)&pm.h_count, 64, hipHostMallocDefault) != hipSuccess) pm.h_count = nullptr;
+            else if (hipEventCreateWithFlags(&pm.landed, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(pm.h_count); pm.h_count = nullptr; pm.landed = nullptr; }
+        }
+        if (pm.h_count && hipMemcpyAsync(pm.h_count, pd.retry + 1, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipEventRecord(pm.landed, st) == hipSuccess) {
+            pm.in_flight = true;
+            pm.asked_slots = cap;
+        }
+    }
     p->last_pd = pd;
     p->last_scene_gen = p->scene->generation;
     p->last_tile[0] = x0; p->last_tile[1] = y0; p->last_tile[2] = x1; p->last_tile[3] = y1;

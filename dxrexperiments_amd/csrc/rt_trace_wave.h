@@ -146,8 +146,11 @@ template <class S> RT_DEV bool load_ray_of(const S &src, uint32_t i, RayD &r, ui
 // iterations of those phases -- with walk[1] + walk[2] (the lanes live in the node steps) and walk[3] (the lanes live in
 // the triangle iterations) the lane utilisation of the two halves of the walk; walk[10] = the node part of walk[5].
 // The per-ray numbers depend on the ray and the tree only, not on chunking or lane assignment; the per-wave ones on both.
+// NO_DEEP (round 5): a launch without rows beyond the LDS ones -- the one-tile-per-wave primary launch, whose one thread per pixel slot made
+// those rows 224 MB per 1080p frame of a set.  A lane whose walk would need such a row gives the ray up: src.overflow(ticket) puts it on a
+// list that a small persistent launch with rows (k_primary_retry, rt_pipeline.hip) walks from the start; nothing is stored for it here.
 #define RT_WALK_WORDS 11
-template <int STACK, int BLOCK, bool TWO_LEVEL, uint32_t CHUNK, bool ANYHIT = false, bool COUNT = false, class Src, class Sink>
+template <int STACK, int BLOCK, bool TWO_LEVEL, uint32_t CHUNK, bool ANYHIT = false, bool COUNT = false, bool NO_DEEP = false, class Src, class Sink>
 RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uint32_t *pool, int *smem, uint32_t *traced_counter,
                        unsigned long long *walk = nullptr)
 {
@@ -167,7 +170,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
     LaneStack<STACK, BLOCK> st;
     st.lds = smem + threadIdx.x;
     st.threads = gridDim.x * BLOCK;
-    st.deep = sc.deep_stack ? sc.deep_stack + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
+    st.deep = sc.deep_stack && !NO_DEEP ? sc.deep_stack + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
 
     // single-level scenes (one identity instance) walk the BLAS directly in world space
     const InstanceRec *in0 = sc.inst;
@@ -355,14 +358,18 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
             if (walking * RT_EXIT_K < n_alive - walking) break;
 #endif
         }
+        // (NO_DEEP: no rows beyond LDS in this launch -- the ray goes to the retry list, at the end of this pass)
+        bool gave_up = NO_DEEP && alive && node_is_internal(node) && sp > STACK - (RT_WIDE - 1);
         // lanes whose stack has outgrown the LDS rows walk on with the global rows until it fits again
-        while (alive && node_is_internal(node) && sp > STACK - (RT_WIDE - 1)) {
-            if (COUNT) {
-                if ((uint32_t)node < top_lim) wk_top++; else wk_glob++;
-                const uint32_t dl = distinct_node_lines(node, !((uint32_t)node < top_lim));
-                if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_read_exec())) { wk_lines += (RT_WIDE == 8 ? 2u : 1u) * dl; wk_node_lines += (RT_WIDE == 8 ? 2u : 1u) * dl; wv_steps++; }       // 64-B lines (96 B of a 128-B record: two)
+        if constexpr (!NO_DEEP) {
+            while (alive && node_is_internal(node) && sp > STACK - (RT_WIDE - 1)) {
+                if (COUNT) {
+                    if ((uint32_t)node < top_lim) wk_top++; else wk_glob++;
+                    const uint32_t dl = distinct_node_lines(node, !((uint32_t)node < top_lim));
+                    if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_read_exec())) { wk_lines += (RT_WIDE == 8 ? 2u : 1u) * dl; wk_node_lines += (RT_WIDE == 8 ? 2u : 1u) * dl; wv_steps++; }       // 64-B lines (96 B of a 128-B record: two)
+                }
+                wide_step<true, ANYHIT>(nodes, top_cur, top_lim, cur.ri, r.tmin, ANYHIT ? r.tmax : best.t, st, node, sp);
             }
-            wide_step<true, ANYHIT>(nodes, top_cur, top_lim, cur.ri, r.tmin, ANYHIT ? r.tmax : best.t, st, node, sp);
         }
 
         // ---- leaves, instance entry / exit, termination -----------------------------------
@@ -391,13 +398,17 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     float e;
                     enter = slab_hit(wri, in->wlo[0], in->whi[0], in->wlo[1], in->whi[1], in->wlo[2], in->whi[2], r.tmin, best.t, e);
                 }
-                if (enter) {
+                if (NO_DEEP && enter && sp >= STACK) {        // (the sentinel would need a row beyond LDS)
+                    gave_up = true;
+                    pop = false;
+                } else if (enter) {
                     cur = to_object(*in, r);
                     nodes = in->wide;
                     tris = in->tris;
                     in_blas = true;
                     top_lim = 0;
-                    st.write(sp, RT_NODE_SENTINEL);
+                    if constexpr (NO_DEEP) st.lds[sp * BLOCK] = RT_NODE_SENTINEL;      // (sp < STACK here)
+                    else st.write(sp, RT_NODE_SENTINEL);
                     sp++;
                     node = in->root_code;
                     pop = false;
@@ -429,9 +440,16 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 }
             }
             if (pop) {
-                if (sp > 0) { sp--; node = st.read(sp); }
+                if (sp > 0) {
+                    sp--;
+                    if constexpr (NO_DEEP) node = st.lds[sp * BLOCK];      // (no entry ever lies beyond the LDS rows)
+                    else node = st.read(sp);
+                }
                 else node = RT_NODE_EMPTY;
             }
+        }
+        if constexpr (NO_DEEP) {
+            if (gave_up) { src.overflow(idx); alive = false; }
         }
 #if RT_LEAF_PRIO
         __builtin_amdgcn_s_setprio(0);

@@ -56,8 +56,11 @@ int rt_context_destroy(rt_context *ctx);
 int rt_context_synchronize(rt_context *ctx);
 int rt_context_get_stream(rt_context *ctx, void **hip_stream_out);
 int rt_context_get_device(rt_context *ctx, int *device_out);
-/* Bytes of the traversal kernels' global stack rows the context holds (the part of a walk's stack beyond the LDS rows: sized by the
- * largest launch so far, shared by every pipeline of the context; the bench scenes never touch them).  No reference counterpart:
+/* Bytes of the traversal kernels' global stack rows the context holds (the part of a walk's stack beyond the LDS rows).  Round 5: rows for
+ * the threads of the PERSISTENT launches only, i.e. for what can be resident at once (57 MB on an MI355X for the bench scene, whatever the
+ * size of a set; rounds 1 - 4: for every thread of the largest launch, and the one-tile-per-wave primary launch has one per pixel slot --
+ * 224 MB per 1080p frame of a set, 4.3 GB for a set of 20); that launch now keeps none and hands the rays that would need one to a small
+ * retry launch.  Shared by every pipeline of the context; the bench scenes never touch them.  No reference counterpart:
  * the Fallback Layer keeps its traversal stack inside DispatchRays (RtContext.cpp:218-221). */
 int rt_context_get_stack_memory(rt_context *ctx, size_t *bytes);
 
@@ -407,6 +410,7 @@ int rt_debug_read_secondary_ray(rt_pipeline *p, uint32_t index, float origin_tmi
  *   seven_waves_always=0|1   single frames on the sets' kernels
  *   free_radius=0|1          the free sphere around the point light (1)
  *   batch_max=0..32          frames per set of launches (0: 32)
+ *   primary_retry_cap=n      entries of the retry list behind the one-tile-per-wave primary launch (0: 2^20; tests make it overflow)
  *   queue_budget_mb=n        worst-case queue bytes a set may reserve up front (0: a quarter of the device's memory)
  *   dist_check_seconds=x     how long rt_dist_create waits for the other ranks' device ids (5) */
 int rt_debug_set_option(rt_context *ctx, const char *name, const char *value);

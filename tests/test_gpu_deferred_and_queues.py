@@ -405,3 +405,42 @@ def test_sponza_1080p_whole_frame_against_the_oracle(gpu, capi, oracle):
     tot = p.totals()
     for k in rays:
         assert tot[k] == rays[k], (k, tot[k], rays[k])
+
+
+@pytest.mark.parametrize("two_level", [False, True])
+def test_primary_launch_without_stack_rows_hands_rays_to_the_retry_launch(gpu, capi, two_level):
+    """Round 5: the one-tile-per-wave primary launch keeps no stack rows beyond LDS (one thread per pixel slot made them 224 MB per 1080p frame
+    of a set); a ray that would need one goes to a list the persistent k_primary_retry walks, and a list that overflows stands for every pixel
+    slot.  The 6-row build of the kernels sends most primary rays of a deep soup that way: the image and the ray counts must be those of the
+    production build bit for bit -- with a list that holds them all, with one of 7 entries (overflow), frame by frame and in a set, single-level
+    and (primary_persistent=0) two-level."""
+    from util import triangle_soup, random_xforms
+    W, H = 200, 120
+    v, i = triangle_soup(60000, seed=77, extent=6.0, size=0.5)
+    inst = [(0, None)] if not two_level else [(0, x) for x in random_xforms(3, seed=5, spread=3.0)]
+    mat = T.default_material()
+    cam = cam_array(dict(eye=(0.0, 1.0, 16.0), at=(0.0, 0.0, 0.0), up=(0, 1, 0), fov=0.8), W / H)
+
+    def render(ctx, frames, deferred):
+        p = make_gpu_pipeline(capi, ctx, [(v, i)], inst, [mat], W, H)
+        host = capi.ProgressiveHost(9)
+        p.set_deferred(deferred)
+        p.reset_totals()
+        for f in range(frames):
+            p.update(host.update(cam, 0.0, f + 1, W, H))
+            p.render()
+        img = p.read_output()
+        return img, p.totals()
+
+    want, wt = render(gpu, 3, 0)
+    for opts in ({"lds_stack_rows": 6}, {"lds_stack_rows": 6, "primary_retry_cap": 7}):
+        ctx = capi.Context(0)
+        for k, val in opts.items():
+            ctx.set_option(k, val)
+        if two_level:
+            ctx.set_option("primary_persistent", 0)          # (two-level scenes run the primary stage as a persistent launch by default)
+        for deferred in (0, 3):
+            got, gt = render(ctx, 3, deferred)
+            assert np.array_equal(got, want), (opts, deferred, int((got != want).any(axis=2).sum()))
+            for k in ("rays_primary", "rays_secondary", "rays_shadow", "primary_hits", "secondary_hits"):
+                assert gt[k] == wt[k], (opts, deferred, k)
