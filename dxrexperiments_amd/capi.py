@@ -145,6 +145,8 @@ SIGNATURES = {
     "rt_pipeline_flush": (_i, [_p]),
     "rt_pipeline_set_queue_budget": (_i, [_p, _sz]),
     "rt_pipeline_get_queue_memory": (_i, [_p, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]),
+    "rt_scene_refs_info": (_i, [_p, _i, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rt_scene_refs_read": (_i, [_p, _i, _p, _p, _p]),
     "rt_debug_set_alloc_limit": (_i, [_sz]),
     "rt_debug_set_option": (_i, [_p, C.c_char_p, C.c_char_p]),
     "rt_debug_read_secondary_ray": (_i, [_p, _u32, _p, _p]),
@@ -398,6 +400,20 @@ class Scene:
         parents = np.empty(nn.value, np.uint32)
         _check(lib().rt_scene_bvh_read(self.h, which, _ptr(nodes), _ptr(keys), _ptr(parents)))
         return nodes, keys, parents, md.value
+
+    def refs(self, which=0):
+        """Split references of instance `which`'s model (rt_refs.h): (ref_off uint32[n_tris + 1], ref_boxes float32[n_refs, 6], record_boxes
+        float32[n_records, 6]); (None, None, None) when no triangle of the model is split."""
+        nt, nr, nn, root, nrec = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_int32(), C.c_uint32()
+        _check(lib().rt_scene_refs_info(self.h, which, C.byref(nt), C.byref(nr)))
+        if nr.value == 0:
+            return None, None, None
+        _check(lib().rt_scene_wide_info(self.h, which, C.byref(nn), C.byref(root), C.byref(nrec)))
+        off = np.empty(nt.value + 1, np.uint32)
+        boxes = np.empty((nr.value, 6), np.float32)
+        rec = np.zeros((nrec.value, 6), np.float32)
+        _check(lib().rt_scene_refs_read(self.h, which, _ptr(off), _ptr(boxes), _ptr(rec)))
+        return off, boxes, rec
 
     def wide_read(self, which=0):
         """The production traversal layout: (nodes uint32[n, 16] (64-B four-wide nodes, raw words; [n, 32] from a library built

@@ -131,6 +131,7 @@ extern "C" int rt_debug_set_option(rt_context *c, const char *name, const char *
     else if (n == "primary_persistent") { if (iv < -1 || iv > 1) return bad(); c->opt_primary_persistent = (int)iv; }
     else if (n == "seven_waves_always") c->opt_seven_waves_always = iv != 0;
     else if (n == "free_radius") c->opt_free_radius = iv != 0;
+    else if (n == "split_refs") c->opt_split_refs = iv != 0;
     else if (n == "primary_retry_cap") { if (iv < 0 || iv > (1 << 24)) return bad(); c->opt_primary_retry_cap = (uint32_t)iv; }
     else if (n == "batch_max") { if (iv < 0 || iv > 32) return bad(); c->opt_batch_max = (uint32_t)iv; }
     else if (n == "queue_budget_mb") { if (iv < 0) return bad(); c->opt_queue_budget_mb = (size_t)iv; }
@@ -394,7 +395,7 @@ int rt_model_destroy(rt_model *m)
     if (!m) return RT_OK;
     if (--m->refs > 0) return RT_OK;
     (void)hipSetDevice(m->ctx->device);
-    m->d_verts.release(); m->d_idx.release(); m->tris.release(); m->normals.release(); m->blas.release();
+    m->d_verts.release(); m->d_idx.release(); m->tris.release(); m->normals.release(); m->blas.release(); m->rec_boxes.release(); m->ref_off.release(); m->ref_boxes.release();
     rt_context *ctx = m->ctx;
     delete m;
     rt_context_release(ctx);
@@ -515,7 +516,7 @@ int rt_scene_wide_info(const rt_scene *s, int which, uint32_t *n_nodes, int32_t 
     if (!b) { rt_set_error("rt_scene_wide_info: scene not built or index out of range"); return RT_ERR_STATE; }
     if (n_nodes) *n_nodes = b->wide_n;
     if (root_code) *root_code = b->root_code;
-    if (n_records) *n_records = which < 0 ? 0u : b->n;
+    if (n_records) *n_records = which < 0 ? 0u : s->inst[which].model->n_recs;
     return RT_OK;
 }
 
@@ -532,7 +533,33 @@ int rt_scene_wide_read(const rt_scene *s, int which, void *nodes, void *records)
     if (!b) { rt_set_error("rt_scene_wide_read: scene not built or index out of range"); return RT_ERR_STATE; }
     RT_TRY(use_device(s->ctx));
     if (nodes && b->wide_n) HIP_TRY(hipMemcpy(nodes, b->wide.p, sizeof(WNode) * (size_t)b->wide_n, hipMemcpyDeviceToHost));
-    if (records && which >= 0) HIP_TRY(hipMemcpy(records, s->inst[which].model->tris.p, sizeof(TriRec) * (size_t)b->n, hipMemcpyDeviceToHost));
+    if (records && which >= 0) HIP_TRY(hipMemcpy(records, s->inst[which].model->tris.p, sizeof(TriRec) * (size_t)s->inst[which].model->n_recs, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+/* the validation boxes of an instance's model (rt_refs.h): *n_refs = 0 when none of its triangles is split */
+int rt_scene_refs_info(const rt_scene *s, int which, uint32_t *n_tris, uint32_t *n_refs)
+{
+    const BvhDev *b = pick_bvh(s, which);
+    if (!b || which < 0) { rt_set_error("rt_scene_refs_info: scene not built or index out of range"); return RT_ERR_STATE; }
+    const rt_model *m = s->inst[which].model;
+    if (n_tris) *n_tris = m->n_tris;
+    if (n_refs) *n_refs = m->ref_off.p ? (uint32_t)(m->ref_boxes.bytes / 24) : 0u;
+    return RT_OK;
+}
+
+int rt_scene_refs_read(const rt_scene *s, int which, uint32_t *ref_off, float *ref_boxes, float *record_boxes)
+{
+    const BvhDev *b = pick_bvh(s, which);
+    if (!b || which < 0) { rt_set_error("rt_scene_refs_read: scene not built or index out of range"); return RT_ERR_STATE; }
+    const rt_model *m = s->inst[which].model;
+    if (!m->ref_off.p) { rt_set_error("rt_scene_refs_read: no triangle of this model is split"); return RT_ERR_STATE; }
+    RT_TRY(use_device(s->ctx));
+    uint32_t total = 0;
+    HIP_TRY(hipMemcpy(&total, m->ref_off.as<uint32_t>() + m->n_tris, 4, hipMemcpyDeviceToHost));
+    if (ref_off) HIP_TRY(hipMemcpy(ref_off, m->ref_off.p, 4 * ((size_t)m->n_tris + 1), hipMemcpyDeviceToHost));
+    if (ref_boxes) HIP_TRY(hipMemcpy(ref_boxes, m->ref_boxes.p, 24 * (size_t)total, hipMemcpyDeviceToHost));
+    if (record_boxes && m->rec_boxes.p) HIP_TRY(hipMemcpy(record_boxes, m->rec_boxes.p, 24 * (size_t)m->n_recs, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -22,6 +22,8 @@
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
+#include "rt_refs.h"
+
 namespace {
 
 struct Box6 { float lo[3]; float hi[3]; };
@@ -315,6 +317,88 @@ __global__ void k_normal_records(const rt_vertex *__restrict__ verts, const uint
 
 inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
+// ---- split references (rt_refs.h): count the pieces of every triangle, then (after a scan) write their boxes ----
+__device__ __forceinline__ void ref_load_tri(const rt_vertex *__restrict__ verts, const uint32_t *__restrict__ idx, uint32_t i, float p[3][3])
+{
+    for (int k = 0; k < 3; k++) {
+        const rt_float3 v = verts[idx[3 * i + k]].position;
+        p[k][0] = v.x; p[k][1] = v.y; p[k][2] = v.z;
+    }
+}
+__device__ __forceinline__ float ref_min_len(const float *__restrict__ bounds)
+{
+    const float ex = bounds[3] - bounds[0], ey = bounds[4] - bounds[1], ez = bounds[5] - bounds[2];
+    return rtd::ref_max2(rtd::ref_max2(ex, ey), ez) * 0.00390625f;          // the model's longest extent / 256
+}
+__global__ void k_ref_count(const rt_vertex *__restrict__ verts, const uint32_t *__restrict__ idx, uint32_t n, const float *__restrict__ bounds,
+                            uint32_t *__restrict__ count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { count[n] = 0u; return; }           // (the scan's last element: the total)
+    float p[3][3];
+    ref_load_tri(verts, idx, i, p);
+    int axis;
+    count[i] = rtd::ref_pieces(p, ref_min_len(bounds), axis);
+}
+__global__ void k_ref_emit(const rt_vertex *__restrict__ verts, const uint32_t *__restrict__ idx, uint32_t n, const float *__restrict__ bounds,
+                           const uint32_t *__restrict__ off, float *__restrict__ ref_boxes, uint32_t *__restrict__ ref_prim)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float p[3][3];
+    ref_load_tri(verts, idx, i, p);
+    const uint32_t first = off[i], k = off[i + 1] - first;
+    if (k == 1u) {                                     // not split: its own box (what k_tri_boxes wrote: exact min / max)
+        float *b = ref_boxes + 6 * (size_t)first;
+        for (int q = 0; q < 3; q++) {
+            b[q] = fminf(fminf(p[0][q], p[1][q]), p[2][q]);
+            b[3 + q] = fmaxf(fmaxf(p[0][q], p[1][q]), p[2][q]);
+        }
+        ref_prim[first] = i;
+        return;
+    }
+    int axis;
+    (void)rtd::ref_pieces(p, ref_min_len(bounds), axis);
+    for (uint32_t j = 0; j < k; j++) {
+        float b[6];
+        rtd::ref_box(p, axis, k, j, b);
+        for (int q = 0; q < 6; q++) ref_boxes[6 * (size_t)(first + j) + q] = b[q];
+        ref_prim[first + j] = i;
+    }
+}
+// Morton keys of the references (the LBVH's codes, over the same bounds) and, after the sort, the leaves PLOC starts from
+__global__ void k_ref_keys(const float *__restrict__ ref_boxes, uint32_t m, const float *__restrict__ bounds, uint64_t *__restrict__ keys)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const float *b = ref_boxes + 6 * (size_t)i;
+    uint32_t code = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float ctr = (b[c] + b[3 + c]) * 0.5f;
+        code |= expand10(quant10(ctr, bounds[c], bounds[3 + c] - bounds[c])) << (2 - c);
+    }
+    keys[i] = ((uint64_t)code << 32) | i;
+}
+__global__ void k_ref_leaves(const uint64_t *__restrict__ keys, uint32_t m, const float *__restrict__ ref_boxes, const uint32_t *__restrict__ ref_prim,
+                             float *__restrict__ leaf_box, uint32_t *__restrict__ leaf_prim)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const uint32_t r = (uint32_t)(keys[k] & 0xFFFFFFFFull);
+    for (int q = 0; q < 6; q++) leaf_box[6 * (size_t)k + q] = ref_boxes[6 * (size_t)r + q];
+    leaf_prim[k] = ref_prim[r];
+}
+// a model with split triangles in a layout that holds every triangle once (LBVH layout): its records say "validate by primitive"
+__global__ void k_ref_mark_records(TriRec *__restrict__ tris, uint32_t n, const uint32_t *__restrict__ off)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t prim = __float_as_uint(tris[k].c.y);
+    if (off[prim + 1] - off[prim] > 1u) tris[k].c.z = __uint_as_float(2u);
+}
+
 // Temporaries of a build over n primitives as slices of the context's build arena (sized for the larger of
 // the LBVH and the PLOC phase, which run one after the other).  A slice that turns out too small makes
 // its DevBuf allocate on its own (DevBuf::reserve), so the sizes here are a fast path, not a contract.
@@ -420,7 +504,9 @@ int rt_build_blas(rt_context *ctx, rt_model *m)
         t_prev = now;
     };
     do {
-        if ((rc = take_build_temps(ctx, n, bt)) != RT_OK) break;
+        // (+ the reference count of every triangle, its scan and the scan's scratch: slices of the arena, no allocation of their own)
+        const size_t ref_words = ((size_t)n + 1 + 63) & ~(size_t)63;
+        if ((rc = take_build_temps(ctx, n, bt, 8 * ref_words + ((size_t)1 << 20))) != RT_OK) break;
         mark("arena");
         if ((rc = boxes.reserve(sizeof(Box6) * (size_t)n)) != RT_OK) break;
         if ((rc = enc.reserve(6 * sizeof(uint32_t))) != RT_OK) break;
@@ -443,12 +529,63 @@ int rt_build_blas(rt_context *ctx, rt_model *m)
             rc = RT_ERR_HIP;
             break;
         }
+        // Split references (rt_refs.h): how many boxes every triangle is validated against.  One each -- every scene of rounds 1 - 4 --
+        // leaves the model as it was; otherwise the boxes by primitive (the canonical walk validates against them) and, below, the
+        // references as the leaves the production tree is built from.
+        m->n_recs = n;
+        m->rec_boxes.release(); m->ref_off.release(); m->ref_boxes.release();
+        DevBuf r_scan, r_prim, r_keys, r_sorted, r_sort_tmp, r_leaf_box, r_leaf_prim;
+        uint32_t n_refs = n;
+        uint32_t *d_count = bt.extra.as<uint32_t>(), *d_off = d_count + ref_words;
+        {
+            void *scan_tmp = (void *)(d_off + ref_words);
+            const size_t scan_room = (size_t)1 << 20;
+            k_ref_count<<<grid_for(n + 1, B), B, 0, st>>>(m->d_verts.as<rt_vertex>(), m->d_idx.as<uint32_t>(), n, bounds.as<float>(), d_count);
+            size_t scan_bytes = 0;
+            if (rocprim::exclusive_scan(nullptr, scan_bytes, d_count, d_off, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st) != hipSuccess) { rt_set_error("reference scan failed"); rc = RT_ERR_HIP; break; }
+            if (scan_bytes > scan_room) { if ((rc = r_scan.reserve(scan_bytes)) != RT_OK) break; scan_tmp = r_scan.p; }
+            if (rocprim::exclusive_scan(scan_tmp, scan_bytes, d_count, d_off, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st) != hipSuccess) { rt_set_error("reference scan failed"); rc = RT_ERR_HIP; break; }
+            uint32_t *back = ctx->pinned ? ctx->pinned : &n_refs;
+            if (hipMemcpyAsync(back, d_off + n, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                rt_set_error("reference count read-back failed");
+                rc = RT_ERR_HIP;
+                break;
+            }
+            n_refs = *back;
+            r_scan.release();
+        }
+        if (n_refs != n) {
+            if (n_refs < n || n_refs > (1u << (32 - RT_NODE_SHIFT))) { rt_set_error("split references: %u for %u triangles", n_refs, n); rc = RT_ERR_UNSUPPORTED; break; }
+            if ((rc = m->ref_off.reserve(4 * ((size_t)n + 1))) != RT_OK) break;
+            if (hipMemcpyAsync(m->ref_off.p, d_off, 4 * ((size_t)n + 1), hipMemcpyDeviceToDevice, st) != hipSuccess) { rt_set_error("reference offsets copy failed"); rc = RT_ERR_HIP; break; }
+            if ((rc = m->ref_boxes.reserve(24 * (size_t)n_refs)) != RT_OK || (rc = r_prim.reserve(4 * (size_t)n_refs)) != RT_OK) break;
+            k_ref_emit<<<grid_for(n, B), B, 0, st>>>(m->d_verts.as<rt_vertex>(), m->d_idx.as<uint32_t>(), n, bounds.as<float>(), m->ref_off.as<uint32_t>(),
+                                                    m->ref_boxes.as<float>(), r_prim.as<uint32_t>());
+            if (ctx->verbose) fprintf(stderr, "[dxr_amd]   BLAS %u triangles -> %u references\n", n, n_refs);
+        }
+        const bool split_layout = n_refs > n && ctx->opt_split_refs && ctx->use_ploc;
+        if (split_layout) {
+            // the references in Morton order: the leaves of the production tree
+            if ((rc = r_keys.reserve(8 * (size_t)n_refs)) != RT_OK || (rc = r_sorted.reserve(8 * (size_t)n_refs)) != RT_OK ||
+                (rc = r_leaf_box.reserve(24 * (size_t)n_refs)) != RT_OK || (rc = r_leaf_prim.reserve(4 * (size_t)n_refs)) != RT_OK) break;
+            k_ref_keys<<<grid_for(n_refs, B), B, 0, st>>>(m->ref_boxes.as<float>(), n_refs, bounds.as<float>(), r_keys.as<uint64_t>());
+            size_t sort_bytes = 0;
+            if (rocprim::radix_sort_keys(nullptr, sort_bytes, r_keys.as<uint64_t>(), r_sorted.as<uint64_t>(), n_refs, 32, 62, st) != hipSuccess ||
+                (rc = r_sort_tmp.reserve(sort_bytes)) != RT_OK ||
+                rocprim::radix_sort_keys(r_sort_tmp.p, sort_bytes, r_keys.as<uint64_t>(), r_sorted.as<uint64_t>(), n_refs, 32, 62, st) != hipSuccess) {
+                if (rc == RT_OK) { rt_set_error("reference sort failed"); rc = RT_ERR_HIP; }
+                break;
+            }
+            k_ref_leaves<<<grid_for(n_refs, B), B, 0, st>>>(r_sorted.as<uint64_t>(), n_refs, m->ref_boxes.as<float>(), r_prim.as<uint32_t>(),
+                                                           r_leaf_box.as<float>(), r_leaf_prim.as<uint32_t>());
+        }
         // production traversal layout: re-cluster the same leaves with PLOC (rt_bvh_ploc.hip), then collapse the binary
         // tree into wide quantised nodes (rt_bvh_wide.hip); tiny meshes and option fast_bvh=lbvh collapse the LBVH itself
         mark("gather");
         bool ploc_done = false;
         if (ctx->use_ploc) {
-            rc = rt_build_ploc_layout(ctx, m, &ploc_done);
+            rc = split_layout ? rt_build_ploc_layout(ctx, m, &ploc_done, n_refs, r_leaf_box.as<float>(), r_leaf_prim.as<uint32_t>())
+                              : rt_build_ploc_layout(ctx, m, &ploc_done);
             // PLOC's nearest-neighbour rounds make no progress on boxes whose surface is not finite (NaN / inf vertices,
             // extents that overflow): such a mesh keeps the LBVH as its traversal layout (m->tris is still in LBVH order)
             if (rc == RT_ERR_STATE) { rc = RT_OK; ploc_done = false; }
@@ -456,6 +593,12 @@ int rt_build_blas(rt_context *ctx, rt_model *m)
         }
         mark("PLOC + wide layout");
         if (!ploc_done && (rc = rt_build_wide_from_lbvh(ctx, m->blas, false, ctx->leaf_max)) != RT_OK) break;
+        if (n_refs > n && !(ploc_done && split_layout)) {
+            // a layout with one record per triangle (LBVH; PLOC with the option split_refs=0): split triangles are validated by primitive
+            m->n_recs = n;
+            k_ref_mark_records<<<grid_for(n, B), B, 0, st>>>(m->tris.as<TriRec>(), n, m->ref_off.as<uint32_t>());
+        }
+        r_prim.release(); r_keys.release(); r_sorted.release(); r_sort_tmp.release(); r_leaf_box.release(); r_leaf_prim.release();
         mark("wide layout (LBVH)");
         if ((rc = lbvh_collect(ctx, m->blas)) != RT_OK) break;
         m->built = true;
@@ -571,7 +714,14 @@ int rt_build_tlas(rt_context *ctx, rt_scene *s)
         r.indices = m->d_idx.as<uint32_t>();
         r.normals = m->normals.as<TriRec>();
         r.n_prims = m->n_tris;
+        r.n_recs = m->n_recs;
+        r.pad_ = 0;
         r.material = i;
+        r.rec_boxes = m->rec_boxes.p ? m->rec_boxes.as<float>() : nullptr;
+        r.ref_off = m->ref_off.p ? m->ref_off.as<uint32_t>() : nullptr;
+        r.ref_boxes = m->ref_boxes.p ? m->ref_boxes.as<float>() : nullptr;
+        if (i == 0) s->has_refs = false;
+        s->has_refs = s->has_refs || m->ref_off.p != nullptr;
         deepest = m->blas.fast_depth > deepest ? m->blas.fast_depth : deepest;
         if (!identity)
             for (uint32_t c = 0; c * INST_BOX_REFS < 3u * m->n_tris; c++) items.push_back(make_uint2(i, c));

@@ -70,15 +70,20 @@ struct PlocArrays {
 };
 
 // clusters start as the canonical leaves, in key order
-__global__ void k_ploc_init(const rt_bvh_node *__restrict__ nodes, uint32_t n, uint32_t *__restrict__ cl_node, Box6 *__restrict__ cl_box,
+// (leaf_box6 != nullptr: the leaves are the references of a model with split triangles, rt_refs.h -- 6 floats each, in Morton order)
+__global__ void k_ploc_init(const rt_bvh_node *__restrict__ nodes, const float *__restrict__ leaf_box6, uint32_t n, uint32_t *__restrict__ cl_node, Box6 *__restrict__ cl_box,
                             uint32_t *__restrict__ size, uint32_t *__restrict__ parent, PlocRound *__restrict__ round0, uint32_t *__restrict__ arrivals)
 {
     const uint32_t k = blockIdx.x * PB + threadIdx.x;
     if (k == 0) { const PlocRound r0 = {n, n, 0u, 0u}; *round0 = r0; *arrivals = 0; }
     if (k >= n) return;
-    const rt_bvh_node nd = nodes[n - 1 + k];
     Box6 b;
-    for (int c = 0; c < 3; c++) { b.lo[c] = nd.bmin[c]; b.hi[c] = nd.bmax[c]; }
+    if (leaf_box6) {
+        for (int c = 0; c < 3; c++) { b.lo[c] = leaf_box6[6 * (size_t)k + c]; b.hi[c] = leaf_box6[6 * (size_t)k + 3 + c]; }
+    } else {
+        const rt_bvh_node nd = nodes[n - 1 + k];
+        for (int c = 0; c < 3; c++) { b.lo[c] = nd.bmin[c]; b.hi[c] = nd.bmax[c]; }
+    }
     cl_node[k] = k;                 // node ids: leaves 0..n-1 (key order), internal n..2n-2 (creation order)
     cl_box[k] = b;
     size[k] = 1;
@@ -318,20 +323,26 @@ __global__ void k_ploc_offsets(const uint32_t *__restrict__ left, const uint32_t
     offset[id] = off;
 }
 
-__global__ void k_ploc_tris(const uint64_t *__restrict__ keys, const rt_vertex *__restrict__ verts, const uint32_t *__restrict__ idx,
-                            const uint32_t *__restrict__ offset, uint32_t n, TriRec *__restrict__ tris)
+// (leaf_prim != nullptr: leaf k is a reference of primitive leaf_prim[k] with the box leaf_box6[k]; the record of a split triangle's reference
+// says so and its box goes to rec_boxes beside it)
+__global__ void k_ploc_tris(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ leaf_prim, const float *__restrict__ leaf_box6,
+                            const uint32_t *__restrict__ ref_off, const rt_vertex *__restrict__ verts, const uint32_t *__restrict__ idx,
+                            const uint32_t *__restrict__ offset, uint32_t n, TriRec *__restrict__ tris, float *__restrict__ rec_boxes)
 {
     const uint32_t k = blockIdx.x * PB + threadIdx.x;
     if (k >= n) return;
-    const uint32_t prim = (uint32_t)(keys[k] & 0xFFFFFFFFull);
+    const uint32_t prim = leaf_prim ? leaf_prim[k] : (uint32_t)(keys[k] & 0xFFFFFFFFull);
     const rt_float3 p0 = verts[idx[3 * prim + 0]].position;
     const rt_float3 p1 = verts[idx[3 * prim + 1]].position;
     const rt_float3 p2 = verts[idx[3 * prim + 2]].position;
     TriRec t;
     t.a = make_float4(p0.x, p0.y, p0.z, p1.x);
     t.b = make_float4(p1.y, p1.z, p2.x, p2.y);
-    t.c = make_float4(p2.z, __uint_as_float(prim), 0.0f, 0.0f);
+    const bool split = leaf_prim && ref_off[prim + 1] - ref_off[prim] > 1u;
+    t.c = make_float4(p2.z, __uint_as_float(prim), __uint_as_float(split ? 1u : 0u), 0.0f);
     tris[offset[k]] = t;
+    if (rec_boxes)
+        for (int q = 0; q < 6; q++) rec_boxes[6 * (size_t)offset[k] + q] = leaf_box6[6 * (size_t)k + q];
 }
 
 inline unsigned gr(size_t n) { return (unsigned)((n + PB - 1) / PB); }
@@ -349,9 +360,9 @@ size_t rt_ploc_temp_bytes(uint32_t n)
 
 // Rebuilds m->tris and m->blas.wide / root_code / fast_depth from a PLOC tree.  The canonical arrays
 // (nodes, keys, parents) are left untouched.  Returns RT_OK with *done = false for meshes too small to bother.
-int rt_build_ploc_layout(rt_context *ctx, rt_model *m, bool *done)
+int rt_build_ploc_layout(rt_context *ctx, rt_model *m, bool *done, uint32_t n_leaves, const float *leaf_box6, const uint32_t *leaf_prim)
 {
-    const uint32_t n = m->n_tris;
+    const uint32_t n = leaf_box6 ? n_leaves : m->n_tris;          // leaves of the tree: triangles, or the references of a model with split ones
     *done = false;
     if (n < 2 * ctx->leaf_max + 2) return RT_OK;          // tiny meshes: the LBVH layout is as good as any
     hipStream_t st = ctx->stream;
@@ -389,7 +400,10 @@ int rt_build_ploc_layout(rt_context *ctx, rt_model *m, bool *done)
             break;
         }
 
-        k_ploc_init<<<gr(n), PB, 0, st>>>(m->blas.nodes.as<rt_bvh_node>(), n, cl_node[0].as<uint32_t>(), cl_box[0].as<Box6>(),
+        if (leaf_box6) {          // records and their boxes for every reference
+            if ((rc = m->tris.reserve(sizeof(TriRec) * (size_t)n)) != RT_OK || (rc = m->rec_boxes.reserve(24 * (size_t)n)) != RT_OK) break;
+        }
+        k_ploc_init<<<gr(n), PB, 0, st>>>(m->blas.nodes.as<rt_bvh_node>(), leaf_box6, n, cl_node[0].as<uint32_t>(), cl_box[0].as<Box6>(),
                                          size.as<uint32_t>(), parent.as<uint32_t>(), pa.round, pa.arrivals);
         k_ploc_leaf_boxes<<<gr(n), PB, 0, st>>>(cl_box[0].as<Box6>(), n, node_box.as<Box6>());
         // Rounds are launched in batches without looking at the cluster count: every launch covers the count the batch
@@ -434,14 +448,16 @@ int rt_build_ploc_layout(rt_context *ctx, rt_model *m, bool *done)
         }
         k_ploc_offsets<<<gr(nn2), PB, 0, st>>>(left.as<uint32_t>(), right.as<uint32_t>(), size.as<uint32_t>(), parent.as<uint32_t>(), n,
                                               offset.as<uint32_t>());
-        k_ploc_tris<<<gr(n), PB, 0, st>>>(m->blas.keys.as<uint64_t>(), m->d_verts.as<rt_vertex>(), m->d_idx.as<uint32_t>(),
-                                         offset.as<uint32_t>(), n, m->tris.as<TriRec>());
+        k_ploc_tris<<<gr(n), PB, 0, st>>>(m->blas.keys.as<uint64_t>(), leaf_prim, leaf_box6, leaf_box6 ? m->ref_off.as<uint32_t>() : nullptr,
+                                         m->d_verts.as<rt_vertex>(), m->d_idx.as<uint32_t>(), offset.as<uint32_t>(), n, m->tris.as<TriRec>(),
+                                         leaf_box6 ? m->rec_boxes.as<float>() : nullptr);
         if (hipGetLastError() != hipSuccess) { rt_set_error("PLOC layout kernels failed"); rc = RT_ERR_HIP; break; }
         // four-wide nodes from the binary tree (root = the last node created); the cluster arrays of the rounds are free now
         // and serve as its scratch
         if ((rc = rt_build_wide_layout(ctx, m->blas, n, 2 * n - 2, left.as<uint32_t>(), right.as<uint32_t>(), parent.as<uint32_t>(), (const float *)node_box.p,
                                        size.as<uint32_t>(), offset.as<uint32_t>(), nullptr, ctx->leaf_max, cl_node[0].p,
                                        (size_t)((char *)left.p - (char *)cl_node[0].p))) != RT_OK) break;
+        if (leaf_box6) m->n_recs = n;
         *done = true;
     } while (0);
     return rc;

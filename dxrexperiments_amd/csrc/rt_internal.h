@@ -127,7 +127,10 @@ struct WNode { float4 q0, q1, q2, q3; };
 // One triangle in leaf order: the three ORIGINAL vertex positions (so that the
 // Moller-Trumbore edges and the triangle's own AABB are recomputed from the same
 // floats the canonical BVH was built from) plus the primitive id.  48 B.
-struct TriRec { float4 a, b, c; };   // a = v0.xyz v1.x ; b = v1.yz v2.xy ; c = v2.z prim 0 0
+struct TriRec { float4 a, b, c; };   // a = v0.xyz v1.x ; b = v1.yz v2.xy ; c = v2.z prim ref 0
+                                     // ref (bits of c.z, round 5, rt_refs.h): 0 = the triangle is validated against its own AABB (every triangle of rounds 1 - 4);
+                                     //   1 = this record is ONE reference of a split triangle, its box is InstanceRec::rec_boxes[record index];
+                                     //   2 = a split triangle in a layout that holds it once (LBVH layout): validated against all its boxes, by primitive
                                      // (padding a record to one 64-B line so that none straddles two: measured, no change)
 
 #define RT_INST_IDENTITY 1u
@@ -143,8 +146,14 @@ struct InstanceRec {
     const uint32_t *indices;
     const TriRec *normals;      // the three vertex normals of primitive p in ONE 48-B record (n0.xyz n1.x | n1.yz n2.xy | n2.z):
                                 //   a shaded hit fetches one record instead of three indices and three scattered vertices
-    uint32_t n_prims;
+    uint32_t n_prims;           // triangles of the model
     uint32_t material;
+    // split references (rt_refs.h): nullptr when no triangle of the model is split
+    const float *rec_boxes;     // 6 floats per record of `tris` (meaningful where the record says ref = 1)
+    const uint32_t *ref_off;    // per primitive: its boxes are ref_boxes[6 * ref_off[p] .. 6 * ref_off[p + 1])
+    const float *ref_boxes;
+    uint32_t n_recs;            // records of `tris`: n_prims, or more when some triangles are held as several references
+    uint32_t pad_;
 };
 
 struct SceneDev {
@@ -208,6 +217,8 @@ struct rt_context {
     bool opt_seven_waves_always = false;    // seven_waves_always=1: single frames on the sets' kernels
     bool opt_free_radius = true;            // free_radius=0: no free sphere around the point light
     uint32_t opt_batch_max = 0;             // batch_max: frames per set of launches (0: RT_MAX_BATCH)
+    bool opt_split_refs = true;             // split_refs=0: no triangle is held as several references (the builder of rounds 1 - 4; the CANDIDATE RULE still
+                                            //   follows rt_refs.h -- results do not depend on this option)
     uint32_t opt_primary_retry_cap = 0;     // primary_retry_cap: entries of the primary launch's retry list (0: 2^20; tests: a few, so that the list overflows)
     size_t opt_queue_budget_mb = 0;         // queue_budget_mb: worst-case queue bytes a set may reserve up front (0: a quarter of the device)
     double opt_dist_check_seconds = 5.0;    // dist_check_seconds: how long rt_dist_create waits for the other ranks' device ids
@@ -237,8 +248,11 @@ struct rt_model {
     std::vector<rt_vertex> h_verts;
     std::vector<uint32_t> h_idx;
     DevBuf d_verts, d_idx;
-    DevBuf tris;                 // TriRec[n_tris] in sorted order
+    DevBuf tris;                 // TriRec[n_recs] in sorted order
     DevBuf normals;              // TriRec[n_tris] in primitive order: the vertex normals (InstanceRec::normals)
+    uint32_t n_recs = 0;         // records of `tris`: n_tris, or more when long thin triangles are held as several references (rt_refs.h)
+    DevBuf rec_boxes;            // float[6 n_recs]: the reference box of every record (split models only)
+    DevBuf ref_off, ref_boxes;   // uint32[n_tris + 1], float[6 refs]: the same boxes by primitive (canonical walk, LBVH layout)
     BvhDev blas;
     bool built = false;
 };
@@ -260,6 +274,7 @@ struct rt_scene {
     float build_ms = 0.0f;
     uint32_t stack_need = 0;     // traversal stack entries a ray can hold at once
     bool two_level = true;       // false: one identity instance, rays walk its BLAS directly
+    bool has_refs = false;       // some model of the scene holds triangles as several references (rt_refs.h)
     SceneDev dev() const
     {
         SceneDev s;
@@ -281,7 +296,9 @@ int rt_build_blas(rt_context *ctx, rt_model *m);
 int rt_build_tlas(rt_context *ctx, rt_scene *s);
 
 // rt_bvh_ploc.hip
-int rt_build_ploc_layout(rt_context *ctx, rt_model *m, bool *done);
+// n_leaves / leaf_box6 / leaf_prim: the leaves to cluster in Morton order -- nullptr: the canonical leaves (one per triangle); else the
+// references of a model with split triangles (rt_refs.h): 6 floats and a primitive id per leaf
+int rt_build_ploc_layout(rt_context *ctx, rt_model *m, bool *done, uint32_t n_leaves = 0, const float *leaf_box6 = nullptr, const uint32_t *leaf_prim = nullptr);
 
 // rt_bvh_wide.hip: collapses a binary tree into the four-wide traversal layout (bv.wide, wide_n, fast_depth, root_code).
 // The binary tree is given in "cluster" numbering: leaves 0..n-1 in sorted-key order, internal nodes n..2n-2;
@@ -321,6 +338,11 @@ static inline unsigned rt_persistent_grid(const rt_context *ctx, K kernel, int b
 #define RT_LDS_STACK_ROWS 18            // LDS stack rows of the traversal kernels; with the 8-row top table (top of the BLAS for
 #endif                                  // single-level walks, top of the TLAS for two-level ones) 26 KiB per 256-thread block = 6 blocks per CU.
                                         // Bench-scene rays: 98.1 % never hold more than 8 entries, 99.97 % not more than 12, none more than 17.
+// The traversal kernels' STACK template argument is the number of LDS stack rows, + RT_STACK_REFS for the instantiations that walk scenes
+// with split references (rt_refs.h; trace_wave's REFS): one argument, so that every launch site picks both at once
+#define RT_STACK_REFS 100
+#define RT_ROWS(S) ((S) % RT_STACK_REFS)
+#define RT_REFS(S) ((S) >= RT_STACK_REFS)
 #define RT_LDS_STACK_ROWS_TEST 6        // second instantiation (option lds_stack_rows=6): tests force rays onto the global rows
 // Sets of frames (rt_pipeline_render_batch) run long launches whose ramp and drain no longer matter, and there a seventh wave
 // per SIMD pays (-3.5 % on the bench scene; frame by frame it costs 2 %, the drain grows with the resident waves:

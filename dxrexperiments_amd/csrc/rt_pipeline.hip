@@ -115,7 +115,7 @@ struct PrimarySinkT {
 // the two-level ones for five -- they take 88 - 96 registers by themselves, except the primary stage of a set (99: a fourth wave lost
 // for three registers; capped it fits 96 without scratch))
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU __attribute__((amdgpu_waves_per_eu(TWO_LEVEL ? 5 : STACK == RT_LDS_STACK_ROWS_SETS ? 7 : STACK == RT_LDS_STACK_ROWS ? 6 : 1)))
+#define RT_WAVES_PER_EU __attribute__((amdgpu_waves_per_eu(TWO_LEVEL ? 5 : RT_ROWS(STACK) == RT_LDS_STACK_ROWS_SETS ? 7 : RT_ROWS(STACK) == RT_LDS_STACK_ROWS ? 6 : 1)))
 #endif
 // PERSIST = false: one 8x8 tile per wave, dealt by the hardware dispatcher -- one thread per pixel slot, so this launch keeps NO stack rows
 // beyond LDS (NO_DEEP: a ray that would need one goes to PipeDev::retry and k_primary_retry walks it); true: a persistent launch that refills
@@ -123,15 +123,15 @@ struct PrimarySinkT {
 template <int STACK, bool TWO_LEVEL, bool BATCH, bool PERSIST>
 __global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_primary(PipeDev pd)
 {
-    __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
+    __shared__ int smem[(RT_ROWS(STACK) + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     // the frame's counters and chunk pools start at zero: its first kernel clears them (nothing here uses them, every later
     // kernel of the frame does) instead of a 20-KB fill launch of its own
     if (blockIdx.x == 0)
         for (uint32_t i = threadIdx.x; i < (uint32_t)(POOL_OFFSET_WORDS + POOL_BYTES / 4); i += PBLOCK) pd.counters[i] = 0u;
     PrimarySrcT<BATCH> src = {pd};
     PrimarySinkT<BATCH> sink = {pd};
-    if (PERSIST) trace_wave<STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, pd.pools + POOL_BYTES / 4, smem, nullptr);
-    else trace_wave<STACK, PBLOCK, TWO_LEVEL, 64u, false, false, true>(pd.sc, src, sink, nullptr, smem, nullptr);
+    if (PERSIST) trace_wave<RT_ROWS(STACK), PBLOCK, TWO_LEVEL, 64u, false, false, false, RT_REFS(STACK)>(pd.sc, src, sink, pd.pools + POOL_BYTES / 4, smem, nullptr);
+    else trace_wave<RT_ROWS(STACK), PBLOCK, TWO_LEVEL, 64u, false, false, true, RT_REFS(STACK)>(pd.sc, src, sink, nullptr, smem, nullptr);
 }
 
 // the pixel slots k_primary<.., PERSIST = false> gave up, walked from the start by a persistent launch with rows beyond LDS (static deal of
@@ -139,11 +139,11 @@ __global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_primary(PipeDev pd)
 template <int STACK, bool TWO_LEVEL>
 __global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_primary_retry(PipeDev pd)
 {
-    __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
+    __shared__ int smem[(RT_ROWS(STACK) + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     if (pd.retry[0] == 0u) return;
     PrimaryRetrySrc src = {pd};
     PrimarySinkT<true> sink = {pd};
-    trace_wave<STACK, PBLOCK, TWO_LEVEL, 64u>(pd.sc, src, sink, nullptr, smem, nullptr);
+    trace_wave<RT_ROWS(STACK), PBLOCK, TWO_LEVEL, 64u, false, false, false, RT_REFS(STACK)>(pd.sc, src, sink, nullptr, smem, nullptr);
 }
 
 // Compaction of the hits of level L (they get shaded).  Level 0 runs over the pixel slots, level 1 over its two batches,
@@ -457,19 +457,19 @@ struct ShadowSinkN {      // ShadowMiss sets visibility 1 (ProgressiveRaytracing
 template <int STACK, bool TWO_LEVEL, bool BATCH>
 __global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_trace_shadow(SceneDev sc, ShadowQueue queues, uint32_t *pool, uint32_t *stat)
 {
-    __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
+    __shared__ int smem[(RT_ROWS(STACK) + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     ShadowSrcN<BATCH> src;
     static_cast<ShadowQueue &>(src) = queues;
     ShadowSinkN sink = {queues};
-    trace_wave<STACK, PBLOCK, TWO_LEVEL, (!TWO_LEVEL && STACK == RT_LDS_STACK_ROWS_SETS) ? RT_POOL_CHUNK_SETS : RT_POOL_CHUNK, RT_SHADOW_UNORDERED != 0>(sc, src, sink, pool, smem, stat);
+    trace_wave<RT_ROWS(STACK), PBLOCK, TWO_LEVEL, (!TWO_LEVEL && RT_ROWS(STACK) == RT_LDS_STACK_ROWS_SETS) ? RT_POOL_CHUNK_SETS : RT_POOL_CHUNK, RT_SHADOW_UNORDERED != 0, false, false, RT_REFS(STACK)>(sc, src, sink, pool, smem, stat);
 }
 
 template <int STACK, bool TWO_LEVEL>
 __global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_trace_secondary(SceneDev sc, QueueSrc src, float4 *hit1, uint32_t *inst1, uint32_t *pool, uint32_t *stat)
 {
-    __shared__ int smem[(STACK + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
+    __shared__ int smem[(RT_ROWS(STACK) + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     SecondarySink sink = {src, hit1, inst1};
-    trace_wave<STACK, PBLOCK, TWO_LEVEL, (!TWO_LEVEL && STACK == RT_LDS_STACK_ROWS_SETS) ? RT_POOL_CHUNK_SETS : RT_POOL_CHUNK>(sc, src, sink, pool, smem, stat);
+    trace_wave<RT_ROWS(STACK), PBLOCK, TWO_LEVEL, (!TWO_LEVEL && RT_ROWS(STACK) == RT_LDS_STACK_ROWS_SETS) ? RT_POOL_CHUNK_SETS : RT_POOL_CHUNK, false, false, false, RT_REFS(STACK)>(sc, src, sink, pool, smem, stat);
 }
 
 // ---- walk counting (rt_pipeline_count_walk): the production walk over the last frame's queues with per-lane
@@ -482,14 +482,14 @@ __global__ void __launch_bounds__(PBLOCK) k_walk_primary(PipeDev pd, unsigned lo
     __shared__ int smem[(RT_LDS_STACK_ROWS + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     PrimarySrc src = {pd};
     NullSink sink;
-    trace_wave<RT_LDS_STACK_ROWS, PBLOCK, TWO_LEVEL, 64u, false, true>(pd.sc, src, sink, nullptr, smem, nullptr, walk);
+    trace_wave<RT_LDS_STACK_ROWS, PBLOCK, TWO_LEVEL, 64u, false, true, false, true>(pd.sc, src, sink, nullptr, smem, nullptr, walk);
 }
 template <bool TWO_LEVEL>
 __global__ void __launch_bounds__(PBLOCK) k_walk_queue(SceneDev sc, QueueSrc src, unsigned long long *walk)
 {
     __shared__ int smem[(RT_LDS_STACK_ROWS + RT_TOP_ROWS(PBLOCK)) * PBLOCK];
     NullSink sink;
-    trace_wave<RT_LDS_STACK_ROWS, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK, false, true>(sc, src, sink, nullptr, smem, nullptr, walk);
+    trace_wave<RT_LDS_STACK_ROWS, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK, false, true, false, true>(sc, src, sink, nullptr, smem, nullptr, walk);
 }
 template <bool TWO_LEVEL>
 __global__ void __launch_bounds__(PBLOCK) k_walk_shadow(SceneDev sc, ShadowQueue queue, unsigned long long *walk)
@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(PBLOCK) k_walk_shadow(SceneDev sc, ShadowQueue
     ShadowSrcN<true> src;
     static_cast<ShadowQueue &>(src) = queue;
     NullSink sink;
-    trace_wave<RT_LDS_STACK_ROWS, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK, RT_SHADOW_UNORDERED != 0, true>(sc, src, sink, nullptr, smem, nullptr, walk);
+    trace_wave<RT_LDS_STACK_ROWS, PBLOCK, TWO_LEVEL, RT_POOL_CHUNK, RT_SHADOW_UNORDERED != 0, true, false, true>(sc, src, sink, nullptr, smem, nullptr, walk);
 }
 
 // the frame's ray / hit counts into the running totals (one thread, once per frame)
@@ -781,9 +781,12 @@ int launch_frame(rt_pipeline *p, PipeDev &pd, uint32_t shadow_slots, bool counte
     return RT_OK;
 }
 
+// (+ RT_STACK_REFS: the instantiations that look references up, for scenes that hold split triangles)
 template <int STACK>
 int launch_frame_any(rt_pipeline *p, PipeDev &pd, uint32_t shadow_slots, bool counted)
 {
+    if (p->scene->has_refs)
+        return p->scene->two_level ? launch_frame<STACK + RT_STACK_REFS, true>(p, pd, shadow_slots, counted) : launch_frame<STACK + RT_STACK_REFS, false>(p, pd, shadow_slots, counted);
     return p->scene->two_level ? launch_frame<STACK, true>(p, pd, shadow_slots, counted) : launch_frame<STACK, false>(p, pd, shadow_slots, counted);
 }
 
@@ -827,7 +830,8 @@ int rt_frame_launch(rt_pipeline *p, PipeDev &pd, uint32_t shadow_slots, bool cou
     // 18 LDS stack rows + the 8-row top table = 26 KiB per 256-thread block = 6 resident blocks per CU, whatever
     // the depth of the tree; the rare deeper walk continues in global rows (rt_trace_wave.h)
     if (p->ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST) return launch_frame_any<RT_LDS_STACK_ROWS_TEST>(p, pd, shadow_slots, counted);
-    if (set_rows) return launch_frame<RT_LDS_STACK_ROWS_SETS, false>(p, pd, shadow_slots, counted);
+    if (set_rows) return p->scene->has_refs ? launch_frame<RT_LDS_STACK_ROWS_SETS + RT_STACK_REFS, false>(p, pd, shadow_slots, counted)
+                                            : launch_frame<RT_LDS_STACK_ROWS_SETS, false>(p, pd, shadow_slots, counted);
     return launch_frame_any<RT_LDS_STACK_ROWS>(p, pd, shadow_slots, counted);
 }
 

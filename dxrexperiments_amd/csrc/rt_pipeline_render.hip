@@ -83,7 +83,7 @@ float free_radius(rt_pipeline *p, const PipeDev &pd, const float lp[3])
     const bool known = f.known_gen == s->generation && memcmp(f.known_lp, lp, sizeof f.known_lp) == 0;
     const bool asked = f.in_flight && f.asked_gen == s->generation && memcmp(f.asked_lp, lp, sizeof f.asked_lp) == 0;
     if (!known && !asked && !f.in_flight) {
-        const uint32_t n = s->two_level ? (uint32_t)s->inst.size() : (s->inst.empty() || !s->inst[0].model ? 0u : s->inst[0].model->n_tris);
+        const uint32_t n = s->two_level ? (uint32_t)s->inst.size() : (s->inst.empty() || !s->inst[0].model ? 0u : s->inst[0].model->n_recs);
         if (n == 0u || !f.landed) return 0.0f;
         if (hipMemsetD32Async((hipDeviceptr_t)f.d_min.p, 0x7f800000, 1, st) != hipSuccess) return 0.0f;      // +inf
         k_free_sphere<<<(n + PBLOCK - 1) / PBLOCK, PBLOCK, 0, st>>>(pd.sc, s->two_level ? 1u : 0u, n, lp[0], lp[1], lp[2], f.d_min.as<uint32_t>());
@@ -157,7 +157,7 @@ int prepare_shadow_cache(rt_pipeline *p, const rt_per_frame_constants &pfc, cons
     c.table = p->shadow_cache.as<uint32_t>();
     c.res = res; c.res_f = (float)res;
     c.two_level = s->two_level ? 1u : 0u;
-    c.n_tris = s->two_level ? 0u : s->inst[0].model->n_tris;
+    c.n_tris = s->two_level ? 0u : s->inst[0].model->n_recs;
     c.entries = (uint32_t)entries;
     c.px_base = px_slots ? (uint32_t)cells : 0u;
     c.px_slots = (uint32_t)px_slots;                 // (launch_frame fills in what belongs to the launch: jlist0, hstride0, the set's frames)

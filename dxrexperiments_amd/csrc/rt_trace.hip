@@ -55,8 +55,8 @@ struct BatchSink {
 template <int STACK, bool TWO_LEVEL>
 __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(SceneDev sc, BatchSrc src, BatchSink sink, uint32_t *pool)
 {
-    __shared__ int smem[(STACK + RT_TOP_ROWS(TRACE_BLOCK)) * TRACE_BLOCK];
-    trace_wave<STACK, TRACE_BLOCK, TWO_LEVEL, RT_POOL_CHUNK>(sc, src, sink, pool, smem, nullptr);
+    __shared__ int smem[(RT_ROWS(STACK) + RT_TOP_ROWS(TRACE_BLOCK)) * TRACE_BLOCK];
+    trace_wave<RT_ROWS(STACK), TRACE_BLOCK, TWO_LEVEL, RT_POOL_CHUNK, false, false, false, RT_REFS(STACK)>(sc, src, sink, pool, smem, nullptr);
 }
 
 template <int STACK>
@@ -90,7 +90,10 @@ int rt_launch_trace(rt_context *ctx, const rt_scene *s, const float4 *o, const f
         uint32_t *pool = ctx->pool.as<uint32_t>();
         // a fixed number of LDS stack rows whatever the depth of the tree: deeper walks continue in global rows
         RT_TRY(rt_scene_dev_for_launch(ctx, s, rt_lds_stack_rows(ctx), (size_t)ctx->cu_count * 16 * TRACE_BLOCK, &sc));
-        if (ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST) launch_fast<RT_LDS_STACK_ROWS_TEST>(ctx, s->two_level, st, sc, src, sink, pool);
+        if (s->has_refs) {
+            if (ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST) launch_fast<RT_LDS_STACK_ROWS_TEST + RT_STACK_REFS>(ctx, s->two_level, st, sc, src, sink, pool);
+            else launch_fast<RT_LDS_STACK_ROWS + RT_STACK_REFS>(ctx, s->two_level, st, sc, src, sink, pool);
+        } else if (ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST) launch_fast<RT_LDS_STACK_ROWS_TEST>(ctx, s->two_level, st, sc, src, sink, pool);
         else launch_fast<RT_LDS_STACK_ROWS>(ctx, s->two_level, st, sc, src, sink, pool);
     }
     HIP_TRY(hipGetLastError());

@@ -78,9 +78,11 @@ RT_DEV f3 xform_dir(const float *m, f3 p)
     return mk3(x, y, z);
 }
 
-// Moller-Trumbore + validation against the triangle's own AABB over [tmin, t].
+// Moller-Trumbore + validation over [tmin, t] against the triangle's own AABB -- or, for a triangle the builder holds as several
+// references (rt_refs.h; round 5), against ONE OF ITS REFERENCE BOXES: ref = 1: this visit's own box (own6), ref = 2: any of the
+// triangle's n_refs boxes (refs6).  ref = 0 is every triangle of rounds 1 - 4.
 RT_DEV bool tri_candidate(f3 o, f3 d, const RayInv &ri, float tmin, float tmax, f3 v0, f3 v1, f3 v2, bool cull,
-                          float &t, float &u, float &v)
+                          float &t, float &u, float &v, uint32_t ref = 0u, const float *own6 = nullptr, const float *refs6 = nullptr, uint32_t n_refs = 0u)
 {
     const f3 e1 = v1 - v0;
     const f3 e2 = v2 - v0;
@@ -98,9 +100,18 @@ RT_DEV bool tri_candidate(f3 o, f3 d, const RayInv &ri, float tmin, float tmax, 
     const float tt = dot(e2, q) * inv;
     if (!(tt > tmin) || !(tt < tmax)) return false;
     float e;
-    if (!slab_hit(ri, fmin2(fmin2(v0.x, v1.x), v2.x), fmax2(fmax2(v0.x, v1.x), v2.x),
-                  fmin2(fmin2(v0.y, v1.y), v2.y), fmax2(fmax2(v0.y, v1.y), v2.y),
-                  fmin2(fmin2(v0.z, v1.z), v2.z), fmax2(fmax2(v0.z, v1.z), v2.z), tmin, tt, e))
+    if (ref == 1u) {
+        if (!slab_hit(ri, own6[0], own6[3], own6[1], own6[4], own6[2], own6[5], tmin, tt, e)) return false;
+    } else if (ref == 2u) {
+        bool ok = false;
+        for (uint32_t k = 0; k < n_refs && !ok; k++) {
+            const float *b = refs6 + 6 * (size_t)k;
+            ok = slab_hit(ri, b[0], b[3], b[1], b[4], b[2], b[5], tmin, tt, e);
+        }
+        if (!ok) return false;
+    } else if (!slab_hit(ri, fmin2(fmin2(v0.x, v1.x), v2.x), fmax2(fmax2(v0.x, v1.x), v2.x),
+                         fmin2(fmin2(v0.y, v1.y), v2.y), fmax2(fmax2(v0.y, v1.y), v2.y),
+                         fmin2(fmin2(v0.z, v1.z), v2.z), fmax2(fmax2(v0.z, v1.z), v2.z), tmin, tt, e))
         return false;
     t = tt; u = uu; v = vv;
     return true;
@@ -133,12 +144,27 @@ RT_DEV ObjRay to_object(const InstanceRec &in, const RayD &r)
     return o;
 }
 
-// candidate (v0,v1,v2,prim) of instance ii against the running best
+// candidate (v0,v1,v2,prim) of instance ii against the running best.  REFS: how split references (rt_refs.h) are looked up --
+//   0  the scene has none: the code of rounds 1 - 4 (the traversal kernels sit exactly on their register budgets: the instantiations for
+//      scenes without split triangles must not carry the lookup -- with it the seven-wave kernels spilled 20 - 36 more bytes and the bench
+//      scene's frame took 9 % longer, profiles/r05/split_refs.txt);
+//   1  production walk of a scene with split triangles: the record says (ref = TriRec::c.z bits) whether it is one reference of several
+//      (its box: rec_boxes[rec]) or, in a layout that holds a split triangle once, that all its boxes are to be tried (by primitive);
+//   2  canonical walk: by primitive.
+template <int REFS = 0>
 RT_DEV bool accept_candidate(const InstanceRec &in, uint32_t ii, uint32_t prim, f3 v0, f3 v1, f3 v2, const RayD &r,
-                             const RayInv &wri, const ObjRay &orr, bool cull, HitD &best)
+                             const RayInv &wri, const ObjRay &orr, bool cull, HitD &best, uint32_t ref = 0u, uint32_t rec = RT_NO_HIT)
 {
     float t, u, v;
-    if (!tri_candidate(orr.o, orr.d, orr.ri, r.tmin, r.tmax, v0, v1, v2, cull, t, u, v)) return false;
+    const float *own6 = nullptr, *refs6 = nullptr;
+    uint32_t n_refs = 0u;
+    if (REFS == 0) ref = 0u;
+    if (REFS == 2) ref = in.ref_off && in.ref_off[prim + 1] - in.ref_off[prim] > 1u ? 2u : 0u;
+    if (REFS != 0) {
+        if (ref == 1u) own6 = in.rec_boxes + 6 * (size_t)rec;
+        else if (ref == 2u) { const uint32_t first = in.ref_off[prim]; refs6 = in.ref_boxes + 6 * (size_t)first; n_refs = in.ref_off[prim + 1] - first; }
+    }
+    if (!tri_candidate(orr.o, orr.d, orr.ri, r.tmin, r.tmax, v0, v1, v2, cull, t, u, v, ref, own6, refs6, n_refs)) return false;
     if (!(in.flags & RT_INST_IDENTITY)) {
         float e;
         if (!slab_hit(wri, in.wlo[0], in.whi[0], in.wlo[1], in.whi[1], in.wlo[2], in.whi[2], r.tmin, t, e)) return false;
@@ -181,8 +207,8 @@ RT_DEV bool canonical_blas(const SceneDev &sc, uint32_t ii, const RayD &r, const
             const rt_float3 p0 = in.verts[in.indices[3 * prim + 0]].position;
             const rt_float3 p1 = in.verts[in.indices[3 * prim + 1]].position;
             const rt_float3 p2 = in.verts[in.indices[3 * prim + 2]].position;
-            if (accept_candidate(in, ii, prim, mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), r, wri, orr,
-                                 cull, best) && first)
+            if (accept_candidate<2>(in, ii, prim, mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), r, wri, orr,
+                                    cull, best) && first)
                 return true;
             if (sp == 0) break;
             cur = stack[--sp];

@@ -150,7 +150,9 @@ template <class S> RT_DEV bool load_ray_of(const S &src, uint32_t i, RayD &r, ui
 // those rows 224 MB per 1080p frame of a set.  A lane whose walk would need such a row gives the ray up: src.overflow(ticket) puts it on a
 // list that a small persistent launch with rows (k_primary_retry, rt_pipeline.hip) walks from the start; nothing is stored for it here.
 #define RT_WALK_WORDS 11
-template <int STACK, int BLOCK, bool TWO_LEVEL, uint32_t CHUNK, bool ANYHIT = false, bool COUNT = false, bool NO_DEEP = false, class Src, class Sink>
+// REFS (round 5): the scene holds triangles that are split into references (rt_refs.h): the leaf phase passes every record's reference mark
+// to the candidate test.  Instantiations for scenes without such triangles are the kernels of round 4, instruction for instruction.
+template <int STACK, int BLOCK, bool TWO_LEVEL, uint32_t CHUNK, bool ANYHIT = false, bool COUNT = false, bool NO_DEEP = false, bool REFS = false, class Src, class Sink>
 RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uint32_t *pool, int *smem, uint32_t *traced_counter,
                        unsigned long long *walk = nullptr)
 {
@@ -292,7 +294,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                         st.lds[(STACK - 1) * BLOCK] = (int)slot;
                         // (an entry is only ever tested if it names a triangle that exists: the table is emptied with the scene, but a pair
                         // torn between two writers, or a table handed over by mistake, must not read past an array)
-                        if (ct != RT_NO_HIT && (!TWO_LEVEL || (ci < sc.n_inst && ct < sc.inst[ci].n_prims))) {      // (single level: the source checks against its own count)
+                        if (ct != RT_NO_HIT && (!TWO_LEVEL || (ci < sc.n_inst && ct < sc.inst[ci].n_recs))) {      // (single level: the source checks against its own count)
                             st.lds[0] = root0;
                             sp = 1;
                             if (TWO_LEVEL) {          // ... inside its instance: the leaf, then the sentinel that leads back out, then the TLAS root
@@ -427,7 +429,8 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     const v4f a = ldg16(tp, 0), b = ldg16(tp, 16), c = ldg16(tp, 32);
                     const uint32_t prim = __float_as_uint(c.y);
                     HitD found = ANYHIT ? make_miss(r) : best;          // (any-hit: the running best never changes before the ray ends)
-                    const bool accepted = accept_candidate(*in, ii, prim, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), r, wri, cur, cull, found);
+                    const bool accepted = accept_candidate<REFS ? 1 : 0>(*in, ii, prim, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), r, wri, cur, cull, found,
+                                                                         REFS ? __float_as_uint(c.z) : 0u, first_tri + k);
                     if (!ANYHIT) best = found;
                     if (accepted && first) {
                         if constexpr (src_has_cache<Src>::value && ANYHIT && !COUNT) src.template remember<TWO_LEVEL>((uint32_t)st.lds[(STACK - 1) * BLOCK], first_tri + k, ii);

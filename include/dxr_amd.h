@@ -134,6 +134,15 @@ int rt_scene_wide_read(const rt_scene *s, int which, void *nodes, void *records)
 /* test / experiment hook: overwrite the node array with a RENUMBERING of itself (same count; node 0 stays the root and the
  * first nodes the breadth-first top the traversal keeps in LDS).  Results do not depend on node numbers. */
 int rt_debug_wide_write(rt_scene *s, int which, const void *nodes, uint32_t n_nodes);
+/* Split references (round 5; dxrexperiments_amd/csrc/rt_refs.h, defined in oracle/oracle_bvh.h): a long thin triangle whose AABB is more than
+ * eight times its own surface is held by the traversal layout as up to 32 references, each with the box of the part of the triangle inside
+ * one slab of its longest axis, and a candidate hit on it is accepted only if one of those boxes passes the slab test over [tmin, t] (an
+ * unsplit triangle: its own AABB, the rule of rounds 1 - 4).  rt_scene_refs_info: triangles of instance `which`'s model and its boxes in all
+ * (0: no triangle is split); rt_scene_refs_read: ref_off[n_tris + 1], the boxes by primitive (6 floats each) and the box of every record of
+ * the traversal layout (rt_scene_wide_read's records; meaningful where a record's third word of c says 1).  No reference counterpart: the
+ * Fallback Layer's builder is not in the checkout (libs/DXRFramework/Helpers/BottomLevelASGenerator.cpp:333 only calls it). */
+int rt_scene_refs_info(const rt_scene *s, int which, uint32_t *n_tris, uint32_t *n_refs);
+int rt_scene_refs_read(const rt_scene *s, int which, uint32_t *ref_off, float *ref_boxes, float *record_boxes);
 /* milliseconds the last rt_scene_build spent on the GPU (BLAS + TLAS) */
 int rt_scene_build_ms(const rt_scene *s, float *ms);
 
@@ -410,6 +419,8 @@ int rt_debug_read_secondary_ray(rt_pipeline *p, uint32_t index, float origin_tmi
  *   seven_waves_always=0|1   single frames on the sets' kernels
  *   free_radius=0|1          the free sphere around the point light (1)
  *   batch_max=0..32          frames per set of launches (0: 32)
+ *   split_refs=0|1           the traversal layout holds long thin triangles as several references (1; rt_scene_refs_info).  Results do not
+ *                            depend on it: the candidate rule follows the references either way
  *   primary_retry_cap=n      entries of the retry list behind the one-tile-per-wave primary launch (0: 2^20; tests make it overflow)
  *   queue_budget_mb=n        worst-case queue bytes a set may reserve up front (0: a quarter of the device's memory)
  *   dist_check_seconds=x     how long rt_dist_create waits for the other ranks' device ids (5) */

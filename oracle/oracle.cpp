@@ -265,6 +265,31 @@ int orc_scene_bvh_read(const orc_scene *sc, int which, rt_bvh_node *nodes, uint6
     return 0;
 }
 
+void orc_set_split_refs(int on) { split_refs_enabled() = on != 0; }
+
+/* the validation boxes of a model's triangles (oracle_bvh.h "Split references"): *n_refs = 0 when no triangle of the model is split;
+ * off[n_tris + 1], boxes[6 * n_refs] = lo.xyz hi.xyz per reference, in primitive order */
+int orc_scene_refs_info(const orc_scene *sc, uint32_t model, uint32_t *n_refs)
+{
+    if (!sc->s.built || model >= sc->s.models.size()) return -1;
+    *n_refs = (uint32_t)sc->s.models[model].refs.size();
+    return 0;
+}
+
+int orc_scene_refs_read(const orc_scene *sc, uint32_t model, uint32_t *off, float *boxes)
+{
+    if (!sc->s.built || model >= sc->s.models.size()) return -1;
+    const Model &m = sc->s.models[model];
+    if (off) memcpy(off, m.ref_off.data(), sizeof(uint32_t) * m.ref_off.size());
+    if (boxes)
+        for (size_t k = 0; k < m.refs.size(); k++) {
+            const Box &b = m.refs[k];
+            const float v[6] = {b.lo.x, b.lo.y, b.lo.z, b.hi.x, b.hi.y, b.hi.z};
+            memcpy(boxes + 6 * k, v, sizeof v);
+        }
+    return 0;
+}
+
 int orc_scene_instance_info(const orc_scene *sc, uint32_t inst, float world_box[6], float inv[12])
 {
     if (!sc->s.built || inst >= sc->s.inst.size()) return -1;

@@ -45,6 +45,9 @@ int  orc_scene_add_instance(orc_scene *s, uint32_t model, const float xform3x4[1
 int  orc_scene_build(orc_scene *s);
 int  orc_scene_bvh_info(const orc_scene *s, int which, uint32_t *n_prims, uint32_t *n_nodes, uint32_t *max_depth);
 int  orc_scene_bvh_read(const orc_scene *s, int which, rt_bvh_node *nodes, uint64_t *keys, uint32_t *parents);
+void orc_set_split_refs(int on);     /* scenes built from now on: 0 = no triangle is split (the candidate rule of rounds 1 - 4) */
+int  orc_scene_refs_info(const orc_scene *s, uint32_t model, uint32_t *n_refs);
+int  orc_scene_refs_read(const orc_scene *s, uint32_t model, uint32_t *off, float *boxes);
 int  orc_scene_instance_info(const orc_scene *s, uint32_t inst, float world_box[6], float inv[12]);
 
 int  orc_trace(const orc_scene *s, const float *origin_tmin, const float *dir_tmax, size_t n, uint32_t flags, int mode,

@@ -26,7 +26,9 @@
  *   ray/tri     Moller-Trumbore, u,v for v1,v2 (RaytracingCommon.hlsli:55),
  *               front face  <=>  det > 0  (clockwise from the origin in a
  *               left-handed frame, DXR spec), TMin < t < TMax exclusive.
- *   candidate   accepted only if its own AABB (and, for a transformed
+ *   candidate   accepted only if its own AABB -- for a triangle the builder holds as
+ *               several references (round 5, "Split references" below): one of
+ *               its reference boxes -- (and, for a transformed
  *               instance, the instance's world AABB: the exact box of its
  *               triangles' transformed vertices) passes the slab test
  *               over [tmin, t]: this makes BVH traversal and the brute-force
@@ -191,6 +193,10 @@ struct Model {
     std::vector<uint32_t> idx;
     uint32_t ntris = 0;
     Bvh blas;
+    /* validation boxes (round 5, "split references"): triangle p is validated against refs[ref_off[p] .. ref_off[p + 1]); an unsplit
+     * triangle has ONE, its own AABB -- rounds 1 - 4's rule.  Empty when no triangle of the model is split. */
+    std::vector<uint32_t> ref_off;
+    std::vector<Box> refs;
 };
 
 struct Instance {
@@ -221,6 +227,93 @@ static inline Box tri_box(V3 a, V3 b, V3 c)
     Box bx = box_empty();
     box_grow(bx, a); box_grow(bx, b); box_grow(bx, c);
     return bx;
+}
+
+/*
+ * Split references (round 5).  A long thin triangle that runs diagonally through space has an AABB hundreds of times the size it needs
+ * (a 47 m x 2 cm cable: AABB 40 x 5 x 25 m): every ray through that box has to test it.  The production tree therefore holds such a
+ * triangle as SEVERAL references, each with the box of the part of the triangle inside one slab of its longest axis, and the candidate
+ * rule becomes "accepted only if ONE OF THE TRIANGLE'S REFERENCE BOXES passes the slab test over [tmin, t]" -- for a triangle that is not
+ * split (every triangle of every scene of rounds 1 - 4) that is its own AABB, the old rule, bit for bit.  Float slab tests are monotone
+ * under box inclusion, so any traversal whose node boxes contain the reference boxes -- the canonical tree over whole triangles, the
+ * production tree over references, brute force -- still returns the same bits.  The rule below IS the definition; rt_refs.h restates it
+ * for the builder and the kernels, operation for operation (no fused operations, IEEE divide and sqrt).
+ *   split iff  every coordinate is finite,  L = longest AABB extent > min_len (= the model's longest extent / 256),
+ *              a2 = |cross(v1 - v0, v2 - v0)| > 0  and  sa = (ex ey + ey ez) + ez ex > 4 a2   (AABB surface over triangle area > 8)
+ *   pieces     k = min(32, trunc(sqrt(sa / a2)), trunc(L / min_len)), at least 2; piece j = the slab [lo + L (j / k), lo + L ((j + 1) / k)]
+ *              of the longest axis (ties: x before y before z), widened by (L / k) / 4 either side and cut back to [lo, hi]; the first
+ *              slab starts at lo, the last ends at hi
+ *   its box    on the split axis the slab; on the others min / max over the vertices inside the slab and the points where the edges
+ *              0->1, 1->2, 2->0 cross the slab's two planes (y = yi + (yj - yi) * ((c - xi) / (xj - xi))); every side moved out by
+ *              pad = 2^-18 x the triangle's largest |coordinate| (rounding of the crossings, of the Moller-Trumbore acceptance itself)
+ */
+static inline bool &split_refs_enabled() { static bool on = true; return on; }      /* (tests: the rule of rounds 1 - 4 beside the new one) */
+static inline float absf_(float x) { return x < 0.0f ? -x : x; }
+static inline uint32_t ref_pieces(V3 a, V3 b, V3 c, float min_len, int *axis_out)
+{
+    const float v[9] = {a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z};
+    for (int k = 0; k < 9; k++) if (!(v[k] - v[k] == 0.0f)) return 1;
+    const Box bx = tri_box(a, b, c);
+    const float ex = bx.hi.x - bx.lo.x, ey = bx.hi.y - bx.lo.y, ez = bx.hi.z - bx.lo.z;
+    const int axis = (ex >= ey && ex >= ez) ? 0 : (ey >= ez ? 1 : 2);
+    const float L = axis == 0 ? ex : (axis == 1 ? ey : ez);
+    if (axis_out) *axis_out = axis;
+    if (!(L > min_len)) return 1;
+    const V3 e1 = vsub(b, a), e2 = vsub(c, a);
+    const V3 cr = cross3(e1, e2);
+    const float a2 = sqrtf((cr.x * cr.x + cr.y * cr.y) + cr.z * cr.z);
+    if (!(a2 > 0.0f)) return 1;
+    const float sa = (ex * ey + ey * ez) + ez * ex;
+    if (!(sa > 4.0f * a2)) return 1;
+    const float kf = sqrtf(sa / a2), lf = L / min_len;
+    uint32_t k = kf >= 32.0f ? 32u : (uint32_t)kf;
+    const uint32_t kl = lf >= 32.0f ? 32u : (uint32_t)lf;
+    if (kl < k) k = kl;
+    return k < 2u ? 1u : k;
+}
+static inline Box ref_box(V3 a, V3 b, V3 c, int axis, uint32_t k, uint32_t j)
+{
+    const float p[3][3] = {{a.x, a.y, a.z}, {b.x, b.y, b.z}, {c.x, c.y, c.z}};
+    const int u = (axis + 1) % 3, w = (axis + 2) % 3;
+    float lo = min2(min2(p[0][axis], p[1][axis]), p[2][axis]), hi = max2(max2(p[0][axis], p[1][axis]), p[2][axis]);
+    const float L = hi - lo;
+    /* (a quarter of a slab of overlap either side: Moller-Trumbore's t is only good to a per cent or so on a 1000:1 sliver, and the
+     * candidate rule asks the ray to be inside the box AT that t) */
+    const float ov = (L / (float)k) * 0.25f;
+    const float s0 = j == 0 ? lo : max2(lo, (lo + L * ((float)j / (float)k)) - ov);
+    const float s1 = j + 1 == k ? hi : min2(hi, (lo + L * ((float)(j + 1) / (float)k)) + ov);
+    const float inf = u2f(0x7f800000u);
+    float ulo = inf, uhi = -inf, wlo = inf, whi = -inf, maxabs = 0.0f;
+    for (int i = 0; i < 3; i++) {
+        for (int q = 0; q < 3; q++) maxabs = max2(maxabs, absf_(p[i][q]));
+        if (p[i][axis] >= s0 && p[i][axis] <= s1) {
+            ulo = min2(ulo, p[i][u]); uhi = max2(uhi, p[i][u]);
+            wlo = min2(wlo, p[i][w]); whi = max2(whi, p[i][w]);
+        }
+    }
+    for (int e = 0; e < 3; e++) {
+        const float *pi = p[e], *pj = p[(e + 1) % 3];
+        for (int side = 0; side < 2; side++) {
+            const float cpl = side == 0 ? s0 : s1;
+            if ((pi[axis] < cpl && pj[axis] > cpl) || (pi[axis] > cpl && pj[axis] < cpl)) {
+                const float t = (cpl - pi[axis]) / (pj[axis] - pi[axis]);
+                const float yu = pi[u] + (pj[u] - pi[u]) * t, yw = pi[w] + (pj[w] - pi[w]) * t;
+                ulo = min2(ulo, yu); uhi = max2(uhi, yu);
+                wlo = min2(wlo, yw); whi = max2(whi, yw);
+            }
+        }
+    }
+    if (!(ulo <= uhi) || !(wlo <= whi)) {          /* (cannot happen for a slab inside the triangle's extent; the whole extent then) */
+        ulo = min2(min2(p[0][u], p[1][u]), p[2][u]); uhi = max2(max2(p[0][u], p[1][u]), p[2][u]);
+        wlo = min2(min2(p[0][w], p[1][w]), p[2][w]); whi = max2(max2(p[0][w], p[1][w]), p[2][w]);
+    }
+    const float pad = maxabs * 3.814697265625e-06f;        /* 2^-18 */
+    float blo[3], bhi[3];
+    blo[axis] = s0 - pad; bhi[axis] = s1 + pad;
+    blo[u] = ulo - pad; bhi[u] = uhi + pad;
+    blo[w] = wlo - pad; bhi[w] = whi + pad;
+    Box r = { v3(blo[0], blo[1], blo[2]), v3(bhi[0], bhi[1], bhi[2]) };
+    return r;
 }
 
 static inline bool is_identity(const float m[12])
@@ -280,6 +373,34 @@ static inline void scene_build(Scene &s)
             boxes[p] = tri_box(a, b, c);
         }
         lbvh_build(boxes, m.blas);
+        /* the validation boxes of split triangles */
+        m.ref_off.clear(); m.refs.clear();
+        const Box &mb = m.blas.bounds;
+        const float ext = max2(max2(mb.hi.x - mb.lo.x, mb.hi.y - mb.lo.y), mb.hi.z - mb.lo.z);
+        const float min_len = ext * 0.00390625f;
+        std::vector<uint32_t> cnt(m.ntris, 1u);
+        bool any = false;
+        for (uint32_t p = 0; p < m.ntris; p++) {
+            V3 a, b, c;
+            tri_verts(m, p, a, b, c);
+            cnt[p] = split_refs_enabled() ? ref_pieces(a, b, c, min_len, nullptr) : 1u;
+            any = any || cnt[p] > 1u;
+        }
+        if (any) {
+            m.ref_off.resize((size_t)m.ntris + 1);
+            uint32_t at = 0;
+            for (uint32_t p = 0; p < m.ntris; p++) { m.ref_off[p] = at; at += cnt[p]; }
+            m.ref_off[m.ntris] = at;
+            m.refs.resize(at);
+            for (uint32_t p = 0; p < m.ntris; p++) {
+                V3 a, b, c;
+                tri_verts(m, p, a, b, c);
+                if (cnt[p] == 1u) { m.refs[m.ref_off[p]] = boxes[p]; continue; }
+                int axis = 0;
+                (void)ref_pieces(a, b, c, min_len, &axis);
+                for (uint32_t j = 0; j < cnt[p]; j++) m.refs[m.ref_off[p] + j] = ref_box(a, b, c, axis, cnt[p], j);
+            }
+        }
     }
     std::vector<Box> ib(s.inst.size());
     for (size_t i = 0; i < s.inst.size(); i++) {
@@ -356,7 +477,8 @@ static inline bool slab_box(const RayInv &r, const Box &b, float t0, float t1)
 
 /* Moller-Trumbore + own-AABB validation.  o,d in the triangle's space. */
 static inline bool tri_candidate(V3 o, V3 d, const RayInv &ri, float tmin, float tmax,
-                                 V3 v0, V3 v1, V3 v2, bool cull_back, float *t, float *u, float *v)
+                                 V3 v0, V3 v1, V3 v2, bool cull_back, float *t, float *u, float *v,
+                                 const Box *refs = nullptr, uint32_t n_refs = 0)
 {
     V3 e1 = vsub(v1, v0);
     V3 e2 = vsub(v2, v0);
@@ -373,8 +495,14 @@ static inline bool tri_candidate(V3 o, V3 d, const RayInv &ri, float tmin, float
     if (!(vv >= 0.0f) || !(uu + vv <= 1.0f)) return false;
     float tt = dot3(e2, q) * inv;
     if (!(tt > tmin) || !(tt < tmax)) return false;
-    Box b = tri_box(v0, v1, v2);
-    if (!slab_box(ri, b, tmin, tt)) return false;
+    if (n_refs > 1u) {              /* a split triangle: one of its reference boxes must pass */
+        bool ok = false;
+        for (uint32_t k = 0; k < n_refs && !ok; k++) ok = slab_box(ri, refs[k], tmin, tt);
+        if (!ok) return false;
+    } else {
+        Box b = tri_box(v0, v1, v2);
+        if (!slab_box(ri, b, tmin, tt)) return false;
+    }
     *t = tt; *u = uu; *v = vv;
     return true;
 }
@@ -410,7 +538,10 @@ static inline bool test_prim(const Scene &s, uint32_t ii, uint32_t prim, const R
     float t, u, v;
     bool cull = (flags & RT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES) != 0;
     /* closest: candidates in (tmin, ray.tmax); ordering vs best handled by better() */
-    if (!tri_candidate(orr.o, orr.d, orr.ri, r.tmin, r.tmax, a, b, c, cull, &t, &u, &v)) return false;
+    const Box *refs = nullptr;
+    uint32_t n_refs = 0;
+    if (!m.ref_off.empty()) { refs = &m.refs[m.ref_off[prim]]; n_refs = m.ref_off[prim + 1] - m.ref_off[prim]; }
+    if (!tri_candidate(orr.o, orr.d, orr.ri, r.tmin, r.tmax, a, b, c, cull, &t, &u, &v, refs, n_refs)) return false;
     if (!in.identity && !slab_box(wri, in.world, r.tmin, t)) return false;
     if (!better(t, ii, prim, best)) return false;
     best.t = t; best.u = u; best.v = v; best.prim = prim; best.inst = ii;

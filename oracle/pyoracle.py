@@ -66,6 +66,10 @@ def lib():
         L.orc_scene_build.argtypes = [p]
         L.orc_scene_bvh_info.argtypes = [p, C.c_int] + [C.POINTER(C.c_uint32)] * 3
         L.orc_scene_bvh_read.argtypes = [p, C.c_int, p, p, p]
+        L.orc_set_split_refs.argtypes = [C.c_int]
+        L.orc_set_split_refs.restype = None
+        L.orc_scene_refs_info.argtypes = [p, C.c_uint32, p]
+        L.orc_scene_refs_read.argtypes = [p, C.c_uint32, p, p]
         L.orc_scene_instance_info.argtypes = [p, C.c_uint32, p, p]
         L.orc_trace.argtypes = [p, p, p, C.c_size_t, C.c_uint32, C.c_int] + [p] * 7 + [C.c_int]
         L.orc_render.argtypes = [p, p, C.c_uint32, p, C.c_int, p, p] + [C.c_uint32] * 9 + [C.c_int, p, C.c_int, p]
@@ -158,6 +162,11 @@ def obj_load(path):
 IDENTITY = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32)
 
 
+def set_split_refs(on):
+    """scenes built from now on: False = no triangle is split into references (the candidate rule of rounds 1 - 4)"""
+    lib().orc_set_split_refs(1 if on else 0)
+
+
 class Scene:
     def __init__(self):
         self.h = C.c_void_p(lib().orc_scene_create())
@@ -199,6 +208,18 @@ class Scene:
         parents = np.empty(nn.value, np.uint32)
         lib().orc_scene_bvh_read(self.h, which, _ptr(nodes), _ptr(keys), _ptr(parents))
         return nodes, keys, parents, md.value
+
+    def refs(self, model, n_tris):
+        """the validation boxes of a model's triangles: (off uint32[n_tris + 1], boxes float32[n_refs, 6]); (None, None) if none is split"""
+        n = C.c_uint32()
+        if lib().orc_scene_refs_info(self.h, model, C.byref(n)) != 0:
+            raise RuntimeError("scene not built")
+        if n.value == 0:
+            return None, None
+        off = np.empty(n_tris + 1, np.uint32)
+        boxes = np.empty((n.value, 6), np.float32)
+        lib().orc_scene_refs_read(self.h, model, _ptr(off), _ptr(boxes))
+        return off, boxes
 
     def instance_info(self, i):
         box = np.empty(6, np.float32)

@@ -35,10 +35,29 @@ def test_stadium_bvh_walk_and_whole_frame_against_the_oracle(gpu, oracle, capi):
     gn, gk, gp, gd = p.g.bvh(0)
     on, ok, op, od = p.o.bvh(0)
     assert np.array_equal(gk, ok) and nodes_equal(gn, on) and np.array_equal(gp, op) and gd == od
+    # split references (round 5, rt_refs.h): the builder's boxes are the oracle's, bit for bit; the production tree holds one record per
+    # reference, every triangle at least once, a split one once per box, and every decoded child box contains the boxes of its subtree
+    ooff, oboxes = p.o.refs(0, t.shape[0])
+    goff, gboxes, grec = p.g.refs(0)
+    assert ooff is not None and np.array_equal(goff, ooff) and np.array_equal(gboxes.view(np.uint32), oboxes.view(np.uint32))
+    cnt = np.diff(ooff)
+    assert cnt.max() <= 32 and 10000 < int((cnt > 1).sum()) < 20000 and oboxes.shape[0] > t.shape[0]
     nodes, root, recs = p.g.wide_read(0)
+    assert recs.shape[0] == oboxes.shape[0]
     lo, hi, prim = Wt.record_bounds(recs)
-    assert np.array_equal(np.sort(prim), np.arange(t.shape[0], dtype=np.uint32))
-    st = Wt.check(nodes, root, lo, hi, t.shape[0], blas=True)
+    assert np.array_equal(np.bincount(prim, minlength=t.shape[0]), cnt)                    # a record per reference
+    tri = v["position"][t[prim]]
+    assert np.array_equal(recs[:, :9].reshape(-1, 3, 3), tri)
+    mark = recs.view(np.uint32)[:, 10]
+    assert np.array_equal(mark == 1, cnt[prim] > 1) and set(np.unique(mark)) <= {0, 1}
+    # the box a record is held by: its reference box if it is one of several, else the triangle's own
+    lo = np.where((mark == 1)[:, None], grec[:, :3], lo)
+    hi = np.where((mark == 1)[:, None], grec[:, 3:], hi)
+    for pr in np.nonzero(cnt > 1)[0][:200]:                      # every box of a split triangle sits on exactly one of its records
+        mine = np.sort(grec[prim == pr].view(np.uint32).view([("", np.uint32)] * 6), axis=0)
+        want = np.sort(oboxes[ooff[pr]:ooff[pr + 1]].view(np.uint32).view([("", np.uint32)] * 6), axis=0)
+        assert np.array_equal(mine, want)
+    st = Wt.check(nodes, root, lo, hi, recs.shape[0], blas=True)
     assert st["nodes"] >= 1
     # hits, all three kinds of search, bit for bit
     O, D = random_rays(150000, 31, [-30, -4, -20], [30, 14, 20])
@@ -77,3 +96,54 @@ def test_stadium_bvh_walk_and_whole_frame_against_the_oracle(gpu, oracle, capi):
     for k in rays:
         assert tot[k] == rays[k], (k, tot[k], rays[k])
     assert tot["primary_hits"] == 3 * W * H - (tot["rays_primary"] - tot["primary_hits"]) and tot["primary_hits"] > 0.9 * 3 * W * H
+
+
+def test_references_do_not_change_a_bit_whatever_layout_holds_them(gpu, oracle, capi):
+    """The candidate rule follows the split references (rt_refs.h) whether the production layout holds a long thin triangle as several
+    records (default), once in a PLOC tree (option split_refs=0) or once in the LBVH layout (fast_bvh=lbvh): hits and image must be the
+    oracle's -- and one another's -- bit for bit on a hall full of cables.  Two-level too: three instances of the cable mesh."""
+    from util import random_xforms
+    v, t = scenes.stadium_class(5, 0.25, ("hall", "cables", "slats"))
+    cores = max(1, len(os.sched_getaffinity(0)))
+    O, D = random_rays(60000, 41, [-30, -4, -20], [30, 14, 20])
+    W, H = 320, 180
+    mat = T.default_material()
+    cam = cam_array(scenes.stadium_camera(), W / H)
+    host = capi.ProgressiveHost(3)
+    pfcs = [host.update(cam, 0.0, f + 1, W, H) for f in range(2)]
+    for inst in ([(0, None)], [(0, x) for x in random_xforms(3, seed=8, spread=4.0)]):
+        osc = oracle.Scene()
+        osc.add_model(v, t)
+        for mi, x in inst:
+            osc.add_instance(mi, x)
+        osc.build()
+        assert osc.refs(0, t.shape[0])[0] is not None
+        want = osc.trace(O, D, flags=0, mode=1, nthreads=cores)
+        want_any = osc.trace(O, D, flags=ANY, mode=1, nthreads=cores)
+        acc = np.zeros((H, W, 4), np.float32)
+        for pfc in pfcs:
+            acc, _ = osc.render(mat, pfc, W, H, accum=acc, env_faces=scenes.sky_cubemap(16), nthreads=cores)
+        for opts in ({}, {"split_refs": 0}, {"fast_bvh": "lbvh"}):
+            ctx = capi.Context(0)
+            for k, val in opts.items():
+                ctx.set_option(k, val)
+            sc = capi.Scene(ctx)
+            gm = capi.Model(ctx, v, t)
+            for mi, x in inst:
+                sc.add_model(gm, x)
+            sc.build()
+            n_rec = sc.wide_read(0)[2].shape[0]
+            assert (n_rec > t.shape[0]) == (not opts), (opts, n_rec)
+            assert_hits_equal(sc.trace(O, D, flags=0), want, "cables %s" % opts)
+            assert_hits_equal(sc.trace(O, D, flags=ANY), want_any, "cables any-hit %s" % opts, closest=False)
+            assert_hits_equal(sc.trace(O[:5000], D[:5000], flags=0, canonical=True), {k: a[:5000] for k, a in want.items()}, "cables canonical %s" % opts)
+            p = capi.Pipeline(ctx)
+            p.set_scene(sc)
+            p.add_material(mat)
+            p.set_environment_cube(scenes.sky_cubemap(16))
+            p.create_output(W, H)
+            p.build_acceleration_structures()
+            for pfc in pfcs:
+                p.update(pfc)
+                p.render()
+            assert np.array_equal(p.read_output(), acc), (opts, len(inst))

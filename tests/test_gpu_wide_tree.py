@@ -25,10 +25,24 @@ def check_blas(sc, which, v, i):
     nodes, root, recs = sc.wide_read(which)
     lo, hi, prim = W.record_bounds(recs)
     n = i.shape[0]
-    assert recs.shape[0] == n and np.array_equal(np.sort(prim), np.arange(n, dtype=np.uint32)), "records are not a permutation of the triangles"
+    off, boxes, rec_boxes = sc.refs(which)
+    mark = recs.view(np.uint32)[:, 10]
+    if off is None:
+        assert recs.shape[0] == n and np.array_equal(np.sort(prim), np.arange(n, dtype=np.uint32)), "records are not a permutation of the triangles"
+        assert not mark.any()
+    else:
+        # split references (round 5, rt_refs.h): a record per reference -- every triangle at least once, a split one once per box -- and a
+        # record that is one of several is held by ITS box, which is what the child boxes above it must contain
+        cnt = np.diff(off)
+        single = recs.shape[0] == n                         # a layout that holds every triangle once (LBVH layout, option split_refs=0)
+        assert np.array_equal(np.bincount(prim, minlength=n), np.ones(n, np.int64) if single else cnt), "records do not cover the references"
+        assert np.array_equal(mark, np.where(cnt[prim] > 1, 2 if single else 1, 0))
+        if not single:
+            lo = np.where((mark == 1)[:, None], rec_boxes[:, :3], lo)
+            hi = np.where((mark == 1)[:, None], rec_boxes[:, 3:], hi)
     tri = v["position"][i[prim]]                           # the record of primitive p holds p's vertices, bit for bit
     assert np.array_equal(recs[:, :9].reshape(-1, 3, 3), tri)
-    st = W.check(nodes, root, lo, hi, n, blas=True)
+    st = W.check(nodes, root, lo, hi, recs.shape[0], blas=True)
     return st, nodes, root
 
 
@@ -38,7 +52,7 @@ def test_soups(gpu, capi, n):
     sc = build(capi, gpu, [(v, i)], [(0, None)])
     st, nodes, root = check_blas(sc, 0, v, i)
     if n > 2:
-        assert st["nodes"] >= 1 and st["nodes"] <= n - 1
+        assert st["nodes"] >= 1 and st["nodes"] <= max(n, sc.wide_read(0)[2].shape[0]) - 1          # (records: triangles, or their references)
 
 
 def test_duplicates_and_flat_boxes(gpu, capi):
