@@ -21,15 +21,17 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 from dxrexperiments_amd import capi, rtypes as T, scenes  # noqa: E402
 from oracle import pyoracle as oracle  # noqa: E402
-from util import CORNELL_OBJ, cam_array, random_xforms, triangle_soup  # noqa: E402
+from util import CORNELL_OBJ, cam_array, random_xforms, sliver_soup, triangle_soup  # noqa: E402
 
 OPTION_FLAGS = ["cosineHemisphereSampling", "showIndirectDiffuseOnly", "showIndirectSpecularOnly", "showAmbientOcclusionOnly",
                 "showGBufferAlbedoOnly", "showDirectLightingOnly", "showFresnelTerm", "noIndirectDiffuse"]
 
 
 def draw(r):
-    kind = r.integers(0, 4)
-    if kind == 0:
+    kind = r.integers(0, 5)
+    if kind == 4:            # (round 5) long thin triangles: held as several references each, validated against their boxes (rt_refs.h)
+        models = [sliver_soup(int(r.integers(4, 600)), seed=int(r.integers(1 << 30)))]
+    elif kind == 0:
         models = [triangle_soup(int(r.integers(1, 4000)), seed=int(r.integers(1 << 30)), extent=4.0, size=float(r.uniform(0.1, 1.5)))]
     elif kind == 1:
         models = [scenes.blob_mesh(level=int(r.integers(1, 4))), triangle_soup(int(r.integers(10, 500)), seed=int(r.integers(1 << 30)), extent=1.5, size=0.4)]

@@ -31,6 +31,27 @@ def triangle_soup(n, seed, extent=10.0, size=0.6):
     return v, np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
 
 
+def sliver_soup(n, seed, extent=4.0):
+    """n long thin triangles in random directions (length 0.5 ... 2 x extent, width 1/30 ... 1/3000 of it) among n small ones: what the
+    builder holds as several references each (rt_refs.h)."""
+    r = rng(seed)
+    c = r.uniform(-extent, extent, (n, 3))
+    d = r.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    w = np.cross(d, r.normal(size=(n, 3))); w /= np.linalg.norm(w, axis=1, keepdims=True)
+    L = r.uniform(0.5, 2.0, n) * extent
+    wd = L / np.exp(r.uniform(np.log(30.0), np.log(3000.0), n))
+    p = np.stack([c - 0.5 * L[:, None] * d, c + 0.5 * L[:, None] * d, c + r.uniform(-0.5, 0.5, n)[:, None] * L[:, None] * d + wd[:, None] * w], 1)
+    sv, si = triangle_soup(n, seed + 1, extent=extent, size=0.3)
+    pos = np.concatenate([np.clip(p, -1.5 * extent, 1.5 * extent).reshape(-1, 3).astype(np.float32), sv["position"]])
+    v = np.zeros(pos.shape[0], T.VERTEX)
+    v["position"] = pos
+    fn = np.cross(pos[1::3] - pos[0::3], pos[2::3] - pos[0::3])
+    l = np.linalg.norm(fn, axis=1, keepdims=True)
+    l[l == 0] = 1
+    v["normal"] = np.repeat((fn / l).astype(np.float32), 3, axis=0)
+    return v, np.arange(pos.shape[0], dtype=np.uint32).reshape(-1, 3)
+
+
 def random_xforms(n, seed, spread=8.0):
     r = rng(seed)
     out = np.zeros((n, 12), np.float32)
