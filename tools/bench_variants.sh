@@ -5,7 +5,7 @@
 for rep in $(seq 1 ${REPS:-2}); do
 for v in "$@"; do
   if [ "$v" = default ]; then unset DXR_AMD_LIB; else export DXR_AMD_LIB=$PWD/dxrexperiments_amd/lib/variants/lib$v.so; fi
-  timeout 300 python bench.py --steps ${STEPS:-60} --warmup ${WARMUP:-30} --cpu-seconds 0 --no-live-pmc --hbm-frames ${HBM:-0} 2>/dev/null | python -c "
+  timeout 300 python bench.py --steps ${STEPS:-60} --warmup ${WARMUP:-30} --cpu-seconds 0 --no-live-pmc --hbm-frames ${HBM:-0} ${EXTRA} 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 fb=d.get('frame_by_frame',{})
