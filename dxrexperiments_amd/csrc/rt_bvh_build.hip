@@ -328,7 +328,7 @@ __device__ __forceinline__ void ref_load_tri(const rt_vertex *__restrict__ verts
 __device__ __forceinline__ float ref_min_len(const float *__restrict__ bounds)
 {
     const float ex = bounds[3] - bounds[0], ey = bounds[4] - bounds[1], ez = bounds[5] - bounds[2];
-    return rtd::ref_max2(rtd::ref_max2(ex, ey), ez) * 0.00390625f;          // the model's longest extent / 256
+    return rtd::ref_max2(rtd::ref_max2(ex, ey), ez) * 0.001953125f;          // the model's longest extent / 512
 }
 __global__ void k_ref_count(const rt_vertex *__restrict__ verts, const uint32_t *__restrict__ idx, uint32_t n, const float *__restrict__ bounds,
                             uint32_t *__restrict__ count)

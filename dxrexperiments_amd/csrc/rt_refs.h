@@ -10,9 +10,10 @@
 // brute force return the same bits.  The rule is DEFINED in the test oracle (oracle_bvh.h) ("Split references"); this file restates it for the
 // builder, operation for operation: no fused operations (-ffp-contract=off), IEEE divide and sqrt, min / max that ignore nothing
 // (every coordinate is finite or the triangle is not split).
-//   split iff  every coordinate is finite,  L = longest AABB extent > min_len (= the model's longest extent / 256),
+//   split iff  every coordinate is finite,  L = longest AABB extent > min_len (= the model's longest extent / 512),
 //              a2 = |cross(v1 - v0, v2 - v0)| > 0  and  sa = (ex ey + ey ez) + ez ex > 4 a2   (AABB surface over triangle area > 8)
-//   pieces     k = min(32, trunc(sqrt(sa / a2)), trunc(L / min_len)), at least 2; piece j = the slab [lo + L (j / k), lo + L ((j + 1) / k)]
+//   pieces     k = min(128, trunc((sa / a2) / 2), trunc(L / min_len)), at least 2 (the references' surface then stays within a few times the triangle's;
+//              the first form of the rule -- min(32, sqrt(sa / a2), L / (extent / 256)) -- left the 2.2 M-triangle stress scene 2.5x slower: profiles/r05/ref_rule.txt); piece j = the slab [lo + L (j / k), lo + L ((j + 1) / k)]
 //              of the longest axis (ties: x before y before z), widened by (L / k) / 4 either side and cut back to [lo, hi]
 //   its box    on the split axis the slab; on the others min / max over the vertices inside the slab and the points where the edges
 //              0->1, 1->2, 2->0 cross the slab's two planes; every side moved out by pad = 2^-18 x the triangle's largest |coordinate|
@@ -24,7 +25,7 @@
 
 namespace rtd {
 
-#define RT_REF_MAX_PIECES 32u
+#define RT_REF_MAX_PIECES 128u
 
 RT_DEV float ref_min2(float a, float b) { return a < b ? a : b; }
 RT_DEV float ref_max2(float a, float b) { return a > b ? a : b; }
@@ -52,9 +53,9 @@ RT_DEV uint32_t ref_pieces(const float p[3][3], float min_len, int &axis)
     if (!(a2 > 0.0f)) return 1u;
     const float sa = (ex * ey + ey * ez) + ez * ex;
     if (!(sa > 4.0f * a2)) return 1u;
-    const float kf = __fsqrt_rn(__fdiv_rn(sa, a2)), lf = __fdiv_rn(L, min_len);
-    uint32_t k = kf >= 32.0f ? RT_REF_MAX_PIECES : (uint32_t)kf;
-    const uint32_t kl = lf >= 32.0f ? RT_REF_MAX_PIECES : (uint32_t)lf;
+    const float kf = __fdiv_rn(sa, a2) * 0.5f, lf = __fdiv_rn(L, min_len);
+    uint32_t k = kf >= (float)RT_REF_MAX_PIECES ? RT_REF_MAX_PIECES : (uint32_t)kf;
+    const uint32_t kl = lf >= (float)RT_REF_MAX_PIECES ? RT_REF_MAX_PIECES : (uint32_t)lf;
     if (kl < k) k = kl;
     return k < 2u ? 1u : k;
 }

@@ -135,7 +135,7 @@ int rt_scene_wide_read(const rt_scene *s, int which, void *nodes, void *records)
  * first nodes the breadth-first top the traversal keeps in LDS).  Results do not depend on node numbers. */
 int rt_debug_wide_write(rt_scene *s, int which, const void *nodes, uint32_t n_nodes);
 /* Split references (round 5; dxrexperiments_amd/csrc/rt_refs.h, defined in oracle/oracle_bvh.h): a long thin triangle whose AABB is more than
- * eight times its own surface is held by the traversal layout as up to 32 references, each with the box of the part of the triangle inside
+ * eight times its own surface is held by the traversal layout as up to 128 references, each with the box of the part of the triangle inside
  * one slab of its longest axis, and a candidate hit on it is accepted only if one of those boxes passes the slab test over [tmin, t] (an
  * unsplit triangle: its own AABB, the rule of rounds 1 - 4).  rt_scene_refs_info: triangles of instance `which`'s model and its boxes in all
  * (0: no triangle is split); rt_scene_refs_read: ref_off[n_tris + 1], the boxes by primitive (6 floats each) and the box of every record of

@@ -238,9 +238,9 @@ static inline Box tri_box(V3 a, V3 b, V3 c)
  * under box inclusion, so any traversal whose node boxes contain the reference boxes -- the canonical tree over whole triangles, the
  * production tree over references, brute force -- still returns the same bits.  The rule below IS the definition; rt_refs.h restates it
  * for the builder and the kernels, operation for operation (no fused operations, IEEE divide and sqrt).
- *   split iff  every coordinate is finite,  L = longest AABB extent > min_len (= the model's longest extent / 256),
+ *   split iff  every coordinate is finite,  L = longest AABB extent > min_len (= the model's longest extent / 512),
  *              a2 = |cross(v1 - v0, v2 - v0)| > 0  and  sa = (ex ey + ey ez) + ez ex > 4 a2   (AABB surface over triangle area > 8)
- *   pieces     k = min(32, trunc(sqrt(sa / a2)), trunc(L / min_len)), at least 2; piece j = the slab [lo + L (j / k), lo + L ((j + 1) / k)]
+ *   pieces     k = min(128, trunc((sa / a2) / 2), trunc(L / min_len)), at least 2; piece j = the slab [lo + L (j / k), lo + L ((j + 1) / k)]
  *              of the longest axis (ties: x before y before z), widened by (L / k) / 4 either side and cut back to [lo, hi]; the first
  *              slab starts at lo, the last ends at hi
  *   its box    on the split axis the slab; on the others min / max over the vertices inside the slab and the points where the edges
@@ -265,9 +265,9 @@ static inline uint32_t ref_pieces(V3 a, V3 b, V3 c, float min_len, int *axis_out
     if (!(a2 > 0.0f)) return 1;
     const float sa = (ex * ey + ey * ez) + ez * ex;
     if (!(sa > 4.0f * a2)) return 1;
-    const float kf = sqrtf(sa / a2), lf = L / min_len;
-    uint32_t k = kf >= 32.0f ? 32u : (uint32_t)kf;
-    const uint32_t kl = lf >= 32.0f ? 32u : (uint32_t)lf;
+    const float kf = (sa / a2) * 0.5f, lf = L / min_len;
+    uint32_t k = kf >= 128.0f ? 128u : (uint32_t)kf;
+    const uint32_t kl = lf >= 128.0f ? 128u : (uint32_t)lf;
     if (kl < k) k = kl;
     return k < 2u ? 1u : k;
 }
@@ -377,7 +377,7 @@ static inline void scene_build(Scene &s)
         m.ref_off.clear(); m.refs.clear();
         const Box &mb = m.blas.bounds;
         const float ext = max2(max2(mb.hi.x - mb.lo.x, mb.hi.y - mb.lo.y), mb.hi.z - mb.lo.z);
-        const float min_len = ext * 0.00390625f;
+        const float min_len = ext * 0.001953125f;
         std::vector<uint32_t> cnt(m.ntris, 1u);
         bool any = false;
         for (uint32_t p = 0; p < m.ntris; p++) {

@@ -41,7 +41,7 @@ def test_stadium_bvh_walk_and_whole_frame_against_the_oracle(gpu, oracle, capi):
     goff, gboxes, grec = p.g.refs(0)
     assert ooff is not None and np.array_equal(goff, ooff) and np.array_equal(gboxes.view(np.uint32), oboxes.view(np.uint32))
     cnt = np.diff(ooff)
-    assert cnt.max() <= 32 and 10000 < int((cnt > 1).sum()) < 20000 and oboxes.shape[0] > t.shape[0]
+    assert cnt.max() <= 128 and 10000 < int((cnt > 1).sum()) < 40000 and oboxes.shape[0] > t.shape[0]
     nodes, root, recs = p.g.wide_read(0)
     assert recs.shape[0] == oboxes.shape[0]
     lo, hi, prim = Wt.record_bounds(recs)
