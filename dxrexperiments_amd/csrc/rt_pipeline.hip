@@ -830,8 +830,10 @@ int rt_frame_launch(rt_pipeline *p, PipeDev &pd, uint32_t shadow_slots, bool cou
     // 18 LDS stack rows + the 8-row top table = 26 KiB per 256-thread block = 6 resident blocks per CU, whatever
     // the depth of the tree; the rare deeper walk continues in global rows (rt_trace_wave.h)
     if (p->ctx->lds_stack_rows == RT_LDS_STACK_ROWS_TEST) return launch_frame_any<RT_LDS_STACK_ROWS_TEST>(p, pd, shadow_slots, counted);
-    if (set_rows) return p->scene->has_refs ? launch_frame<RT_LDS_STACK_ROWS_SETS + RT_STACK_REFS, false>(p, pd, shadow_slots, counted)
-                                            : launch_frame<RT_LDS_STACK_ROWS_SETS, false>(p, pd, shadow_slots, counted);
+    // (scene_for_set never asks for the sets' rows on a scene with split triangles: there the 18-row six-wave kernels are the faster ones --
+    // 2.2 M-triangle stress scene 5.63 -> 4.89 ms per frame, 272 k 4.88 -> 4.86: profiles/r05/ref_rule.txt -- and the reference-aware
+    // seven-wave instantiations, which spilled 36 - 72 B, are not compiled)
+    if (set_rows) return launch_frame<RT_LDS_STACK_ROWS_SETS, false>(p, pd, shadow_slots, counted);
     return launch_frame_any<RT_LDS_STACK_ROWS>(p, pd, shadow_slots, counted);
 }
 

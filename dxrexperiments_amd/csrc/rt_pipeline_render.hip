@@ -189,7 +189,8 @@ int scene_for_set(rt_pipeline *p, uint32_t n_frames, size_t cap, SceneDev *out, 
 {
     rt_context *ctx = p->ctx;
     const bool seven_waves_always = ctx->opt_seven_waves_always;      // (experiment: single frames on the sets' kernels)
-    const bool set_rows = (n_frames > 1 || seven_waves_always) && !p->scene->two_level && ctx->lds_stack_rows != RT_LDS_STACK_ROWS_TEST && RT_LDS_STACK_ROWS_SETS != RT_LDS_STACK_ROWS;
+    // (a scene with split triangles keeps the 18-row kernels in sets too: rt_frame_launch)
+    const bool set_rows = (n_frames > 1 || seven_waves_always) && !p->scene->two_level && !p->scene->has_refs && ctx->lds_stack_rows != RT_LDS_STACK_ROWS_TEST && RT_LDS_STACK_ROWS_SETS != RT_LDS_STACK_ROWS;
     // (round 5: rows for the threads of the PERSISTENT launches only -- at most eight 256-thread workgroups per CU fit their LDS, sixteen
     // is the option's limit; the one-tile-per-wave primary launch, one thread per pixel slot, keeps none: PipeDev::retry)
     const size_t resident = (size_t)ctx->cu_count * (ctx->blocks_per_cu_override > 8u ? ctx->blocks_per_cu_override : 8u) * PBLOCK;
