@@ -25,6 +25,7 @@
 
 namespace rtd {
 
+// S2-RULE-BEGIN (tests/test_s2_truth.py hashes the code between the marks: a change here needs new bounds in tests/golden/s2_bounds.json)
 #define RT_REF_MAX_PIECES 128u
 
 RT_DEV float ref_min2(float a, float b) { return a < b ? a : b; }
@@ -100,4 +101,5 @@ RT_DEV void ref_box(const float p[3][3], int axis, uint32_t k, uint32_t j, float
     out[w] = wlo - pad; out[3 + w] = whi + pad;
 }
 
+// S2-RULE-END
 }  // namespace rtd

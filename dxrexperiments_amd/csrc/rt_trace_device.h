@@ -24,8 +24,10 @@
 
 namespace rtd {
 
+// S2-RULE-BEGIN (tests/test_s2_truth.py hashes the code between the marks: a change here needs new bounds in tests/golden/s2_bounds.json)
 #define RT_SLAB_SLACK 1.0000152587890625f
 
+// S2-RULE-END
 struct RayD {
     f3 o; float tmin;
     f3 d; float tmax;
@@ -46,6 +48,7 @@ RT_DEV RayInv make_inv(f3 o, f3 d)
     return r;
 }
 
+// S2-RULE-BEGIN (tests/test_s2_truth.py hashes the code between the marks: a change here needs new bounds in tests/golden/s2_bounds.json)
 // slab test of one box; entry = max(lo, t0)
 RT_DEV bool slab_hit(const RayInv &r, float lx, float hx, float ly, float hy, float lz, float hz,
                      float t0, float t1, float &entry)
@@ -63,6 +66,7 @@ RT_DEV bool slab_hit(const RayInv &r, float lx, float hx, float ly, float hy, fl
 // the rounded -o*inv leaves an ABSOLUTE error that lets rays grazing a tessellated wall pass every box of that wall
 // (4 ms tails) unless every axis carries its own margin.  profiles/r02/fma_slab_experiment.md.)
 
+// S2-RULE-END
 RT_DEV f3 xform_point(const float *m, f3 p)
 {
     float x = m[0] * p.x; x += m[1] * p.y; x += m[2] * p.z; x += m[3];
@@ -78,9 +82,24 @@ RT_DEV f3 xform_dir(const float *m, f3 p)
     return mk3(x, y, z);
 }
 
-// Moller-Trumbore + validation over [tmin, t] against the triangle's own AABB -- or, for a triangle the builder holds as several
-// references (rt_refs.h; round 5), against ONE OF ITS REFERENCE BOXES: ref = 1: this visit's own box (own6), ref = 2: any of the
-// triangle's n_refs boxes (refs6).  ref = 0 is every triangle of rounds 1 - 4.
+// S2-RULE-BEGIN (tests/test_s2_truth.py hashes the code between the marks: a change here needs new bounds in tests/golden/s2_bounds.json)
+// The candidate rule's box clause (defined in the test oracle's box_clause, oracle_bvh.h).  Moller-Trumbore said the
+// ray meets the triangle at tt; the box holds (a part of) the triangle.  Passing over [tmin, tt]: the candidate stands at tt.  Failing that but
+// meeting the box inside (tmin, tmax) -- on a sliver the fp32 tt can lie a little before the ray enters the box -- it stands at the entry
+// distance (round 6; rounds 1 - 5 rejected it and the ray went through the triangle).  Either way every traversal that still looks for hits at
+// that distance or beyond reaches the box: slab tests are monotone under box inclusion and in their upper limit.
+RT_DEV bool box_clause(const RayInv &ri, float lx, float hx, float ly, float hy, float lz, float hz, float tmin, float tmax, float tt, float &at)
+{
+    float e;
+    if (slab_hit(ri, lx, hx, ly, hy, lz, hz, tmin, tt, e)) { at = tt; return true; }
+    if (!slab_hit(ri, lx, hx, ly, hy, lz, hz, tmin, tmax, e) || !(e < tmax)) return false;
+    at = e;
+    return true;
+}
+
+// Moller-Trumbore + the box clause against the triangle's own AABB -- or, for a triangle the builder holds as several
+// references (rt_refs.h; round 5), against ITS REFERENCE BOXES: ref = 1: this visit's own box (own6; the walk visits the others on its
+// own and the nearest answer wins), ref = 2: the nearest of what the triangle's n_refs boxes say (refs6).  ref = 0 is every triangle of rounds 1 - 4.
 RT_DEV bool tri_candidate(f3 o, f3 d, const RayInv &ri, float tmin, float tmax, f3 v0, f3 v1, f3 v2, bool cull,
                           float &t, float &u, float &v, uint32_t ref = 0u, const float *own6 = nullptr, const float *refs6 = nullptr, uint32_t n_refs = 0u)
 {
@@ -99,21 +118,26 @@ RT_DEV bool tri_candidate(f3 o, f3 d, const RayInv &ri, float tmin, float tmax, 
     if (!(vv >= 0.0f) || !(uu + vv <= 1.0f)) return false;
     const float tt = dot(e2, q) * inv;
     if (!(tt > tmin) || !(tt < tmax)) return false;
-    float e;
+    float at;
     if (ref == 1u) {
-        if (!slab_hit(ri, own6[0], own6[3], own6[1], own6[4], own6[2], own6[5], tmin, tt, e)) return false;
+        if (!box_clause(ri, own6[0], own6[3], own6[1], own6[4], own6[2], own6[5], tmin, tmax, tt, at)) return false;
     } else if (ref == 2u) {
         bool ok = false;
-        for (uint32_t k = 0; k < n_refs && !ok; k++) {
+        at = tt;
+        for (uint32_t k = 0; k < n_refs; k++) {
             const float *b = refs6 + 6 * (size_t)k;
-            ok = slab_hit(ri, b[0], b[3], b[1], b[4], b[2], b[5], tmin, tt, e);
+            float a;
+            if (!box_clause(ri, b[0], b[3], b[1], b[4], b[2], b[5], tmin, tmax, tt, a)) continue;
+            if (!ok || a < at) at = a;
+            ok = true;
+            if (at == tt) break;
         }
         if (!ok) return false;
-    } else if (!slab_hit(ri, fmin2(fmin2(v0.x, v1.x), v2.x), fmax2(fmax2(v0.x, v1.x), v2.x),
-                         fmin2(fmin2(v0.y, v1.y), v2.y), fmax2(fmax2(v0.y, v1.y), v2.y),
-                         fmin2(fmin2(v0.z, v1.z), v2.z), fmax2(fmax2(v0.z, v1.z), v2.z), tmin, tt, e))
+    } else if (!box_clause(ri, fmin2(fmin2(v0.x, v1.x), v2.x), fmax2(fmax2(v0.x, v1.x), v2.x),
+                           fmin2(fmin2(v0.y, v1.y), v2.y), fmax2(fmax2(v0.y, v1.y), v2.y),
+                           fmin2(fmin2(v0.z, v1.z), v2.z), fmax2(fmax2(v0.z, v1.z), v2.z), tmin, tmax, tt, at))
         return false;
-    t = tt; u = uu; v = vv;
+    t = at; u = uu; v = vv;
     return true;
 }
 
@@ -126,6 +150,7 @@ RT_DEV bool hit_better(float t, uint32_t inst, uint32_t prim, const HitD &h)
     return prim < h.prim;
 }
 
+// S2-RULE-END
 RT_DEV HitD make_miss(const RayD &r)
 {
     HitD h;
@@ -165,9 +190,8 @@ RT_DEV bool accept_candidate(const InstanceRec &in, uint32_t ii, uint32_t prim, 
         else if (ref == 2u) { const uint32_t first = in.ref_off[prim]; refs6 = in.ref_boxes + 6 * (size_t)first; n_refs = in.ref_off[prim + 1] - first; }
     }
     if (!tri_candidate(orr.o, orr.d, orr.ri, r.tmin, r.tmax, v0, v1, v2, cull, t, u, v, ref, own6, refs6, n_refs)) return false;
-    if (!(in.flags & RT_INST_IDENTITY)) {
-        float e;
-        if (!slab_hit(wri, in.wlo[0], in.whi[0], in.wlo[1], in.whi[1], in.wlo[2], in.whi[2], r.tmin, t, e)) return false;
+    if (!(in.flags & RT_INST_IDENTITY)) {        // the instance's world box: the same clause, on what the triangle's said
+        if (!box_clause(wri, in.wlo[0], in.whi[0], in.wlo[1], in.whi[1], in.wlo[2], in.whi[2], r.tmin, r.tmax, t, t)) return false;
     }
     if (!hit_better(t, ii, prim, best)) return false;
     best.t = t; best.u = u; best.v = v; best.prim = prim; best.inst = ii;

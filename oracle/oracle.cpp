@@ -27,10 +27,26 @@
 #include <utility>
 #include "oracle_shade.h"
 #include "oracle.h"
+#include "truth64.h"
 
 using namespace orc;
 
-struct orc_scene { Scene s; };
+struct orc_scene {
+    Scene s;
+    truth64::Scene truth;       /* the same arrays for the float64 geometric truth (truth64.h); filled by orc_scene_build */
+};
+
+/* RenderCtx::truth: the float64 truth as the frame's tracer (its t, u, v rounded to fp32 for the shading code) */
+static Hit truth_hook(const void *ts, const Ray &r, uint32_t flags)
+{
+    const float o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
+    const truth64::Hit h = truth64::trace(*(const truth64::Scene *)ts, o, r.tmin, d, r.tmax,
+                                          (flags & RT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES) != 0,
+                                          (flags & RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH) != 0);
+    Hit out = miss_hit(r);
+    if (h.inst != 0xFFFFFFFFu) { out.t = (float)h.t; out.u = (float)h.u; out.v = (float)h.v; out.prim = h.prim; out.inst = h.inst; }
+    return out;
+}
 
 extern "C" {
 
@@ -236,7 +252,40 @@ int orc_scene_add_instance(orc_scene *sc, uint32_t model, const float xform3x4[1
     return (int)sc->s.inst.size() - 1;
 }
 
-int orc_scene_build(orc_scene *sc) { scene_build(sc->s); return 0; }
+int orc_scene_build(orc_scene *sc)
+{
+    scene_build(sc->s);
+    sc->truth = truth64::Scene();
+    for (const Model &m : sc->s.models)
+        truth64::add_model(sc->truth, m.verts.empty() ? nullptr : &m.verts[0].position.x, sizeof(rt_vertex) / sizeof(float), m.idx.data(), m.ntris);
+    for (const Instance &in : sc->s.inst) truth64::add_instance(sc->truth, in.model, in.m);
+    return 0;
+}
+
+/* the float64 geometric truth (truth64.h) of every ray: t (float64; -1 on a miss), u, v, prim, inst */
+int orc_truth64_trace(const orc_scene *sc, const float *origin_tmin, const float *dir_tmax, size_t n, uint32_t flags,
+                      double *t, double *u, double *v, uint32_t *prim, uint32_t *inst, int nthreads)
+{
+    if (!sc->s.built) return -1;
+    if (nthreads < 1) nthreads = 1;
+    const bool cull = (flags & RT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES) != 0, first = (flags & RT_RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH) != 0;
+    auto work = [&](int k) {
+        for (size_t i = (size_t)k; i < n; i += (size_t)nthreads) {
+            const truth64::Hit h = truth64::trace(sc->truth, origin_tmin + 4 * i, origin_tmin[4 * i + 3], dir_tmax + 4 * i, dir_tmax[4 * i + 3], cull, first);
+            const bool miss = h.inst == 0xFFFFFFFFu;
+            if (t) t[i] = miss ? -1.0 : h.t;
+            if (u) u[i] = h.u;
+            if (v) v[i] = h.v;
+            if (prim) prim[i] = h.prim;
+            if (inst) inst[i] = h.inst;
+        }
+    };
+    if (nthreads == 1) { work(0); return 0; }
+    std::vector<std::thread> th;
+    for (int k = 0; k < nthreads; k++) th.emplace_back(work, k);
+    for (std::thread &x : th) x.join();
+    return 0;
+}
 
 static const Bvh *pick(const orc_scene *sc, int which)
 {
@@ -352,7 +401,8 @@ int orc_render(const orc_scene *sc, const rt_material_params *mats, uint32_t nma
     rc.width = width; rc.height = height;
     rc.max_radiance_depth = max_radiance_depth;
     rc.max_shadow_depth = max_shadow_depth;
-    rc.use_brute = use_brute != 0;
+    rc.use_brute = use_brute == 1;
+    if (use_brute == 2) { rc.truth = truth_hook; rc.truth_scene = &sc->truth; }      /* (2: the float64 geometric truth as the tracer) */
     if (x1 > width) x1 = width;
     if (y1 > height) y1 = height;
     if (nthreads < 1) nthreads = 1;

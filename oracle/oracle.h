@@ -54,6 +54,11 @@ int  orc_trace(const orc_scene *s, const float *origin_tmin, const float *dir_tm
                float *t, float *u, float *v, uint32_t *prim, uint32_t *inst, uint32_t *cnt_nodes, uint32_t *cnt_tris,
                int nthreads);
 
+/* the float64 geometric truth (truth64.h: Moller-Trumbore over every instance x triangle, no box of any kind); t = -1 on a miss */
+int  orc_truth64_trace(const orc_scene *s, const float *origin_tmin, const float *dir_tmax, size_t n, uint32_t flags,
+                       double *t, double *u, double *v, uint32_t *prim, uint32_t *inst, int nthreads);
+
+/* use_brute: 0 = BVH traversal, 1 = the brute-force loop of oracle_bvh.h, 2 = the float64 geometric truth as the tracer */
 int  orc_render(const orc_scene *s, const rt_material_params *mats, uint32_t nmats,
                 const float *env_faces, int env_size, const float env_constant[3],
                 const rt_per_frame_constants *pfc, uint32_t width, uint32_t height,

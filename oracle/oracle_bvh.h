@@ -247,6 +247,7 @@ static inline Box tri_box(V3 a, V3 b, V3 c)
  *              0->1, 1->2, 2->0 cross the slab's two planes (y = yi + (yj - yi) * ((c - xi) / (xj - xi))); every side moved out by
  *              pad = 2^-18 x the triangle's largest |coordinate| (rounding of the crossings, of the Moller-Trumbore acceptance itself)
  */
+/* S2-RULE-BEGIN (tests/test_s2_truth.py hashes the code between the marks: a change here needs new bounds in tests/golden/s2_bounds.json) */
 static inline bool &split_refs_enabled() { static bool on = true; return on; }      /* (tests: the rule of rounds 1 - 4 beside the new one) */
 static inline float absf_(float x) { return x < 0.0f ? -x : x; }
 static inline uint32_t ref_pieces(V3 a, V3 b, V3 c, float min_len, int *axis_out)
@@ -316,6 +317,7 @@ static inline Box ref_box(V3 a, V3 b, V3 c, int axis, uint32_t k, uint32_t j)
     return r;
 }
 
+/* S2-RULE-END */
 static inline bool is_identity(const float m[12])
 {
     static const float id[12] = {1,0,0,0, 0,1,0,0, 0,0,1,0};
@@ -458,6 +460,7 @@ static inline RayInv ray_inv(V3 o, V3 d)
  * flat (zero-thickness) box; multiplying by a positive constant keeps the
  * test monotone under box inclusion, which is what the exactness argument in
  * the header needs.  All distances here are >= 0 because t0 >= 0. */
+/* S2-RULE-BEGIN (tests/test_s2_truth.py hashes the code between the marks: a change here needs new bounds in tests/golden/s2_bounds.json) */
 #define ORC_SLAB_SLACK 1.0000152587890625f
 static inline bool slab(const RayInv &r, const float bmin[3], const float bmax[3], float t0, float t1, float *entry)
 {
@@ -475,7 +478,27 @@ static inline bool slab_box(const RayInv &r, const Box &b, float t0, float t1)
     return slab(r, lo, hi, t0, t1, &e);
 }
 
-/* Moller-Trumbore + own-AABB validation.  o,d in the triangle's space. */
+/*
+ * The candidate rule's box clause (paragraph S2.4).  Moller-Trumbore said the ray meets the triangle at tt; `b` is a
+ * box that contains (a part of) the triangle.  Float slab tests are monotone under box inclusion and in their upper limit, so a candidate
+ * whose box passes over [tmin, tt] is reached by every traversal that still looks for hits at tt or beyond: it stands at tt.  On a sliver
+ * the fp32 tt can lie a little BEFORE the ray even enters the box the triangle is in (1000:1 slivers: tt is good to a per mille or so;
+ * rounds 1 - 5 rejected such a candidate, and the ray went through the triangle: 13 - 27 of 20,000 rays aimed at slivers,
+ * profiles/r06/s2_truth_before.txt).  Since round 6 such a candidate stands at the point where the ray enters the box -- the nearest point
+ * of the ray that can lie on the triangle at all -- provided the ray meets the box inside (tmin, tmax): a traversal that still looks for
+ * hits at that entry distance or beyond visits the box, so trees, visiting orders and brute force keep agreeing bit for bit.
+ * Returns false (no candidate) or the distance the candidate stands at.
+ */
+static inline bool box_clause(const RayInv &ri, const Box &b, float tmin, float tmax, float tt, float *t_at)
+{
+    float lo[3] = {b.lo.x, b.lo.y, b.lo.z}, hi[3] = {b.hi.x, b.hi.y, b.hi.z}, e;
+    if (slab(ri, lo, hi, tmin, tt, &e)) { *t_at = tt; return true; }
+    if (!slab(ri, lo, hi, tmin, tmax, &e) || !(e < tmax)) return false;      /* (e = max(entry, tmin) > tt > tmin here) */
+    *t_at = e;
+    return true;
+}
+
+/* Moller-Trumbore + the box clause against the triangle's own AABB / its reference boxes.  o,d in the triangle's space. */
 static inline bool tri_candidate(V3 o, V3 d, const RayInv &ri, float tmin, float tmax,
                                  V3 v0, V3 v1, V3 v2, bool cull_back, float *t, float *u, float *v,
                                  const Box *refs = nullptr, uint32_t n_refs = 0)
@@ -495,15 +518,22 @@ static inline bool tri_candidate(V3 o, V3 d, const RayInv &ri, float tmin, float
     if (!(vv >= 0.0f) || !(uu + vv <= 1.0f)) return false;
     float tt = dot3(e2, q) * inv;
     if (!(tt > tmin) || !(tt < tmax)) return false;
-    if (n_refs > 1u) {              /* a split triangle: one of its reference boxes must pass */
+    float at;
+    if (n_refs > 1u) {              /* a split triangle: the nearest of what its reference boxes say */
         bool ok = false;
-        for (uint32_t k = 0; k < n_refs && !ok; k++) ok = slab_box(ri, refs[k], tmin, tt);
+        for (uint32_t k = 0; k < n_refs; k++) {
+            float a;
+            if (!box_clause(ri, refs[k], tmin, tmax, tt, &a)) continue;
+            if (!ok || a < at) at = a;
+            ok = true;
+            if (at == tt) break;    /* (no clause answers less than tt) */
+        }
         if (!ok) return false;
     } else {
         Box b = tri_box(v0, v1, v2);
-        if (!slab_box(ri, b, tmin, tt)) return false;
+        if (!box_clause(ri, b, tmin, tmax, tt, &at)) return false;
     }
-    *t = tt; *u = uu; *v = vv;
+    *t = at; *u = uu; *v = vv;
     return true;
 }
 
@@ -516,6 +546,7 @@ static inline bool better(float t, uint32_t inst, uint32_t prim, const Hit &h)
     return prim < h.prim;
 }
 
+/* S2-RULE-END */
 struct ObjRay { V3 o, d; RayInv ri; };
 
 static inline ObjRay to_object(const Instance &in, const Ray &r)
@@ -542,7 +573,7 @@ static inline bool test_prim(const Scene &s, uint32_t ii, uint32_t prim, const R
     uint32_t n_refs = 0;
     if (!m.ref_off.empty()) { refs = &m.refs[m.ref_off[prim]]; n_refs = m.ref_off[prim + 1] - m.ref_off[prim]; }
     if (!tri_candidate(orr.o, orr.d, orr.ri, r.tmin, r.tmax, a, b, c, cull, &t, &u, &v, refs, n_refs)) return false;
-    if (!in.identity && !slab_box(wri, in.world, r.tmin, t)) return false;
+    if (!in.identity && !box_clause(wri, in.world, r.tmin, r.tmax, t, &t)) return false;      /* (the instance's world box: the same clause, on what the triangle's said) */
     if (!better(t, ii, prim, best)) return false;
     best.t = t; best.u = u; best.v = v; best.prim = prim; best.inst = ii;
     return true;

@@ -40,6 +40,10 @@ struct RenderCtx {
     uint32_t max_radiance_depth;   /* MAX_RADIANCE_RAY_DEPTH, RaytracingCommon.hlsli:11 */
     uint32_t max_shadow_depth;     /* MAX_SHADOW_RAY_DEPTH,   RaytracingCommon.hlsli:12 */
     bool use_brute;                /* trace through the brute-force loop instead of the BVH */
+    /* tests/test_s2_truth.py: trace through the float64 geometric truth instead (truth64.h: no box of any kind); the hook is filled
+     * by oracle.cpp, NULL otherwise */
+    Hit (*truth)(const void *truth_scene, const Ray &r, uint32_t flags) = nullptr;
+    const void *truth_scene = nullptr;
 };
 
 struct PixelStats {
@@ -57,6 +61,7 @@ struct PixelCtx {
 
 static inline Hit trace(const PixelCtx &pc, const Ray &r, uint32_t flags)
 {
+    if (pc.rc->truth) return pc.rc->truth(pc.rc->truth_scene, r, flags);
     if (pc.rc->use_brute) return trace_brute(*pc.rc->scene, r, flags);
     Counters c;
     Hit h = trace_bvh(*pc.rc->scene, r, flags, c);

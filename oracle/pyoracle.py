@@ -72,6 +72,7 @@ def lib():
         L.orc_scene_refs_read.argtypes = [p, C.c_uint32, p, p]
         L.orc_scene_instance_info.argtypes = [p, C.c_uint32, p, p]
         L.orc_trace.argtypes = [p, p, p, C.c_size_t, C.c_uint32, C.c_int] + [p] * 7 + [C.c_int]
+        L.orc_truth64_trace.argtypes = [p, p, p, C.c_size_t, C.c_uint32] + [p] * 5 + [C.c_int]
         L.orc_render.argtypes = [p, p, C.c_uint32, p, C.c_int, p, p] + [C.c_uint32] * 9 + [C.c_int, p, C.c_int, p]
         L.orc_render_realtime.argtypes = [p, p, C.c_uint32, p, C.c_int, p, p] + [C.c_uint32] * 4 + [p, p, C.c_int, p]
         L.orc_denoise.argtypes = [p, p, C.c_uint32, C.c_uint32, p, p, p, C.c_int]
@@ -239,6 +240,18 @@ class Scene:
         if rc != 0:
             raise RuntimeError("orc_trace -> %d" % rc)
         return dict(t=t, u=u, v=v, prim=prim, inst=inst, nodes=cn, tris=ct)
+
+    def truth64(self, origin_tmin, dir_tmax, flags=0, nthreads=8):
+        """the float64 geometric truth of every ray (oracle/truth64.h: no box of any kind); t = -1 on a miss"""
+        o = _f32(origin_tmin).reshape(-1, 4)
+        d = _f32(dir_tmax).reshape(-1, 4)
+        n = o.shape[0]
+        t = np.empty(n, np.float64); u = np.empty(n, np.float64); v = np.empty(n, np.float64)
+        prim = np.empty(n, np.uint32); inst = np.empty(n, np.uint32)
+        rc = lib().orc_truth64_trace(self.h, _ptr(o), _ptr(d), n, flags, _ptr(t), _ptr(u), _ptr(v), _ptr(prim), _ptr(inst), nthreads)
+        if rc != 0:
+            raise RuntimeError("orc_truth64_trace -> %d" % rc)
+        return dict(t=t, u=u, v=v, prim=prim, inst=inst)
 
     def render_realtime(self, materials, pfc, width, height, env_faces=None, env_constant=(0.5, 0.5, 0.5),
                         max_radiance_depth=1, max_shadow_depth=2, nthreads=1):
