@@ -22,7 +22,12 @@ CXX ?= g++
 HOSTFLAGS = -O2 -std=c++17 -Wall -Iinclude -Idxrexperiments_amd/include
 HOSTLINK = -L$(LIBDIR) -ldxrexperiments_amd -L/opt/rocm/lib -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib
 
-all: $(LIB) $(BIN)
+all: $(LIB) $(BIN) build/rt_rccl_abi_check.o
+
+# the hand-declared RCCL prototypes (rt_rccl_abi.h; RCCL is dlopen'ed) against the installed <rccl/rccl.h>: compiled, linked into nothing
+build/rt_rccl_abi_check.o: $(CSRC)/rt_rccl_abi_check.cpp $(CSRC)/rt_rccl_abi.h
+	@mkdir -p build
+	$(HIPCC) -std=c++17 --offload-arch=$(ARCH) -x hip -I/opt/rocm/include -c $< -o $@
 
 # host programs written against the reference-shaped C++ API (no HIP needed to compile them)
 $(LIBDIR)/progressive: examples/progressive.cpp $(LIB) $(wildcard dxrexperiments_amd/include/*.h)

@@ -105,6 +105,7 @@ SIGNATURES = {
     "rt_pipeline_set_depth_limits": (_i, [_p, _u32, _u32]),
     "rt_pipeline_set_skip_unlit_shadow_rays": (_i, [_p, _i]),
     "rt_pipeline_set_accumulation_mode": (_i, [_p, _u32]),
+    "rt_pipeline_set_accumulation_storage": (_i, [_p, _u32, _u32]),
     "rt_pipeline_clear_output": (_i, [_p]),
     "rt_pipeline_update": (_i, [_p, _p]),
     "rt_pipeline_render": (_i, [_p, _u32, _u32]),
@@ -541,6 +542,10 @@ class Pipeline:
 
     def set_accumulation_mode(self, mode):
         _check(lib().rt_pipeline_set_accumulation_mode(self.h, mode))
+
+    def set_accumulation_storage(self, fmt, rounding=0):
+        """RT_FORMAT_R16G16B16A16_FLOAT: the running mean is rounded to fp16 every frame, as the reference's RGBA16F texture does (DXRExperimentsApp.cpp:28)"""
+        _check(lib().rt_pipeline_set_accumulation_storage(self.h, fmt, rounding))
 
     def clear_output(self):
         _check(lib().rt_pipeline_clear_output(self.h))

@@ -113,9 +113,14 @@ extern "C" int rt_debug_set_option(rt_context *c, const char *name, const char *
 {
     RT_REQUIRE(c && name && value, "null argument");
     const std::string n(name);
-    const long iv = atol(value);
-    const double fv = atof(value);
+    // every option but fast_bvh takes a number: the whole of `value` must be one ('true', 'on', '4x' used to read as 0 and quietly switch things off)
+    char *end_i = nullptr, *end_f = nullptr;
+    const long iv = strtol(value, &end_i, 10);
+    const double fv = strtod(value, &end_f);
     auto bad = [&]() { rt_set_error("rt_debug_set_option: value '%s' out of range for '%s'", value, name); return RT_ERR_INVALID_ARG; };
+    const bool is_int = *value != '\0' && end_i && *end_i == '\0', is_num = *value != '\0' && end_f && *end_f == '\0';
+    const bool wants_float = n == "sah_node" || n == "sah_prim" || n == "dist_check_seconds";
+    if (n != "fast_bvh" && !(wants_float ? is_num : is_int)) { rt_set_error("rt_debug_set_option: '%s' is not a number (option '%s')", value, name); return RT_ERR_INVALID_ARG; }
     if (n == "lds_top") c->lds_top = iv != 0;
     else if (n == "lds_stack_rows") { if (iv != 0 && iv != RT_LDS_STACK_ROWS && iv != RT_LDS_STACK_ROWS_TEST) return bad(); c->lds_stack_rows = (uint32_t)iv; }
     else if (n == "persistent_blocks_per_cu") { if (iv < 0 || iv > 16) return bad(); c->blocks_per_cu_override = (uint32_t)iv; }
@@ -132,6 +137,7 @@ extern "C" int rt_debug_set_option(rt_context *c, const char *name, const char *
     else if (n == "seven_waves_always") c->opt_seven_waves_always = iv != 0;
     else if (n == "free_radius") c->opt_free_radius = iv != 0;
     else if (n == "split_refs") c->opt_split_refs = iv != 0;
+    else if (n == "fail_ploc_rounds") c->opt_fail_ploc_rounds = iv != 0;
     else if (n == "primary_retry_cap") { if (iv < 0 || iv > (1 << 24)) return bad(); c->opt_primary_retry_cap = (uint32_t)iv; }
     else if (n == "batch_max") { if (iv < 0 || iv > 32) return bad(); c->opt_batch_max = (uint32_t)iv; }
     else if (n == "queue_budget_mb") { if (iv < 0) return bad(); c->opt_queue_budget_mb = (size_t)iv; }
@@ -179,7 +185,13 @@ static int context_create(int device, void *stream, bool own, rt_context **out)
             if (end == std::string::npos) end = all.size();
             const std::string item = all.substr(at, end - at);
             const size_t eq = item.find('=');
-            if (eq != std::string::npos && rt_debug_set_option(c, item.substr(0, eq).c_str(), item.substr(eq + 1).c_str()) != RT_OK) {
+            if (item.empty()) { at = end + 1; continue; }
+            if (eq == std::string::npos) {
+                rt_set_error("RT_DEBUG_OPTIONS: '%s' is not name=value", item.c_str());
+                rt_context_release(c);
+                return RT_ERR_INVALID_ARG;
+            }
+            if (rt_debug_set_option(c, item.substr(0, eq).c_str(), item.substr(eq + 1).c_str()) != RT_OK) {
                 const std::string why = rt_last_error();
                 rt_set_error("RT_DEBUG_OPTIONS: %s", why.c_str());
                 rt_context_release(c);
@@ -187,6 +199,18 @@ static int context_create(int device, void *stream, bool own, rt_context **out)
             }
             at = end + 1;
         }
+    }
+    // the RT_* variables the library read one by one until round 4 are no longer looked at: say so once instead of quietly running the defaults
+    {
+        static const char *const legacy[] = {"RT_BATCH_MAX", "RT_BUILD_BATCH", "RT_DIST_CHECK_SECONDS", "RT_FAST_BVH", "RT_FREE_RADIUS", "RT_LDS_STACK_ROWS", "RT_LDS_TOP",
+                                             "RT_LEAF_MAX", "RT_PERSISTENT_BLOCKS_PER_CU", "RT_PRIMARY_PERSISTENT", "RT_QUEUE_BUDGET_MB", "RT_SAH_NODE", "RT_SAH_PRIM",
+                                             "RT_SEVEN_WAVES_ALWAYS", "RT_SHADOW_CACHE_PIXELS", "RT_SHADOW_CACHE_RES", "RT_VERBOSE", "RT_WIDE_SAH"};
+        static bool warned = false;
+        for (const char *v : legacy)
+            if (!warned && getenv(v)) {
+                fprintf(stderr, "[dxr_amd] %s is set but no longer read: use RT_DEBUG_OPTIONS=\"name=value,...\" or rt_debug_set_option (INTEGRATION.md)\n", v);
+                warned = true;
+            }
     }
     *out = c;
     return RT_OK;

@@ -317,6 +317,15 @@ __global__ void k_normal_records(const rt_vertex *__restrict__ verts, const uint
 
 inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
+// 64-bit sum of n 32-bit counts (grid-stride; one atomic per wave)
+__global__ void k_sum64(const uint32_t *__restrict__ v, uint32_t n, unsigned long long *__restrict__ out)
+{
+    unsigned long long s = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += v[i];
+    for (int o = 32; o > 0; o >>= 1) s += (unsigned long long)__shfl_xor((long long)s, o, 64);
+    if ((threadIdx.x & 63u) == 0u && s) atomicAdd(out, s);
+}
+
 // ---- split references (rt_refs.h): count the pieces of every triangle, then (after a scan) write their boxes ----
 __device__ __forceinline__ void ref_load_tri(const rt_vertex *__restrict__ verts, const uint32_t *__restrict__ idx, uint32_t i, float p[3][3])
 {
@@ -553,6 +562,21 @@ int rt_build_blas(rt_context *ctx, rt_model *m)
             }
             n_refs = *back;
             r_scan.release();
+            // up to RT_REF_MAX_PIECES references per triangle: beyond 2^32 / 128 triangles the 32-bit scan can wrap past a plausible
+            // total, so such a mesh has its counts summed again in 64 bits
+            if ((uint64_t)n * RT_REF_MAX_PIECES > 0xFFFFFFFFull) {
+                DevBuf sum64;
+                unsigned long long total64 = 0;
+                if ((rc = sum64.reserve(8)) != RT_OK) break;
+                if (hipMemsetAsync(sum64.p, 0, 8, st) != hipSuccess) { rt_set_error("reference count (64-bit) failed"); rc = RT_ERR_HIP; break; }
+                k_sum64<<<1024, B, 0, st>>>(d_count, n, sum64.as<unsigned long long>());
+                if (hipMemcpyAsync(&total64, sum64.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                    rt_set_error("reference count (64-bit) failed");
+                    rc = RT_ERR_HIP;
+                    break;
+                }
+                if (total64 != (unsigned long long)n_refs) { rt_set_error("split references: %llu for %u triangles", total64, n); rc = RT_ERR_UNSUPPORTED; break; }
+            }
         }
         if (n_refs != n) {
             if (n_refs < n || n_refs > (1u << (32 - RT_NODE_SHIFT))) { rt_set_error("split references: %u for %u triangles", n_refs, n); rc = RT_ERR_UNSUPPORTED; break; }
@@ -588,7 +612,19 @@ int rt_build_blas(rt_context *ctx, rt_model *m)
                               : rt_build_ploc_layout(ctx, m, &ploc_done);
             // PLOC's nearest-neighbour rounds make no progress on boxes whose surface is not finite (NaN / inf vertices,
             // extents that overflow): such a mesh keeps the LBVH as its traversal layout (m->tris is still in LBVH order)
-            if (rc == RT_ERR_STATE) { rc = RT_OK; ploc_done = false; }
+            if (rc == RT_ERR_STATE || (rc == RT_OK && ctx->opt_fail_ploc_rounds)) {      // (the option: tests force this path)
+                rc = RT_OK;
+                ploc_done = false;
+                if (split_layout) {
+                    // the split-reference path had already grown m->tris for one record per REFERENCE (DevBuf::reserve keeps no contents):
+                    // back to one LBVH-ordered record per triangle, which is what the collapse below and k_ref_mark_records index
+                    m->rec_boxes.release();
+                    m->n_recs = n;
+                    if ((rc = m->tris.reserve(sizeof(TriRec) * (size_t)n)) != RT_OK) break;
+                    k_gather_tris<<<grid_for(n, B), B, 0, st>>>(m->blas.keys.as<uint64_t>(), m->d_verts.as<rt_vertex>(),
+                                                                m->d_idx.as<uint32_t>(), n, m->tris.as<TriRec>());
+                }
+            }
             if (rc != RT_OK) break;
         }
         mark("PLOC + wide layout");

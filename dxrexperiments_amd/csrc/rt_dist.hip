@@ -24,19 +24,12 @@
 #include <new>
 
 #include "rt_internal.h"
+#include "rt_rccl_abi.h"
 
 namespace {
 
-// the few RCCL entry points used, with the types of <rccl/rccl.h> (NCCL 2.x ABI)
-struct nccl_id { char internal[128]; };
-typedef void *nccl_comm;
-typedef int (*fn_get_unique_id)(nccl_id *);
-typedef int (*fn_comm_init_rank)(nccl_comm *, int, nccl_id, int);
-typedef int (*fn_comm_destroy)(nccl_comm);
-typedef int (*fn_all_reduce)(const void *, void *, size_t, int, int, nccl_comm, hipStream_t);
-typedef int (*fn_all_gather)(const void *, void *, size_t, int, nccl_comm, hipStream_t);
-typedef const char *(*fn_error_string)(int);
-constexpr int NCCL_FLOAT = 7, NCCL_SUM = 0;
+// the few RCCL entry points used: rt_rccl_abi.h, checked against <rccl/rccl.h> at compile time by rt_rccl_abi_check.cpp
+using namespace rt_rccl;
 
 struct Rccl {
     void *so = nullptr;

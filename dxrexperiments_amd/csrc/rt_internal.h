@@ -217,6 +217,7 @@ struct rt_context {
     bool opt_seven_waves_always = false;    // seven_waves_always=1: single frames on the sets' kernels
     bool opt_free_radius = true;            // free_radius=0: no free sphere around the point light
     uint32_t opt_batch_max = 0;             // batch_max: frames per set of launches (0: RT_MAX_BATCH)
+    bool opt_fail_ploc_rounds = false;      // fail_ploc_rounds=1 (tests): the PLOC layout is thrown away as if its rounds had made no progress (non-finite boxes): the LBVH fallback
     bool opt_split_refs = true;             // split_refs=0: no triangle is held as several references (the builder of rounds 1 - 4; the CANDIDATE RULE still
                                             //   follows rt_refs.h -- results do not depend on this option)
     uint32_t opt_primary_retry_cap = 0;     // primary_retry_cap: entries of the primary launch's retry list (0: 2^20; tests: a few, so that the list overflows)
@@ -323,12 +324,17 @@ int rt_launch_trace(rt_context *ctx, const rt_scene *s, const float4 *origin_tmi
 // Grid of a persistent traversal kernel: exactly the blocks that are resident at once (the static
 // chunk interleaving gives every launched wave its share of the queue, so a block that has to wait
 // for a slot would run its share as a serial tail).
+#define RT_RESIDENT_BLOCKS_PER_CU 8
 template <class K>
 static inline unsigned rt_persistent_grid(const rt_context *ctx, K kernel, int block, size_t rays)
 {
     int per_cu = (int)ctx->blocks_per_cu_override;
     if (per_cu <= 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess) per_cu = 4;
     if (per_cu < 1) per_cu = 1;
+    // the global stack rows behind the LDS ones are sized for RT_RESIDENT_BLOCKS_PER_CU 256-thread workgroups per CU (or the option's count, if larger:
+    // scene_for_set): a launch may not have more threads than that, whatever the occupancy query says for a kernel with little LDS
+    const int row_cap = ((int)ctx->blocks_per_cu_override > RT_RESIDENT_BLOCKS_PER_CU ? (int)ctx->blocks_per_cu_override : RT_RESIDENT_BLOCKS_PER_CU) * 256 / block;
+    if (per_cu > row_cap) per_cu = row_cap;
     const size_t want = (rays + (size_t)block - 1) / (size_t)block;
     const size_t cap = (size_t)ctx->cu_count * (size_t)per_cu;
     return (unsigned)(want < cap ? (want ? want : 1) : cap);

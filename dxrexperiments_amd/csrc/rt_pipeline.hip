@@ -522,7 +522,11 @@ RT_DEV float4 accumulate(const PipeDev &pd, const float4 prev, const Shaded &sh)
     if (pd.accum_mode == RT_ACCUM_SUM) return make_float4(prev.x + cur.x, prev.y + cur.y, prev.z + cur.z, prev.w + cur.w);
     const float n = (float)pd.pfc.cameraParams.accumCount;
     const float n1 = (float)(pd.pfc.cameraParams.accumCount + 1u);
-    return make_float4((n * prev.x + cur.x) / n1, (n * prev.y + cur.y) / n1, (n * prev.z + cur.z) / n1, (n * prev.w + cur.w) / n1);
+    float4 m = make_float4((n * prev.x + cur.x) / n1, (n * prev.y + cur.y) / n1, (n * prev.z + cur.z) / n1, (n * prev.w + cur.w) / n1);
+    // the reference's RGBA16F texture (src/DXRExperimentsApp.cpp:28): what the next frame reads back is this mean rounded to fp16
+    if (pd.accum_f16 == 1u) m = make_float4(__half2float(__float2half_rn(m.x)), __half2float(__float2half_rn(m.y)), __half2float(__float2half_rn(m.z)), __half2float(__float2half_rn(m.w)));
+    else if (pd.accum_f16 == 2u) m = make_float4(__half2float(__float2half_rz(m.x)), __half2float(__float2half_rz(m.y)), __half2float(__float2half_rz(m.z)), __half2float(__float2half_rz(m.w)));
+    return m;
 }
 RT_DEV void write_aovs(const PipeDev &pd, size_t pixel, const Shaded &sh)          // two AOVs, no accumulation
 {

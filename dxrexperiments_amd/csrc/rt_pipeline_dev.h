@@ -113,6 +113,7 @@ struct PipeDev {
     uint32_t n_pixels;                  // pixels of the image this launch covers
     uint32_t max_rad, max_shadow;
     uint32_t accum_mode;
+    uint32_t accum_f16;            // 0: the running mean stays fp32; 1 / 2: rounded to fp16 every frame, to nearest even / toward zero (rt_pipeline_set_accumulation_storage)
     uint32_t skip_unlit;                // do not traverse shadow rays of lights with N.L == 0 (their visibility is multiplied by 0)
     uint32_t shadow_compact;            // shadow queues hold ONE float4 per shaded hit (QueueSrc, "light rays")
     uint32_t kind;                      // RT_PIPELINE_PROGRESSIVE / RT_PIPELINE_REALTIME
@@ -182,7 +183,7 @@ struct rt_pipeline {
     float4 *accum = nullptr;
     rt_per_frame_constants pfc;
     bool have_pfc = false;
-    uint32_t max_rad = 1, max_shadow = 2, accum_mode = RT_ACCUM_RUNNING_MEAN;
+    uint32_t max_rad = 1, max_shadow = 2, accum_mode = RT_ACCUM_RUNNING_MEAN, accum_f16 = 0;
     uint32_t skip_unlit = 0;           // off by default: every shadow ray the reference traces is traversed (rt_pipeline_set_skip_unlit_shadow_rays)
     // queues: every render call asks each buffer for what its launches need (DevBuf::reserve keeps what it has when that is
     // enough), so there is no second book of capacities that could disagree with the allocations after a failed growth

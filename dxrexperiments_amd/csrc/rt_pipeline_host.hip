@@ -244,6 +244,16 @@ int rt_pipeline_set_accumulation_mode(rt_pipeline *p, uint32_t mode)
     return RT_OK;
 }
 
+int rt_pipeline_set_accumulation_storage(rt_pipeline *p, uint32_t format, uint32_t rounding)
+{
+    RT_REQUIRE(p, "null pipeline");
+    RT_REQUIRE(format == RT_FORMAT_R32G32B32A32_FLOAT || format == RT_FORMAT_R16G16B16A16_FLOAT, "unsupported accumulation storage format");
+    RT_REQUIRE(rounding == RT_ROUND_NEAREST_EVEN || rounding == RT_ROUND_TOWARD_ZERO, "unknown rounding");
+    RT_TRY(rt_pipeline_flush_pending(p));
+    p->accum_f16 = format == RT_FORMAT_R16G16B16A16_FLOAT ? (rounding == RT_ROUND_TOWARD_ZERO ? 2u : 1u) : 0u;
+    return RT_OK;
+}
+
 int rt_pipeline_clear_output(rt_pipeline *p)
 {
     RT_REQUIRE(p, "null pipeline");

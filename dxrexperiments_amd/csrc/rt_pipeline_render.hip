@@ -193,7 +193,7 @@ int scene_for_set(rt_pipeline *p, uint32_t n_frames, size_t cap, SceneDev *out, 
     const bool set_rows = (n_frames > 1 || seven_waves_always) && !p->scene->two_level && !p->scene->has_refs && ctx->lds_stack_rows != RT_LDS_STACK_ROWS_TEST && RT_LDS_STACK_ROWS_SETS != RT_LDS_STACK_ROWS;
     // (round 5: rows for the threads of the PERSISTENT launches only -- at most eight 256-thread workgroups per CU fit their LDS, sixteen
     // is the option's limit; the one-tile-per-wave primary launch, one thread per pixel slot, keeps none: PipeDev::retry)
-    const size_t resident = (size_t)ctx->cu_count * (ctx->blocks_per_cu_override > 8u ? ctx->blocks_per_cu_override : 8u) * PBLOCK;
+    const size_t resident = (size_t)ctx->cu_count * (ctx->blocks_per_cu_override > (uint32_t)RT_RESIDENT_BLOCKS_PER_CU ? ctx->blocks_per_cu_override : (uint32_t)RT_RESIDENT_BLOCKS_PER_CU) * PBLOCK;      // (rt_persistent_grid clamps its launches to the same count)
     (void)cap;
     if (sets_kernels) *sets_kernels = set_rows;
     return rt_scene_dev_for_launch(ctx, p->scene, set_rows ? RT_LDS_STACK_ROWS_SETS : rt_lds_stack_rows(ctx), resident, out);
@@ -307,6 +307,7 @@ static int render_region(rt_pipeline *p, uint32_t width, uint32_t height, uint32
     pd.sh_levels = shadow_levels(levels_now, p->max_shadow);
     for (int k = 0; k <= MAXD; k++) pd.sh_cbase[k] = 0;
     pd.accum_mode = p->accum_mode;
+    pd.accum_f16 = p->accum_f16;
     pd.skip_unlit = p->skip_unlit;
     pd.kind = p->kind;
     // The primary stage as a persistent launch that refills its lanes from a pool of tiles (instead of one tile per wave, dealt by the

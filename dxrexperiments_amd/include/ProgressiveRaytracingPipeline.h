@@ -139,6 +139,10 @@ public:
     void setEnvironmentConstant(float r, float g, float b) { const float c[3] = {r, g, b}; DXRFramework::ThrowIfFailed(rt_pipeline_set_environment_constant(mPipeline, c)); }
 
     virtual void createOutputResource(UINT format, UINT width, UINT height) override { DXRFramework::ThrowIfFailed(rt_pipeline_create_output(mPipeline, format, width, height)); mWidth = width; mHeight = height; mFormat = format; }
+    // the reference's output texture is RGBA16F and RayGen read-modify-writes it every frame (src/DXRExperimentsApp.cpp:28,
+    // assets/shaders/ProgressiveRaytracing.hlsl:36-38): setAccumulationStorage(RT_FORMAT_R16G16B16A16_FLOAT) rounds the running mean to
+    // fp16 every frame as that texture does; the default keeps it fp32 (createOutputResource's format then only converts on read)
+    void setAccumulationStorage(UINT format, UINT rounding = RT_ROUND_NEAREST_EVEN) { DXRFramework::ThrowIfFailed(rt_pipeline_set_accumulation_storage(mPipeline, format, rounding)); }
     virtual void buildAccelerationStructures() override
     {
         mRtScene->build(mRtContext, mRtProgram->getHitProgramCount());

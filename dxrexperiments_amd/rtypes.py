@@ -43,6 +43,7 @@ RAY_FLAG_SKIP_CLOSEST_HIT_SHADER = 0x08
 RAY_FLAG_CULL_BACK_FACING_TRIANGLES = 0x10
 FORMAT_R32G32B32A32_FLOAT = 2
 FORMAT_R16G16B16A16_FLOAT = 10
+ROUND_NEAREST_EVEN, ROUND_TOWARD_ZERO = 0, 1          # rt_pipeline_set_accumulation_storage
 ACCUM_RUNNING_MEAN = 0
 ACCUM_SUM = 1
 

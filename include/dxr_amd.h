@@ -202,6 +202,16 @@ int rt_pipeline_build_acceleration_structures(rt_pipeline *p);               /* 
  * more -> RT_ERR_UNSUPPORTED.  The shadow depth is unbounded (levels past the radiance depth cast none). */
 int rt_pipeline_set_depth_limits(rt_pipeline *p, uint32_t max_radiance_depth, uint32_t max_shadow_depth);
 int rt_pipeline_set_accumulation_mode(rt_pipeline *p, uint32_t mode);        /* RT_ACCUM_* */
+/* The reference's accumulation STORAGE: its output texture is DXGI_FORMAT_R16G16B16A16_FLOAT (src/DXRExperimentsApp.cpp:28 ->
+ * src/ProgressiveRaytracingPipeline.cpp:127-131) and RayGen read-modify-writes it every frame (assets/shaders/ProgressiveRaytracing.hlsl:36-38):
+ * the running mean is read as fp16, formed in fp32 and rounded back to fp16 by the store, every frame.
+ *   format = RT_FORMAT_R32G32B32A32_FLOAT (default; north_star's "float accumulation buffer"): the mean stays fp32 from frame to frame, and an
+ *            output created as RGBA16F is only converted when it is read;
+ *   format = RT_FORMAT_R16G16B16A16_FLOAT: every frame's mean is rounded to fp16 (rounding = RT_ROUND_NEAREST_EVEN, or RT_ROUND_TOWARD_ZERO --
+ *            the D3D11 functional spec's rule for float -> lower-precision float; hardware differs, parity unpinned) before the next frame
+ *            reads it.  The buffer stays 16 B per pixel (values exactly representable in fp16); RT_ACCUM_SUM images are not rounded.
+ * Flushes a deferred set; applies from the next frame. */
+int rt_pipeline_set_accumulation_storage(rt_pipeline *p, uint32_t format, uint32_t rounding);
 /* evaluateDirectionalLight / evaluatePointLight trace their shadow ray even when N.L == 0 (RaytracingCommon.hlsli:126-147) and
  * then multiply the visibility by that zero.  off (default): they are traversed like every other ray, as in the reference.
  * on: such rays are emitted and counted (rt_stats.rays_shadow) but not traversed (rt_stats.rays_shadow_skipped); the image is
@@ -421,9 +431,12 @@ int rt_debug_read_secondary_ray(rt_pipeline *p, uint32_t index, float origin_tmi
  *   batch_max=0..32          frames per set of launches (0: 32)
  *   split_refs=0|1           the traversal layout holds long thin triangles as several references (1; rt_scene_refs_info).  Results do not
  *                            depend on it: the candidate rule follows the references either way
+ *   fail_ploc_rounds=0|1     (tests) the PLOC layout of every build is thrown away as if its rounds had made no progress (what non-finite boxes
+ *                            cause): the LBVH is collapsed instead
  *   primary_retry_cap=n      entries of the retry list behind the one-tile-per-wave primary launch (0: 2^20; tests make it overflow)
  *   queue_budget_mb=n        worst-case queue bytes a set may reserve up front (0: a quarter of the device's memory)
- *   dist_check_seconds=x     how long rt_dist_create waits for the other ranks' device ids (5) */
+ *   dist_check_seconds=x     how long rt_dist_create waits for the other ranks' device ids (5)
+ * Every value but fast_bvh's must be a number in full ("true", "4x", "" are RT_ERR_INVALID_ARG, not 0); RT_DEBUG_OPTIONS items must be name=value. */
 int rt_debug_set_option(rt_context *ctx, const char *name, const char *value);
 /* test hook: device allocations of more than `bytes` bytes fail with RT_ERR_OOM as if the device were full (0: no limit) */
 int rt_debug_set_alloc_limit(size_t bytes);

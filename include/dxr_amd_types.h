@@ -120,6 +120,9 @@ typedef struct rt_bvh_node {
 /* Accumulation modes. */
 #define RT_ACCUM_RUNNING_MEAN 0u  /* (n*prev+cur)/(n+1), ProgressiveRaytracing.hlsl:36-38 */
 #define RT_ACCUM_SUM          1u  /* prev+cur; caller divides by count (multi-GPU shards) */
+/* rounding of the fp32 running mean when the accumulation is STORED as RGBA16F (rt_pipeline_set_accumulation_storage) */
+#define RT_ROUND_NEAREST_EVEN 0u
+#define RT_ROUND_TOWARD_ZERO  1u
 
 /* Render statistics: rt_pipeline_get_stats = the most recent render call (frames = 1);
  * rt_pipeline_get_totals = sums since rt_pipeline_reset_totals. */

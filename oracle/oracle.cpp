@@ -55,6 +55,11 @@ extern "C" {
 uint32_t orc_init_rand(uint32_t v0, uint32_t v1) { return initRand(v0, v1); }
 float orc_next_rand(uint32_t *s) { return nextRand(s); }
 
+void orc_round_to_half(const float *x, float *out, size_t n, int nearest)
+{
+    for (size_t i = 0; i < n; i++) out[i] = round_to_half(x[i], nearest != 0);
+}
+
 void orc_math_batch(int fn, const float *x, const float *y, float *out, size_t n)
 {
     for (size_t i = 0; i < n; i++) {

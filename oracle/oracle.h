@@ -28,6 +28,7 @@ typedef struct orc_render_stats {
 
 uint32_t orc_init_rand(uint32_t v0, uint32_t v1);
 float    orc_next_rand(uint32_t *s);
+void     orc_round_to_half(const float *x, float *out, size_t n, int nearest);      /* binary32 -> binary16 -> binary32 */
 void     orc_math_batch(int fn, const float *x, const float *y, float *out, size_t n);
 void     orc_sample_batch(int kind, const uint32_t *seeds, const float *vec3_in, float exponent,
                           float *vec3_out, float *pdf_brdf, uint32_t *seeds_out, size_t n);

@@ -83,6 +83,46 @@ static inline float saturate(float x) { return fmin_(fmax_(x, 0.0f), 1.0f); }
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
+/* IEEE binary32 -> binary16 -> binary32: what a store to / load from an RGBA16F texture does to a value (the reference's output texture,
+ * src/DXRExperimentsApp.cpp:28).  nearest = true: round to nearest even; false: toward zero (the D3D11 functional spec's rule for float ->
+ * lower-precision float).  Subnormal halves are produced (no flush), overflow goes to infinity (nearest) or 65504 (toward zero), NaN stays NaN. */
+static inline float round_to_half(float x, bool nearest)
+{
+    const uint32_t u = f2u(x), sign = u & 0x80000000u, a = u & 0x7FFFFFFFu;
+    if (a >= 0x7F800000u) return x;                                  /* inf, NaN */
+    uint32_t h;                                                      /* the half's 15 magnitude bits */
+    if (a >= 0x38800000u) {                                          /* normal half range (>= 2^-14) or overflow */
+        const uint32_t m = a - 0x38000000u;                          /* rebias 127 -> 15; 13 fraction bits to drop */
+        h = m >> 13;
+        const uint32_t rest = m & 0x1FFFu;
+        if (nearest && (rest > 0x1000u || (rest == 0x1000u && (h & 1u)))) h++;
+        if (h >= 0x7C00u) h = nearest ? 0x7C00u : 0x7BFFu;
+    } else if (a < 0x33000000u) {                                    /* below half the smallest subnormal half (2^-25) */
+        h = 0;
+        if (nearest && a > 0x33000000u) h = 1;                       /* (never: kept for symmetry) */
+    } else {                                                         /* subnormal half: value = mant * 2^-24 */
+        const int e = (int)(a >> 23);                                /* 102 (2^-25) .. 112 (2^-15) */
+        const uint32_t mant = (a & 0x7FFFFFu) | 0x800000u;           /* 24-bit significand */
+        const int shift = 126 - e;                                   /* bits to drop: 14 .. 24 */
+        h = mant >> shift;
+        const uint32_t rest = mant & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+        if (nearest && (rest > halfway || (rest == halfway && (h & 1u)))) h++;
+    }
+    /* back to binary32 (exact) */
+    uint32_t out;
+    const uint32_t he = h >> 10, hm = h & 0x3FFu;
+    if (h == 0) out = 0;
+    else if (he == 0x1Fu) out = 0x7F800000u | (hm << 13);
+    else if (he != 0) out = ((he + 112u) << 23) | (hm << 13);
+    else {                                                           /* subnormal half -> normal float */
+        int k = 0;
+        uint32_t mm = hm;
+        while (!(mm & 0x400u)) { mm <<= 1; k++; }
+        out = ((uint32_t)(113 - k) << 23) | ((mm & 0x3FFu) << 13);
+    }
+    return u2f(sign | out);
+}
+
 /* ---- deterministic transcendental kernels ------------------------------ */
 
 /* sin and cos of x (|x| < 2^16 * pi/2).  Quadrant reduction with a 3-term

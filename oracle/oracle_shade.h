@@ -383,16 +383,21 @@ static inline bool rayGen(const PixelCtx &pc, float out[4])
 /* ProgressiveRaytracing.hlsl:36-38 */
 static inline void accumulate(float *px, const float cur[4], uint32_t accumCount, uint32_t mode)
 {
-    if (mode == RT_ACCUM_SUM) {
+    if ((mode & 0xFFu) == RT_ACCUM_SUM) {
         for (int k = 0; k < 4; k++) px[k] = px[k] + cur[k];
         return;
     }
+    /* mode bits 8-9: the accumulation is STORED as RGBA16F, as the reference's output texture is (src/DXRExperimentsApp.cpp:28 ->
+     * src/ProgressiveRaytracingPipeline.cpp:127-131; read-modify-write at ProgressiveRaytracing.hlsl:36-38): every frame's mean is rounded
+     * to fp16 -- 1: to nearest even, 2: toward zero -- before the next frame reads it */
+    uint32_t f16 = (mode >> 8) & 3u;
     float n = (float)accumCount;
     float n1 = (float)(accumCount + 1u);
     for (int k = 0; k < 4; k++) {
         float a = n * px[k];
         a = a + cur[k];
         px[k] = a / n1;
+        if (f16) px[k] = round_to_half(px[k], f16 == 1u);
     }
 }
 

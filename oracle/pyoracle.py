@@ -76,6 +76,7 @@ def lib():
         L.orc_render.argtypes = [p, p, C.c_uint32, p, C.c_int, p, p] + [C.c_uint32] * 9 + [C.c_int, p, C.c_int, p]
         L.orc_render_realtime.argtypes = [p, p, C.c_uint32, p, C.c_int, p, p] + [C.c_uint32] * 4 + [p, p, C.c_int, p]
         L.orc_denoise.argtypes = [p, p, C.c_uint32, C.c_uint32, p, p, p, C.c_int]
+        L.orc_round_to_half.argtypes = [p, p, C.c_size_t, C.c_int]
         L.orc_camera_look.argtypes = [p] * 5
         L.orc_camera_basis.argtypes = [p, p, C.c_float, C.c_float, p, p, p]
         L.orc_progressive_create.restype = p
@@ -271,7 +272,8 @@ class Scene:
         return direct, indirect, st.as_dict()
 
     def render(self, materials, pfc, width, height, accum=None, env_faces=None, env_constant=(0.5, 0.5, 0.5),
-               tile=None, accum_mode=0, max_radiance_depth=1, max_shadow_depth=2, use_brute=False, nthreads=1):
+               tile=None, accum_mode=0, max_radiance_depth=1, max_shadow_depth=2, use_brute=False, nthreads=1, accum_f16=0):
+        """accum_f16: 1 / 2 = the running mean is rounded to fp16 every frame (nearest even / toward zero): the reference's RGBA16F storage"""
         mats = np.ascontiguousarray(materials)
         assert mats.nbytes % MATERIAL_BYTES == 0
         pfc = np.ascontiguousarray(pfc)
@@ -285,7 +287,7 @@ class Scene:
         st = RenderStats()
         rc = lib().orc_render(self.h, _ptr(mats), mats.nbytes // MATERIAL_BYTES,
                               _ptr(ef), 0 if ef is None else ef.shape[1], _ptr(ec), _ptr(pfc),
-                              width, height, x0, y0, x1, y1, accum_mode, max_radiance_depth, max_shadow_depth,
+                              width, height, x0, y0, x1, y1, accum_mode | (accum_f16 << 8), max_radiance_depth, max_shadow_depth,
                               int(use_brute), _ptr(accum), nthreads, C.byref(st))
         if rc != 0:
             raise RuntimeError("orc_render -> %d" % rc)
@@ -306,6 +308,14 @@ def denoise(direct, indirect, params, nthreads=8):
     if rc != 0:
         raise RuntimeError("orc_denoise -> %d" % rc)
     return oh, ov
+
+
+def round_to_half(x, nearest=True):
+    """float32 -> float16 -> float32 by the oracle's own conversion (tests pin it against numpy's)"""
+    x = _f32(x)
+    out = np.empty_like(x)
+    lib().orc_round_to_half(_ptr(x), _ptr(out), x.size, 1 if nearest else 0)
+    return out
 
 
 def camera_look(eye, at, up):

@@ -254,6 +254,48 @@ def test_max_iterations_early_out_and_formats(gpu, capi, oracle):
     assert np.array_equal(p16.read_output(), imgs[0].astype(np.float16))
 
 
+@pytest.mark.parametrize("rounding", (T.ROUND_NEAREST_EVEN, T.ROUND_TOWARD_ZERO))
+@pytest.mark.parametrize("deferred", (0, 4))
+def test_rgba16f_accumulation_storage(gpu, capi, oracle, rounding, deferred):
+    """The reference's accumulation STORAGE (src/DXRExperimentsApp.cpp:28 -> src/ProgressiveRaytracingPipeline.cpp:127-131; read-modify-write at
+    assets/shaders/ProgressiveRaytracing.hlsl:36-38): an RGBA16F texture, so every frame's running mean is rounded to fp16 before the next frame reads
+    it.  rt_pipeline_set_accumulation_storage(RT_FORMAT_R16G16B16A16_FLOAT) does that; 8 Cornell frames equal the oracle's twin bit for bit, frame by
+    frame and in deferred sets, and the fp16 read-out is then exact (every stored value IS an fp16 number)."""
+    W, H = 64, 64
+    v, i = oracle.obj_load(CORNELL_OBJ)
+    mat = T.default_material()
+    p = make_gpu_pipeline(capi, gpu, [(v, i)], [(0, None)], [mat], W, H)
+    ref32 = make_gpu_pipeline(capi, gpu, [(v, i)], [(0, None)], [mat], W, H)
+    p.set_accumulation_storage(T.FORMAT_R16G16B16A16_FLOAT, rounding)
+    p.set_deferred(deferred)
+    osc = make_oracle_scene(oracle, [(v, i)], [(0, None)])
+    host = capi.ProgressiveHost(5)
+    cam = cam_array(scenes.cornell_camera(), 1.0)
+    acc = np.zeros((H, W, 4), np.float32)
+    for f in range(8):
+        pfc = host.update(cam, 0.0, f + 1, W, H)
+        for q in (p, ref32):
+            q.update(pfc)
+            q.render()
+        acc, _ = osc.render(mat, pfc, W, H, accum=acc, accum_f16=1 if rounding == T.ROUND_NEAREST_EVEN else 2, nthreads=4)
+    img = p.read_output()
+    assert np.array_equal(img, acc), "%d pixels differ" % int((img != acc).any(axis=2).sum())
+    assert np.array_equal(img.astype(np.float16).astype(np.float32), img)              # every stored value is an fp16 number
+    img32 = ref32.read_output()
+    assert not np.array_equal(img, img32)
+    # what the storage format costs: RMS against the fp32 accumulation over 8 frames (half an fp16 ulp per frame at most; stated in DESIGN.md section 2)
+    assert rms(img[..., :3], img32[..., :3]) < (4e-4 if rounding == T.ROUND_NEAREST_EVEN else 2e-3)
+    # back to fp32 storage: the next frame's mean is no longer rounded
+    p.set_accumulation_storage(T.FORMAT_R32G32B32A32_FLOAT)
+    pfc = host.update(cam, 0.0, 9, W, H)
+    p.update(pfc)
+    p.render()
+    acc, _ = osc.render(mat, pfc, W, H, accum=acc, nthreads=4)
+    assert np.array_equal(p.read_output(), acc)
+    with pytest.raises(capi.RtError):
+        p.set_accumulation_storage(1234)
+
+
 def test_error_paths(gpu, capi):
     p = capi.Pipeline(gpu)
     with pytest.raises(capi.RtError):

@@ -123,7 +123,9 @@ def test_references_do_not_change_a_bit_whatever_layout_holds_them(gpu, oracle, 
         acc = np.zeros((H, W, 4), np.float32)
         for pfc in pfcs:
             acc, _ = osc.render(mat, pfc, W, H, accum=acc, env_faces=scenes.sky_cubemap(16), nthreads=cores)
-        for opts in ({}, {"split_refs": 0}, {"fast_bvh": "lbvh"}):
+        # (fail_ploc_rounds: the split-reference PLOC layout thrown away after it had re-sized the record array -- the path a mesh with
+        # non-finite boxes takes; round 6: the records are gathered again in LBVH order before the LBVH is collapsed)
+        for opts in ({}, {"split_refs": 0}, {"fast_bvh": "lbvh"}, {"fail_ploc_rounds": 1}):
             ctx = capi.Context(0)
             for k, val in opts.items():
                 ctx.set_option(k, val)
@@ -147,3 +149,36 @@ def test_references_do_not_change_a_bit_whatever_layout_holds_them(gpu, oracle, 
                 p.update(pfc)
                 p.render()
             assert np.array_equal(p.read_output(), acc), (opts, len(inst))
+
+
+def test_a_nan_vertex_among_slivers(gpu, oracle, capi):
+    """A mesh with split triangles AND a triangle with a NaN corner (which PLOC's nearest-neighbour rounds may refuse: the builder then falls
+    back to the LBVH layout, after the split-reference path had already re-sized the records): whichever layout results, hits are the oracle's."""
+    from util import sliver_soup
+    v, t = sliver_soup(400, seed=21)
+    v = v.copy()
+    v["position"][t[401, 1], 0] = np.nan          # one of the small triangles
+    cores = max(1, len(os.sched_getaffinity(0)))
+    O, D = random_rays(50000, 43, [-6, -6, -6], [6, 6, 6])
+    for opts in ({}, {"fail_ploc_rounds": 1}):
+        ctx = capi.Context(0)
+        for k, val in opts.items():
+            ctx.set_option(k, val)
+        p = Pair(oracle, capi, ctx, [(v, t)], [(0, None)])
+        assert p.o.refs(0, t.shape[0])[0] is not None
+        for flags in (0, CULL):
+            assert_hits_equal(p.g.trace(O, D, flags=flags), p.o.trace(O, D, flags=flags, mode=1, nthreads=cores), "nan + slivers %s flags=%d" % (opts, flags))
+        assert_hits_equal(p.g.trace(O, D, flags=ANY), p.o.trace(O, D, flags=ANY, mode=1, nthreads=cores), "nan + slivers any-hit", closest=False)
+        ctx.close()
+
+
+def test_debug_options_are_parsed_strictly(gpu, capi):
+    """rt_debug_set_option: a value that is not a number is an error, not a silent 0 ('lds_top=true' used to switch the LDS top off)"""
+    ctx = capi.Context(0)
+    for name, value in (("lds_top", "true"), ("split_refs", "yes"), ("leaf_max", "4x"), ("sah_node", "one"), ("verbose", "")):
+        with pytest.raises(capi.RtError):
+            ctx.set_option(name, value)
+    ctx.set_option("lds_top", 1)
+    ctx.set_option("sah_node", "1.5")
+    ctx.set_option("fast_bvh", "ploc")
+    ctx.close()

@@ -302,3 +302,25 @@ def test_structures_fixture_reproduced(oracle):
     prm = np.frombuffer(g["denoise_params"].tobytes(), oracle.DENOISE_PARAMS)[0]
     _, out = oracle.denoise(g["direct"], g["indirect"], prm)
     assert np.array_equal(out, g["denoised"])
+
+
+def test_round_to_half_is_ieee(oracle):
+    """the oracle's binary32 -> binary16 -> binary32 (the reference's RGBA16F accumulation texture, src/DXRExperimentsApp.cpp:28) against numpy's
+    float16: every half, every midpoint between two halves and its fp32 neighbours, subnormals, overflow; toward-zero: representable, never larger in
+    magnitude, and tight"""
+    r = np.random.default_rng(1)
+    h = np.arange(0, 0x7c00, dtype=np.uint16).view(np.float16).astype(np.float32)
+    mid = ((h[:-1].astype(np.float64) + h[1:].astype(np.float64)) / 2).astype(np.float32)
+    x = np.concatenate([r.uniform(-70000, 70000, 100000), r.normal(size=100000) * 1e-5, r.normal(size=100000) * 1e-7, r.normal(size=100000),
+                        [0, -0.0, 65504, 65519.99, 65520, 1e9, 5.96e-8, 2.98e-8, 2.9802322e-8, 3e-8, np.inf, -np.inf]]).astype(np.float32)
+    x = np.concatenate([x, h, mid, np.nextafter(mid, np.float32(np.inf)), np.nextafter(mid, np.float32(-np.inf)), -mid])
+    with np.errstate(over="ignore"):
+        want = x.astype(np.float16).astype(np.float32)
+    assert np.array_equal(oracle.round_to_half(x, True).view(np.uint32), want.view(np.uint32))
+    t = oracle.round_to_half(x, False)
+    fin = np.isfinite(x)
+    th = t.astype(np.float16)
+    assert np.array_equal(th.astype(np.float32)[fin], t[fin]) and (np.abs(t[fin]) <= np.abs(x[fin])).all()
+    with np.errstate(over="ignore"):
+        up = np.nextafter(np.abs(th), np.float16(np.inf)).astype(np.float32)
+    assert ((up[fin] > np.abs(x[fin])) | (np.abs(t[fin]) == 65504)).all()
