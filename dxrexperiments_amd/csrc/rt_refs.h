@@ -1,10 +1,11 @@
-// rt_refs.h -- split references (round 5): the validation boxes of long thin triangles.
+// rt_refs.h -- split references (round 5): the validation boxes of long thin triangles.  Normative text: DESIGN.md section 2.1, paragraph S2.5 (the rule)
+// and S2.4 (what a box is for); this file and oracle/oracle_bvh.h implement it operation for operation.
 //
 // A 47 m x 2 cm cable that runs diagonally through a hall has an AABB of 40 x 5 x 25 m: every ray through that box has to test the
 // triangle, and 12,000 such triangles (4 % of the stress scene, tests/test_gpu_stress_scene.py) cost three times what the other 260,000
 // cost together (profiles/r05/stress_parts.txt).  The production tree therefore holds such a triangle as SEVERAL references -- the parts of
 // it inside overlapping slabs of its longest axis, each with its own small box -- and the candidate rule of the engine
-// reads "accepted only if ONE OF THE TRIANGLE'S REFERENCE BOXES passes the slab test over [tmin, t]".  A triangle that is not split has one
+// reads "a candidate only through ONE OF THE TRIANGLE'S REFERENCE BOXES (S2.4: at t if the box passes over [tmin, t], at the box's entry if the ray only meets it later)".  A triangle that is not split has one
 // reference, its own AABB: rounds 1 - 4's rule, bit for bit, and no triangle of any earlier scene is split.  Float slab tests are monotone
 // under box inclusion, so the exactness rule stands: the canonical tree over whole triangles, the production tree over references and
 // brute force return the same bits.  The rule is DEFINED in the test oracle (oracle_bvh.h) ("Split references"); this file restates it for the

@@ -14,9 +14,10 @@
 //   - closest hit: smaller t wins, equal t -> smaller (instance, primitive);
 //   - barycentrics (u, v) weight v1, v2 (RaytracingCommon.hlsli:55).
 // Engine-defined parts (the Fallback Layer's own arithmetic is not in the
-// reference checkout): slab box test with slack 1+2^-16, Moller-Trumbore, and
-// the candidate re-validation against the triangle's own AABB / the instance's
-// world AABB that makes BVH order irrelevant to the result (DESIGN.md "Exactness").
+// reference checkout), normative text DESIGN.md section 2.1: slab box test with slack
+// 1+2^-16 (S2.2), Moller-Trumbore (S2.3), and the box clause against the triangle's own
+// AABB / reference boxes / the instance's world AABB (S2.4) that makes BVH order
+// irrelevant to the result (S2.7) and is measured against oracle/truth64.h (S2.8).
 #pragma once
 
 #include "rt_device_math.h"
@@ -83,7 +84,7 @@ RT_DEV f3 xform_dir(const float *m, f3 p)
 }
 
 // S2-RULE-BEGIN (tests/test_s2_truth.py hashes the code between the marks: a change here needs new bounds in tests/golden/s2_bounds.json)
-// The candidate rule's box clause (defined in the test oracle's box_clause, oracle_bvh.h).  Moller-Trumbore said the
+// The candidate rule's box clause (the oracle's box_clause in oracle_bvh.h is its twin).  Moller-Trumbore said the
 // ray meets the triangle at tt; the box holds (a part of) the triangle.  Passing over [tmin, tt]: the candidate stands at tt.  Failing that but
 // meeting the box inside (tmin, tmax) -- on a sliver the fp32 tt can lie a little before the ray enters the box -- it stands at the entry
 // distance (round 6; rounds 1 - 5 rejected it and the ray went through the triangle).  Either way every traversal that still looks for hits at

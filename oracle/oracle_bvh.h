@@ -17,24 +17,25 @@
  * u32 indices, one geometry per BLAS, OPAQUE) and TopLevelASGenerator.cpp:
  * 344-362 (instance = 3x4 row-major object-to-world, mask 0xFF, flags NONE).
  *
- * Definition summary (DESIGN.md has the long form):
+ * Definition summary -- the normative text is DESIGN.md section 2.1, paragraphs S2.1 - S2.8, cited below by number:
  *   BLAS/TLAS   LBVH: 30-bit Morton code of the primitive-AABB centre in the
  *               structure's AABB, key = morton<<32 | index, ascending sort,
  *               Karras-2012 radix tree, bottom-up exact min/max refit.
- *   ray/box     slab test with precomputed 1/d, min/max ignoring NaN,
- *               hit iff max(lo, tmin) <= min(hi, tcur) * (1 + 2^-16).
- *   ray/tri     Moller-Trumbore, u,v for v1,v2 (RaytracingCommon.hlsli:55),
+ *   ray/box     S2.2: slab test with precomputed 1/d, min/max ignoring NaN,
+ *               passes iff max(lo, tmin) <= min(hi, tcur) * (1 + 2^-16).
+ *   ray/tri     S2.3: Moller-Trumbore, u,v for v1,v2 (RaytracingCommon.hlsli:55),
  *               front face  <=>  det > 0  (clockwise from the origin in a
  *               left-handed frame, DXR spec), TMin < t < TMax exclusive.
- *   candidate   accepted only if its own AABB -- for a triangle the builder holds as
- *               several references (round 5, "Split references" below): one of
- *               its reference boxes -- (and, for a transformed
- *               instance, the instance's world AABB: the exact box of its
- *               triangles' transformed vertices) passes the slab test
- *               over [tmin, t]: this makes BVH traversal and the brute-force
- *               loop agree exactly, because float slab tests are monotone
- *               under box inclusion.
- *   closest     smaller t wins; equal t -> smaller (instance, primitive).
+ *   candidate   S2.4 (box clause): through a box that holds the triangle -- its AABB, or one of
+ *               the reference boxes of a triangle held as several references (S2.5) -- and, for a
+ *               transformed instance, through the instance's world AABB: the box passing over
+ *               [tmin, t] leaves the candidate at t; failing that but meeting the ray inside
+ *               (tmin, tmax) moves it to the box's entry distance (round 6; rounds 1 - 5 dropped
+ *               it).  Slab tests are monotone under box inclusion and in their upper limit, so
+ *               BVH traversal and the brute-force loop agree exactly (S2.7).
+ *   closest     S2.6: smaller t wins; equal t -> smaller (instance, primitive).
+ *   truth       S2.8: oracle/truth64.h (float64, no boxes) is what this definition is MEASURED against
+ *               (tests/test_s2_truth.py, tests/golden/s2_bounds.json).
  */
 #ifndef ORACLE_BVH_H
 #define ORACLE_BVH_H
@@ -230,7 +231,7 @@ static inline Box tri_box(V3 a, V3 b, V3 c)
 }
 
 /*
- * Split references (round 5).  A long thin triangle that runs diagonally through space has an AABB hundreds of times the size it needs
+ * Split references (round 5; DESIGN.md section 2.1, S2.5).  A long thin triangle that runs diagonally through space has an AABB hundreds of times the size it needs
  * (a 47 m x 2 cm cable: AABB 40 x 5 x 25 m): every ray through that box has to test it.  The production tree therefore holds such a
  * triangle as SEVERAL references, each with the box of the part of the triangle inside one slab of its longest axis, and the candidate
  * rule becomes "accepted only if ONE OF THE TRIANGLE'S REFERENCE BOXES passes the slab test over [tmin, t]" -- for a triangle that is not
@@ -479,7 +480,7 @@ static inline bool slab_box(const RayInv &r, const Box &b, float t0, float t1)
 }
 
 /*
- * The candidate rule's box clause (paragraph S2.4).  Moller-Trumbore said the ray meets the triangle at tt; `b` is a
+ * The candidate rule's box clause (paragraph S2.4; why trees cannot matter: S2.7).  Moller-Trumbore said the ray meets the triangle at tt; `b` is a
  * box that contains (a part of) the triangle.  Float slab tests are monotone under box inclusion and in their upper limit, so a candidate
  * whose box passes over [tmin, tt] is reached by every traversal that still looks for hits at tt or beyond: it stands at tt.  On a sliver
  * the fp32 tt can lie a little BEFORE the ray even enters the box the triangle is in (1000:1 slivers: tt is good to a per mille or so;
