@@ -451,7 +451,11 @@ struct ShadowSrcN : ShadowQueue {
 };
 struct ShadowSinkN {      // ShadowMiss sets visibility 1 (ProgressiveRaytracing.hlsl:178-182)
     ShadowQueue s;
-    RT_DEV void store(uint32_t ticket, const HitD &h, bool) const { if (ticket != RT_NO_HIT) s.vis[ticket] = h.inst == RT_NO_HIT ? 1u : 0u; }
+    // Round 6: ONE BIT per shadow ray (bit ticket & 31 of word ticket >> 5, cleared before the launch), set by a no-return atomic when the ray
+    // reaches its light.  A 4-byte store per ray cost 22 B of HBM writes per ray (scattered partial lines: 4.4 GB per 20-frame launch,
+    // profiles/r05/c2s_write.md) to deliver that bit.  The 32 tickets of a word are consecutive rays of one (level, light) run and such runs
+    // start at multiples of 64, so the word belongs to ONE chunk of the queue = one wave = one XCD's L2: no two L2s ever update the same word.
+    RT_DEV void store(uint32_t ticket, const HitD &h, bool) const { if (ticket != RT_NO_HIT && h.inst == RT_NO_HIT) atomicOr(&s.vis[ticket >> 5], 1u << (ticket & 31u)); }
 };
 
 template <int STACK, bool TWO_LEVEL, bool BATCH>
@@ -761,6 +765,7 @@ int launch_frame(rt_pipeline *p, PipeDev &pd, uint32_t shadow_slots, bool counte
         sq.cache.frames_magic = (uint32_t)(0x100000000ull / (pd.n_frames ? pd.n_frames : 1u)) + 1u;
         if (sq.cache.px_slots > pd.fcap) sq.cache.px_slots = pd.fcap;
         const size_t rays_max = sh_total << pd.sh_log2;
+        HIP_TRY(hipMemsetAsync(pd.sh_vis, 0, ((rays_max + 31) / 32) * 4, st));      // the visibility bits: set by the rays that reach their light
         if (B) k_trace_shadow<STACK, TWO_LEVEL, true><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL, true>, PBLOCK, rays_max), PBLOCK, 0, st>>>(
             pd.sc, sq, pd.pools, &pd.counters[C_SHADOW]);
         else k_trace_shadow<STACK, TWO_LEVEL, false><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL, false>, PBLOCK, rays_max), PBLOCK, 0, st>>>(

@@ -157,6 +157,11 @@ RT_DEV size_t sh_ray(const PipeDev &pd, int L, uint32_t idx, uint32_t s)
 {
     return ((size_t)pd.sh_cbase[L] << pd.sh_log2) + (size_t)s * pd.lv[L].hstride + idx;
 }
+// the any-hit launch's answer for shadow ray number n (ShadowSinkN): bit n & 31 of word n >> 5, 1 = the ray reached its light
+RT_DEV uint32_t shadow_bit(const PipeDev &pd, size_t n)
+{
+    return (pd.sh_vis[n >> 5] >> (uint32_t)(n & 31u)) & 1u;
+}
 
 inline unsigned blocks(size_t n) { return (unsigned)((n + PBLOCK - 1) / PBLOCK); }
 

@@ -34,7 +34,7 @@ inline LightRays no_light_rays()
 // ---- queue memory ------------------------------------------------------------------------------------------------------
 // Level l keeps, per RAY slot (l = 0: per pixel slot; no ray is stored there), the ray (32 B + 4 B pixel slot), its hit record
 // (16 + 4 B) and the two compaction maps (4 + 4 B); per HIT of the level its shadow rays -- compact form: ONE float4 per hit +
-// 4 B of visibility per shadow ray; explicit form (the ambient-occlusion view): 36 B per shadow ray; all levels in ONE queue -- and, for paths of more
+// one BIT of visibility per shadow ray (round 6; 4 B until then); explicit form (the ambient-occlusion view): 32 B + a bit per shadow ray; all levels in ONE queue -- and, for paths of more
 // than one bounce, 16 B of colour per ray slot.  How many slots a level needs is only known once the level before has been
 // compacted: the worst case is 2 rays per pixel at level 1 and as many rays as slots at every deeper level, 228 B per pixel and
 // frame for the reference's depth limits and 884 B with four bounces -- times up to 32 frames per set of launches.  So:
@@ -84,12 +84,12 @@ inline int reserve_shadows(rt_pipeline *p, size_t hits, uint32_t log2, bool comp
     hipStream_t st = p->ctx->stream;
     if (compact) RT_TRY(grow_keep(p->sh_hits, hits * 16, keep_hits * 16, st));
     else { RT_TRY(grow_keep(p->sh_O, (hits << log2) * 16, (keep_hits << log2) * 16, st)); RT_TRY(grow_keep(p->sh_D, (hits << log2) * 16, (keep_hits << log2) * 16, st)); }
-    return grow_keep(p->sh_vis, (hits << log2) * 4, 0, st);         // (results: nothing is in there before the shadow launch)
+    return grow_keep(p->sh_vis, (((hits << log2) + 31) / 32) * 4 + 64, 0, st);         // (results, one bit per ray: nothing is in there before the shadow launch)
 }
 // levels 0 .. n - 1 cast shadow rays: level 0 always has its entries (their masks are empty when no shadow ray is allowed at all)
 inline uint32_t shadow_levels(uint32_t levels, uint32_t max_shadow) { return 1u + (max_shadow > 1u ? (levels < max_shadow - 1u ? levels : max_shadow - 1u) : 0u); }
 inline size_t level_ray_bytes(uint32_t l, bool deep) { return (l > 0 ? 36u : 0u) + 28u + (l > 0 && deep ? 16u : 0u); }
-inline size_t level_shadow_bytes(uint32_t shadow_slots, bool compact) { return compact ? 16u + 4u * shadow_slots : 36u * shadow_slots; }
+inline size_t level_shadow_bytes(uint32_t shadow_slots, bool compact) { return (compact ? 16u : 32u * shadow_slots) + 1u; }      // (+ one bit of visibility per ray: a byte per hit at most)
 inline size_t worst_case_queue_bytes(size_t cap, uint32_t levels, uint32_t max_shadow, uint32_t shadow_slots0, bool compact)
 {
     const bool deep = levels > 1;

@@ -437,7 +437,7 @@ struct ResolveIO {
     {
         if (depth >= pd.max_shadow) return 1.0f;
         if (!matters && pd.skip_unlit) return 1.0f;                       // never traced; the caller multiplies by zero
-        return pd.sh_vis[sh_ray(pd, L, idx, (uint32_t)s)] ? 1.0f : 0.0f;
+        return shadow_bit(pd, sh_ray(pd, L, idx, (uint32_t)s)) ? 1.0f : 0.0f;
     }
     RT_DEV f3 secondary(int w, f3 o, f3 d, float tmin, uint32_t depth)
     {
@@ -472,7 +472,7 @@ struct LevelResolveIO {
     {
         if (depth >= pd.max_shadow) return 1.0f;
         if (!matters && pd.skip_unlit) return 1.0f;
-        return pd.sh_vis[sh_ray(pd, L, idx, (uint32_t)s)] ? 1.0f : 0.0f;
+        return shadow_bit(pd, sh_ray(pd, L, idx, (uint32_t)s)) ? 1.0f : 0.0f;
     }
     RT_DEV f3 secondary(int w, f3, f3 d, float, uint32_t depth)
     {
