@@ -150,6 +150,7 @@ SIGNATURES = {
     "rt_scene_refs_read": (_i, [_p, _i, _p, _p, _p]),
     "rt_debug_set_alloc_limit": (_i, [_sz]),
     "rt_debug_set_option": (_i, [_p, C.c_char_p, C.c_char_p]),
+    "rt_debug_repack_stats": (_i, [_p, _p]),
     "rt_debug_read_secondary_ray": (_i, [_p, _u32, _p, _p]),
     "rt_camera_look": (_i, [_p, _p, _p, _p, _p]),
     "rt_camera_basis": (_i, [_p, _p, _f, _f, _p, _p, _p]),
@@ -254,6 +255,13 @@ class Context:
     def set_option(self, name, value):
         """rt_debug_set_option: the context's experiment / test knobs (include/dxr_amd.h lists them)"""
         _check(lib().rt_debug_set_option(self.h, str(name).encode(), str(value).encode()))
+
+    def repack_stats(self):
+        """rt_debug_repack_stats: the re-packed engine's tallies since the last call (option repack=1)"""
+        out = (C.c_ulonglong * 8)()
+        _check(lib().rt_debug_repack_stats(self.h, out))
+        names = ("node_steps", "node_step_lanes", "leaf_passes", "leaf_pass_lanes", "rays_to_leaf_queue", "rays_to_node_queue", "refills", "watchdog_aborts")
+        return dict(zip(names, [int(x) for x in out]))
 
     def stack_memory(self):
         """bytes of the traversal kernels' global stack rows held by the context"""

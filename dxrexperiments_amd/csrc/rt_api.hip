@@ -138,11 +138,27 @@ extern "C" int rt_debug_set_option(rt_context *c, const char *name, const char *
     else if (n == "free_radius") c->opt_free_radius = iv != 0;
     else if (n == "split_refs") c->opt_split_refs = iv != 0;
     else if (n == "fail_ploc_rounds") c->opt_fail_ploc_rounds = iv != 0;
+    else if (n == "repack") c->opt_repack = iv != 0;
     else if (n == "primary_retry_cap") { if (iv < 0 || iv > (1 << 24)) return bad(); c->opt_primary_retry_cap = (uint32_t)iv; }
     else if (n == "batch_max") { if (iv < 0 || iv > 32) return bad(); c->opt_batch_max = (uint32_t)iv; }
     else if (n == "queue_budget_mb") { if (iv < 0) return bad(); c->opt_queue_budget_mb = (size_t)iv; }
     else if (n == "dist_check_seconds") { if (!(fv >= 0.0)) return bad(); c->opt_dist_check_seconds = fv; }
     else { rt_set_error("rt_debug_set_option: unknown option '%s'", name); return RT_ERR_INVALID_ARG; }
+    return RT_OK;
+}
+
+// the re-packed engine's tallies since they were last read (rt_trace_repack.h: node steps, lanes in them, leaf passes, lanes in them, rays through
+// the leaf queue, through the node queue, refills, watchdog aborts); synchronises
+extern "C" int rt_debug_repack_stats(rt_context *c, unsigned long long out[8])
+{
+    RT_REQUIRE(c && out, "null argument");
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    if (!c->rp_records.p || !c->rp_grid) return RT_OK;
+    char *at = (char *)c->rp_records.p + (size_t)c->rp_grid * 256 * 64;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(out, at, 64, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(at, 0, 64, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 
@@ -244,6 +260,7 @@ void rt_context_release(rt_context *ctx)
     for (DevBuf &b : ctx->scratch) b.release();
     ctx->pool.release();
     ctx->deep_stack.release();
+    ctx->rp_records.release();
     ctx->build_arena.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

@@ -217,6 +217,9 @@ struct rt_context {
     bool opt_seven_waves_always = false;    // seven_waves_always=1: single frames on the sets' kernels
     bool opt_free_radius = true;            // free_radius=0: no free sphere around the point light
     uint32_t opt_batch_max = 0;             // batch_max: frames per set of launches (0: RT_MAX_BATCH)
+    bool opt_repack = false;                // repack=1 (round 6, rt_trace_repack.h): the shadow stage of single-level scenes on the re-packed engine
+    unsigned rp_grid = 0;                   // ... the grid they were sized for
+    DevBuf rp_records;                      // ... and its slot records (64 B x 256 slots per resident workgroup)
     bool opt_fail_ploc_rounds = false;      // fail_ploc_rounds=1 (tests): the PLOC layout is thrown away as if its rounds had made no progress (non-finite boxes): the LBVH fallback
     bool opt_split_refs = true;             // split_refs=0: no triangle is held as several references (the builder of rounds 1 - 4; the CANDIDATE RULE still
                                             //   follows rt_refs.h -- results do not depend on this option)

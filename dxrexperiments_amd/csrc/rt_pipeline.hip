@@ -35,6 +35,7 @@
 #include <utility>
 
 #include "rt_shade.h"
+#include "rt_trace_repack.h"
 #include "rt_pipeline_queues.h"
 
 using namespace rtd;
@@ -468,6 +469,20 @@ __global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_trace_shadow(SceneDe
     trace_wave<RT_ROWS(STACK), PBLOCK, TWO_LEVEL, (!TWO_LEVEL && RT_ROWS(STACK) == RT_LDS_STACK_ROWS_SETS) ? RT_POOL_CHUNK_SETS : RT_POOL_CHUNK, RT_SHADOW_UNORDERED != 0, false, false, RT_REFS(STACK)>(sc, src, sink, pool, smem, stat);
 }
 
+// the shadow stage on the re-packed engine (rt_trace_repack.h; single-level scenes, option repack=1): one stack row less than the launch
+// it replaces, so that the rings fit the same LDS budget
+template <int STACK, bool BATCH>
+__global__ void __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(RT_ROWS(STACK) == RT_LDS_STACK_ROWS_SETS ? 7 : RT_ROWS(STACK) == RT_LDS_STACK_ROWS ? 6 : 1)))
+k_trace_shadow_rp(SceneDev sc, ShadowQueue queues, uint32_t *pool, uint32_t *stat, char *records)
+{
+    constexpr int ROWS = RT_ROWS(STACK) - 1;
+    __shared__ int smem[(ROWS + RT_TOP_ROWS(PBLOCK)) * PBLOCK + RT_RP_LDS_EXTRA_INTS];
+    ShadowSrcN<BATCH> src;
+    static_cast<ShadowQueue &>(src) = queues;
+    ShadowSinkN sink = {queues};
+    trace_wave_repack<ROWS, PBLOCK, RT_ROWS(STACK) == RT_LDS_STACK_ROWS_SETS ? RT_POOL_CHUNK_SETS : RT_POOL_CHUNK, RT_REFS(STACK)>(sc, src, sink, pool, smem, stat, records);
+}
+
 template <int STACK, bool TWO_LEVEL>
 __global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_trace_secondary(SceneDev sc, QueueSrc src, float4 *hit1, uint32_t *inst1, uint32_t *pool, uint32_t *stat)
 {
@@ -766,6 +781,19 @@ int launch_frame(rt_pipeline *p, PipeDev &pd, uint32_t shadow_slots, bool counte
         if (sq.cache.px_slots > pd.fcap) sq.cache.px_slots = pd.fcap;
         const size_t rays_max = sh_total << pd.sh_log2;
         HIP_TRY(hipMemsetAsync(pd.sh_vis, 0, ((rays_max + 31) / 32) * 4, st));      // the visibility bits: set by the rays that reach their light
+        if (!TWO_LEVEL && ctx->opt_repack && RT_ROWS(STACK) != RT_LDS_STACK_ROWS_TEST) {
+            if constexpr (!TWO_LEVEL && RT_ROWS(STACK) != RT_LDS_STACK_ROWS_TEST) {
+                const unsigned grid = B ? rt_persistent_grid(ctx, k_trace_shadow_rp<STACK, true>, PBLOCK, rays_max) : rt_persistent_grid(ctx, k_trace_shadow_rp<STACK, false>, PBLOCK, rays_max);
+                // (+ 64 B of tallies behind the records: rt_debug_repack_stats; a launch with another grid moves them, so they are cleared then)
+                if (ctx->rp_grid != grid) {
+                    RT_TRY(ctx->rp_records.reserve((size_t)grid * PBLOCK * RT_RP_SLOT_BYTES + 64));
+                    HIP_TRY(hipMemsetAsync((char *)ctx->rp_records.p + (size_t)grid * PBLOCK * RT_RP_SLOT_BYTES, 0, 64, st));
+                    ctx->rp_grid = grid;
+                }
+                if (B) k_trace_shadow_rp<STACK, true><<<grid, PBLOCK, 0, st>>>(pd.sc, sq, pd.pools, &pd.counters[C_SHADOW], (char *)ctx->rp_records.p);
+                else k_trace_shadow_rp<STACK, false><<<grid, PBLOCK, 0, st>>>(pd.sc, sq, pd.pools, &pd.counters[C_SHADOW], (char *)ctx->rp_records.p);
+            }
+        } else
         if (B) k_trace_shadow<STACK, TWO_LEVEL, true><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL, true>, PBLOCK, rays_max), PBLOCK, 0, st>>>(
             pd.sc, sq, pd.pools, &pd.counters[C_SHADOW]);
         else k_trace_shadow<STACK, TWO_LEVEL, false><<<rt_persistent_grid(ctx, k_trace_shadow<STACK, TWO_LEVEL, false>, PBLOCK, rays_max), PBLOCK, 0, st>>>(

@@ -88,6 +88,9 @@ RT_DEV v4f ldg16(const void *base, size_t byte_off)
 #ifndef RT_POOL_XCD
 #define RT_POOL_XCD 1                   // any-hit launches: every XCD works through one contiguous eighth of the queue (then helps its neighbours)
 #endif
+#ifndef RT_REFILL_TESTS
+#define RT_REFILL_TESTS 1               // (round 6) a new shadow ray's cached candidate is tested at the refill, and the refill repeats until the wave is full
+#endif
 #ifndef RT_EXIT_K
 #define RT_EXIT_K 1                     // leave the node loop once (lanes still on internal nodes) * K < lanes waiting on a leaf
                                         //   (four-wide nodes, ms per frame 1080p / 10 M triangles 4K: K = 0 3.31 / 21.9, 1 2.80 / 15.5, 2 2.86 / 16.5, 3 2.88 / 16.9)
@@ -221,9 +224,16 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
     for (;;) {
         // ---- refill idle lanes: the wave owns a chunk [chunk_next, chunk_end) of the ray pool and
         //      only goes to the global counter (one atomic, lane 0) when the chunk is used up ----
-        const unsigned long long idle = __ballot(!alive);
-        const int n_idle = __popcll(idle);
-        if (!exhausted && n_idle >= RT_REFILL_LANES) {
+        // (round 6) REFILL_TESTS: any-hit walks of single-level scenes whose source keeps first candidates (the pipeline's shadow cache) test a new
+        // ray's candidate RIGHT HERE -- every lane of the refill has one, so the triangle test runs with the whole refill live -- and a ray it occludes
+        // never takes the lane: the refill goes round again until the wave is full (or the pool dry).  Until round 5 the candidate went in front of
+        // the root as a one-triangle leaf: its lane sat through the wave's next node loop doing nothing, was tested in the leaf phase, and most of
+        // the time (a cached occluder usually still occludes) ended there -- node steps of the shadow stage ran with 0.4 - 0.5 of their lanes by
+        // the hardware's count (profiles/r05/c2s_lanes.md) against 0.66 in the walk without the cache.
+        constexpr bool REFILL_TESTS = src_has_cache<Src>::value && ANYHIT && !COUNT && !TWO_LEVEL && RT_REFILL_TESTS;
+        unsigned long long idle = __ballot(!alive);
+        int n_idle = __popcll(idle);
+        for (int refill_round = 0; !exhausted && n_idle >= RT_REFILL_LANES && (refill_round == 0 || REFILL_TESTS); refill_round++) {
 #if RT_REFILL_PRIO
             __builtin_amdgcn_s_setprio(RT_REFILL_PRIO);
 #endif
@@ -287,6 +297,22 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     node = root0;
                     sp = 0;
                     if (TWO_LEVEL) { nodes = sc.tlas_wide; in_blas = false; top_lim = sc.top_n; }
+                    bool occluded_at_once = false;
+                    if constexpr (REFILL_TESTS) {
+                        uint32_t slot, ci;
+                        const uint32_t ct = src.template cached_leaf<false>(idx, r, slot, ci);
+                        st.lds[(STACK - 1) * BLOCK] = (int)slot;
+                        if (ct != RT_NO_HIT) {
+                            const char *tp = (const char *)(tris0 + ct);
+                            const v4f a = ldg16(tp, 0), b = ldg16(tp, 16), c = ldg16(tp, 32);
+                            HitD found = best;
+                            if (accept_candidate<REFS ? 1 : 0>(*in0, 0u, __float_as_uint(c.y), mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), r, wri, cur, cull, found,
+                                                               REFS ? __float_as_uint(c.z) : 0u, ct)) {
+                                sink.store(idx, found, true);
+                                occluded_at_once = true;
+                            }
+                        }
+                    } else
                     if constexpr (src_has_cache<Src>::value && ANYHIT && !COUNT) {
                         // the triangle that answered this question last time goes first: a one-triangle leaf in front of the root
                         uint32_t slot, ci;
@@ -311,7 +337,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                             node = ~(int)(ct << 3);
                         }
                     }
-                    alive = true;
+                    alive = !occluded_at_once;
                     started = true;
                     if (COUNT) wk_ray0 = wk_glob + wk_top;
                 } else {
@@ -325,6 +351,8 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
 #if RT_REFILL_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
+            idle = __ballot(!alive);
+            n_idle = __popcll(idle);
         }
         if (__ballot(alive) == 0ull) {
             if (exhausted) break;

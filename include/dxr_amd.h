@@ -433,11 +433,16 @@ int rt_debug_read_secondary_ray(rt_pipeline *p, uint32_t index, float origin_tmi
  *                            depend on it: the candidate rule follows the references either way
  *   fail_ploc_rounds=0|1     (tests) the PLOC layout of every build is thrown away as if its rounds had made no progress (what non-finite boxes
  *                            cause): the LBVH is collapsed instead
+ *   repack=0|1               the shadow stage of single-level scenes on the re-packed engine (rt_debug_repack_stats; 0)
  *   primary_retry_cap=n      entries of the retry list behind the one-tile-per-wave primary launch (0: 2^20; tests make it overflow)
  *   queue_budget_mb=n        worst-case queue bytes a set may reserve up front (0: a quarter of the device's memory)
  *   dist_check_seconds=x     how long rt_dist_create waits for the other ranks' device ids (5)
  * Every value but fast_bvh's must be a number in full ("true", "4x", "" are RT_ERR_INVALID_ARG, not 0); RT_DEBUG_OPTIONS items must be name=value. */
 int rt_debug_set_option(rt_context *ctx, const char *name, const char *value);
+/* option repack=1 (round 6, csrc/rt_trace_repack.h; measured slower, off by default: profiles/r06/repack.txt): the shadow stage of single-level scenes on the
+ * engine whose rays change lanes at every phase switch.  Its tallies since the last call: node steps issued, lanes live in them, leaf passes, lanes live in them,
+ * rays through the leaf queue, rays through the node queue, refills, watchdog aborts (must be 0).  Synchronises the context. */
+int rt_debug_repack_stats(rt_context *ctx, unsigned long long out[8]);
 /* test hook: device allocations of more than `bytes` bytes fail with RT_ERR_OOM as if the device were full (0: no limit) */
 int rt_debug_set_alloc_limit(size_t bytes);
 int rt_debug_sample_cube(rt_context *ctx, const float *faces_rgba32f, uint32_t size, uint32_t filter, const float *dirs, float *out, size_t n);

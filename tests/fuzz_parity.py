@@ -113,6 +113,11 @@ def run(iters, seed, ctx, verbose=True):
         cam = cam_array(dict(eye=tuple(eye), at=tuple(r.uniform(-1, 1, 3)), up=(0, 1, 0), fov=float(r.uniform(0.4, 1.2))), W / H)
         omats = np.stack(mats)
         acc = np.zeros((H, W, 4), np.float32)
+        # (round 6) the reference's accumulation storage for a fifth of the progressive draws: the running mean rounded to fp16 every frame
+        f16 = 0 if realtime or r.random() >= 0.2 else int(r.integers(1, 3))
+        if f16:
+            p.set_accumulation_storage(T.FORMAT_R16G16B16A16_FLOAT, T.ROUND_NEAREST_EVEN if f16 == 1 else T.ROUND_TOWARD_ZERO)
+        desc["accum_f16"] = f16
         for f in range(2):
             pfc = host.update_realtime(cam, 0.0, f + 1, W, H) if realtime else host.update(cam, 0.0, f + 1, W, H)
             if f == 0 or moving:
@@ -125,7 +130,7 @@ def run(iters, seed, ctx, verbose=True):
                 d, ind, ost = osc.render_realtime(omats, pfc, W, H, env_faces=env, max_radiance_depth=depth[0], max_shadow_depth=depth[1], nthreads=8)
                 ok = np.array_equal(p.read_output(0), d) and np.array_equal(p.read_output(1), ind)
             else:
-                acc, ost = osc.render(omats, pfc, W, H, accum=acc, env_faces=env, max_radiance_depth=depth[0], max_shadow_depth=depth[1], nthreads=8)
+                acc, ost = osc.render(omats, pfc, W, H, accum=acc, env_faces=env, max_radiance_depth=depth[0], max_shadow_depth=depth[1], nthreads=8, accum_f16=f16)
                 ok = np.array_equal(p.read_output(), acc)
             gst = p.stats()
             same = all(gst[k] == ost[k] for k in ("rays_primary", "rays_secondary", "rays_shadow", "primary_hits", "secondary_hits"))
@@ -158,7 +163,7 @@ def run(iters, seed, ctx, verbose=True):
                     p.update(pfc)
                     p.render()
             for pfc in more:
-                acc, ost = osc.render(omats, pfc, W, H, accum=acc, env_faces=env, max_radiance_depth=depth[0], max_shadow_depth=depth[1], nthreads=8)
+                acc, ost = osc.render(omats, pfc, W, H, accum=acc, env_faces=env, max_radiance_depth=depth[0], max_shadow_depth=depth[1], nthreads=8, accum_f16=f16)
             if not np.array_equal(p.read_output(), acc):
                 oracle.set_cube_seamless(True)
                 return "MISMATCH %r after a batch of %d frames" % (desc, len(more))
