@@ -29,13 +29,15 @@ def scene_models(name):
         v, t = scenes.stadium_class(seed=5, parts=("hall", "cables", "slats"))
         vh, th = scenes.stadium_class(seed=5, parts=("hall",))
         return [(v, t)], [(0, None)], np.arange(len(th), len(t))
+    if name == "terrain":                        # C5's kind of mesh in small: a displaced grid (20 k triangles; the bench's has 10 M)
+        return [scenes.displaced_grid(100, seed=7)], [(0, None)], None
     if name == "sliver_soup":
         v, t = sliver_soup(600, seed=77)
         return [(v, t)], [(0, None)], np.arange(600)
     raise KeyError(name)
 
 
-SCENES = ("cornell", "atrium", "instances", "stadium_slivers", "sliver_soup")
+SCENES = ("cornell", "atrium", "instances", "terrain", "stadium_slivers", "sliver_soup")
 
 
 def load_arrays(orc, models):

@@ -59,8 +59,9 @@ def test_oracle_trace_ray_against_the_geometric_truth(oracle, name):
             assert c["lost"] <= b["lost"] and c["phantom"] <= b["phantom"], (name, sname, mode, c, b)
             # ... and no leakier than the rule ever was: whole-AABB validation (rounds 1 - 4), reference boxes over [tmin, t] (round 5)
             for earlier in ("rounds_1_4", "round_5"):
-                e = BOUNDS["earlier_rules"][earlier][name][sname][mode]
-                assert c["lost"] <= e["lost"], (name, sname, mode, earlier, c, e)
+                e = BOUNDS["earlier_rules"][earlier].get(name)          # (scenes added after the earlier rules were measured have no entry)
+                if e is not None:
+                    assert c["lost"] <= e[sname][mode]["lost"], (name, sname, mode, earlier, c, e[sname][mode])
     # brute force over the engine's own rule says the same as its traversal (the exactness argument of DESIGN.md section 2 on these very rays)
     O, D, _ = sets["aimed"]
     a, b = sc.trace(O[:4000], D[:4000], 0, mode=0, nthreads=CORES), sc.trace(O[:4000], D[:4000], 0, mode=1, nthreads=CORES)
