@@ -2,6 +2,7 @@
 // Python test can compare it with the committed golden frames (tests/golden/cornell64_golden.npz).
 //   test_wrapper <cornell.obj> <out.f32>
 #include <cstdio>
+#include <cstdint>
 #include <cstring>
 #include <vector>
 
@@ -86,6 +87,36 @@ int main(int argc, char **argv)
             std::vector<float> again(image.size());
             batched->readOutput(again.data(), again.size() * 4);
             if (std::memcmp(again.data(), image.data(), image.size() * 4) != 0) return 13;
+        }
+        // the reference's accumulation storage (an RGBA16F texture read-modify-written every frame, src/DXRExperimentsApp.cpp:28): the mirror's
+        // setAccumulationStorage rounds the running mean to fp16 every frame -- every stored value is then an fp16 number, and the image differs
+        // from the fp32 accumulation by rounding only
+        {
+            auto half = ProgressiveRaytracingPipeline::create(context, 1234);
+            half->setDeferredFrames(0);
+            half->setScene(scene);
+            half->addMaterial(material);
+            half->setCamera(camera);
+            half->loadResources(3);
+            half->createOutputResource(RT_FORMAT_R32G32B32A32_FLOAT, W, H);
+            half->buildAccelerationStructures();
+            half->setAccumulationStorage(RT_FORMAT_R16G16B16A16_FLOAT);
+            for (UINT frame = 1; frame <= 4; ++frame) {
+                half->update(0.0f, frame, 0, 0, W, H);
+                half->render(0, W, H);
+            }
+            std::vector<float> h16(image.size());
+            half->readOutput(h16.data(), h16.size() * 4);
+            bool differs = false;
+            for (size_t k = 0; k < h16.size(); k++) {
+                uint32_t u;
+                std::memcpy(&u, &h16[k], 4);
+                if ((u & 0x1FFFu) != 0 && h16[k] >= 6.103515625e-05f) return 18;      // a normal fp16 number has 13 zero mantissa bits in fp32
+                const float d = h16[k] - image[k];
+                if (d != 0.0f) differs = true;
+                if (d > 2e-3f * (image[k] > 1.0f ? image[k] : 1.0f) || -d > 2e-3f * (image[k] > 1.0f ? image[k] : 1.0f)) return 19;
+            }
+            if (!differs) return 20;
         }
         // error behaviour: a missing model falls back to the reference's single triangle, bad programs throw
         auto fallback = RtModel::create(context, "/nonexistent.obj");
