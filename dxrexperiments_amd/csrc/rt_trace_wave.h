@@ -88,6 +88,21 @@ RT_DEV v4f ldg16(const void *base, size_t byte_off)
 #ifndef RT_POOL_XCD
 #define RT_POOL_XCD 1                   // any-hit launches: every XCD works through one contiguous eighth of the queue (then helps its neighbours)
 #endif
+#ifndef RT_REFILL_RAYS_PER_PASS
+#define RT_REFILL_RAYS_PER_PASS 28u     // "loading rays is the work": the wave has loaded more rays than this per pass of its outer loop (refill, node loop, leaf phase)
+#endif
+#ifndef RT_REFILL_ENTER_TESTS
+#define RT_REFILL_ENTER_TESTS 32        // single frames (64-ray chunks)
+#endif
+#ifndef RT_REFILL_STOP_TESTS
+#define RT_REFILL_STOP_TESTS 32
+#endif
+#ifndef RT_REFILL_ENTER_TESTS_SETS
+#define RT_REFILL_ENTER_TESTS_SETS 40   // sets of frames (128-ray chunks)
+#endif
+#ifndef RT_REFILL_STOP_TESTS_SETS
+#define RT_REFILL_STOP_TESTS_SETS 24
+#endif
 #ifndef RT_REFILL_TESTS
 #define RT_REFILL_TESTS 1               // (round 6) a new shadow ray's cached candidate is tested at the refill, and the refill repeats until the wave is full
 #endif
@@ -159,6 +174,7 @@ template <int STACK, int BLOCK, bool TWO_LEVEL, uint32_t CHUNK, bool ANYHIT = fa
 RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uint32_t *pool, int *smem, uint32_t *traced_counter,
                        unsigned long long *walk = nullptr)
 {
+    uint32_t rf_loaded = 0, rf_passes = 0;      // (REFILL_TESTS; both only ever changed where the whole wave runs: wave-uniform) rays this wave loaded / passes of its outer loop
     uint32_t n_traced = 0;           // rays this WAVE actually traversed (statistics; wave-uniform: a scalar register, not a lane's)
     uint32_t n_skipped = 0;          // any-hit launches: queue slots marked RT_TMAX_SKIPPED (likewise)
     uint32_t wk_glob = 0, wk_top = 0, wk_tri = 0, wk_inst = 0, wk_lines = 0;
@@ -233,7 +249,19 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
         constexpr bool REFILL_TESTS = src_has_cache<Src>::value && ANYHIT && !COUNT && !TWO_LEVEL && RT_REFILL_TESTS;
         unsigned long long idle = __ballot(!alive);
         int n_idle = __popcll(idle);
-        for (int refill_round = 0; !exhausted && n_idle >= RT_REFILL_LANES && (refill_round == 0 || REFILL_TESTS); refill_round++) {
+        // (round 6) A refill pass of a walk that tests candidates is ~500 instructions (ray, light ray, 1 / d, cache cell, candidate: half of the any-hit stage's
+        // instructions on the bench scene, where a shadow ray takes 3.7 node steps on average because two in three end at their candidate) and should run with many
+        // lanes -- but only where loading rays IS the work: where the rays that walk walk long (the stress scene: 40 steps; a cold cache) waiting for more free
+        // lanes only empties the node steps.  So the wave keeps count: while it has loaded more than RT_REFILL_RAYS_PER_PASS rays per pass of this loop (short lives: the
+        // bench scene's waves load more; the stress scene's, whose rays walk 40 steps, fewer: 28 keeps the one's gain and the other's time), a refill starts at RT_REFILL_ENTER_TESTS free lanes and goes round until
+        // fewer than RT_REFILL_STOP_TESTS are free; otherwise at RT_REFILL_LANES as every other walk.  (Both tallies change only where the whole wave runs -- a tally
+        // kept inside the node loop, which lanes leave one by one, differs from lane to lane and sends the lanes of a wave different ways at the refill: a hang.)
+        // Sets of frames (CHUNK 128) and single frames have their own pair of thresholds (profiles/r06/refill_thresholds.txt).
+        if (REFILL_TESTS) rf_passes++;
+        const bool mostly_answered = REFILL_TESTS && rf_loaded >= RT_REFILL_RAYS_PER_PASS * rf_passes && rf_loaded >= 64u;
+        const int REFILL_ENTER = mostly_answered ? (CHUNK > 64u ? RT_REFILL_ENTER_TESTS_SETS : RT_REFILL_ENTER_TESTS) : RT_REFILL_LANES;
+        const int REFILL_STOP = mostly_answered ? (CHUNK > 64u ? RT_REFILL_STOP_TESTS_SETS : RT_REFILL_STOP_TESTS) : RT_REFILL_LANES;
+        for (int refill_round = 0; !exhausted && n_idle >= (refill_round == 0 ? REFILL_ENTER : REFILL_STOP) && (refill_round == 0 || REFILL_TESTS); refill_round++) {
 #if RT_REFILL_PRIO
             __builtin_amdgcn_s_setprio(RT_REFILL_PRIO);
 #endif
@@ -346,6 +374,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                 }
             }
             n_traced += (uint32_t)__popcll(__ballot(started));
+            if (REFILL_TESTS) rf_loaded += (uint32_t)__popcll(__ballot(started));
             if (ANYHIT) n_skipped += (uint32_t)__popcll(__ballot(skipped));
             chunk_next += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
 #if RT_REFILL_PRIO
