@@ -103,6 +103,9 @@ RT_DEV v4f ldg16(const void *base, size_t byte_off)
 #ifndef RT_REFILL_STOP_TESTS_SETS
 #define RT_REFILL_STOP_TESTS_SETS 24
 #endif
+#ifndef RT_REFILL_TESTS_TWO_LEVEL
+#define RT_REFILL_TESTS_TWO_LEVEL 1     // ... in two-level walks too (the candidate is tested in its instance's space)
+#endif
 #ifndef RT_REFILL_TESTS
 #define RT_REFILL_TESTS 1               // (round 6) a new shadow ray's cached candidate is tested at the refill, and the refill repeats until the wave is full
 #endif
@@ -246,7 +249,7 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
         // the root as a one-triangle leaf: its lane sat through the wave's next node loop doing nothing, was tested in the leaf phase, and most of
         // the time (a cached occluder usually still occludes) ended there -- node steps of the shadow stage ran with 0.4 - 0.5 of their lanes by
         // the hardware's count (profiles/r05/c2s_lanes.md) against 0.66 in the walk without the cache.
-        constexpr bool REFILL_TESTS = src_has_cache<Src>::value && ANYHIT && !COUNT && !TWO_LEVEL && RT_REFILL_TESTS;
+        constexpr bool REFILL_TESTS = src_has_cache<Src>::value && ANYHIT && !COUNT && (!TWO_LEVEL || RT_REFILL_TESTS_TWO_LEVEL) && RT_REFILL_TESTS;
         unsigned long long idle = __ballot(!alive);
         int n_idle = __popcll(idle);
         // (round 6) A refill pass of a walk that tests candidates is ~500 instructions (ray, light ray, 1 / d, cache cell, candidate: half of the any-hit stage's
@@ -328,13 +331,16 @@ RT_DEV void trace_wave(const SceneDev &sc, const Src &src, const Sink &sink, uin
                     bool occluded_at_once = false;
                     if constexpr (REFILL_TESTS) {
                         uint32_t slot, ci;
-                        const uint32_t ct = src.template cached_leaf<false>(idx, r, slot, ci);
+                        const uint32_t ct = src.template cached_leaf<TWO_LEVEL>(idx, r, slot, ci);
                         st.lds[(STACK - 1) * BLOCK] = (int)slot;
-                        if (ct != RT_NO_HIT) {
-                            const char *tp = (const char *)(tris0 + ct);
+                        // (two-level: an entry is a (triangle, instance) pair, tested in that instance's space; it is only ever tested if it names a triangle that exists)
+                        if (ct != RT_NO_HIT && (!TWO_LEVEL || (ci < sc.n_inst && ct < sc.inst[ci].n_recs))) {
+                            const InstanceRec *cin = TWO_LEVEL ? sc.inst + ci : in0;
+                            const ObjRay orr = TWO_LEVEL ? to_object(*cin, r) : cur;
+                            const char *tp = (const char *)((TWO_LEVEL ? cin->tris : tris0) + ct);
                             const v4f a = ldg16(tp, 0), b = ldg16(tp, 16), c = ldg16(tp, 32);
                             HitD found = best;
-                            if (accept_candidate<REFS ? 1 : 0>(*in0, 0u, __float_as_uint(c.y), mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), r, wri, cur, cull, found,
+                            if (accept_candidate<REFS ? 1 : 0>(*cin, TWO_LEVEL ? ci : 0u, __float_as_uint(c.y), mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), r, wri, orr, cull, found,
                                                                REFS ? __float_as_uint(c.z) : 0u, ct)) {
                                 sink.store(idx, found, true);
                                 occluded_at_once = true;
