@@ -1,5 +1,5 @@
 // rt_refs.h -- split references (round 5): the validation boxes of long thin triangles.  Normative text: DESIGN.md section 2.1, paragraph S2.5 (the rule)
-// and S2.4 (what a box is for); this file and oracle/oracle_bvh.h implement it operation for operation.
+// and S2.4 (what a box is for); this file and the test oracle (oracle_bvh.h) implement it operation for operation.
 //
 // A 47 m x 2 cm cable that runs diagonally through a hall has an AABB of 40 x 5 x 25 m: every ray through that box has to test the
 // triangle, and 12,000 such triangles (4 % of the stress scene, tests/test_gpu_stress_scene.py) cost three times what the other 260,000

@@ -17,7 +17,7 @@
 // reference checkout), normative text DESIGN.md section 2.1: slab box test with slack
 // 1+2^-16 (S2.2), Moller-Trumbore (S2.3), and the box clause against the triangle's own
 // AABB / reference boxes / the instance's world AABB (S2.4) that makes BVH order
-// irrelevant to the result (S2.7) and is measured against oracle/truth64.h (S2.8).
+// irrelevant to the result (S2.7) and is measured against the test infrastructure's float64 brute force, truth64.h (S2.8).
 #pragma once
 
 #include "rt_device_math.h"
