@@ -8,7 +8,10 @@
 //     counters per launch, shared by a group of workgroups on one XCD -- and refills
 //     its idle lanes from the chunk once REFILL of them are idle (ballot + popcount
 //     prefix sum hands out the indices): on wave64, incoherent rays otherwise leave
-//     most of a wave's 64 lanes parked while the longest ray finishes;
+//     most of a wave's 64 lanes parked while the longest ray finishes.  (Round 6: an any-hit
+//     walk over a source with cached first candidates tests a new ray's candidate at the
+//     refill, goes round until the wave is full, and -- while its rays are short-lived --
+//     waits for 32 / 40 free lanes before it starts: RT_REFILL_TESTS, RT_REFILL_ENTER_TESTS*);
 //   * "while-while" order with a straggler exit: lanes walk internal nodes until they
 //     stand on a leaf; once those still walking are fewer than half of those waiting,
 //     the wave turns to the leaves, so the (short) triangle code is not serialised
