@@ -84,3 +84,34 @@ def test_split_references_boxes_and_hits(oracle):
     D = np.concatenate([d, np.full((1500, 1), 1e30)], 1).astype(np.float32)
     O2, D2 = random_rays(1500, 13, [-5, -5, -5], [5, 5, 5])
     both(oracle, [(v, t)], [(0, None)], np.concatenate([O, O2]), np.concatenate([D, D2]), refs={0: (off2, boxes2)})
+
+
+def test_canonical_lbvh_stated_twice(oracle):
+    """the canonical acceleration structure ("LBVH"): Morton keys, the Karras radix tree, exact refit -- tests/golden/nversion_lbvh.py against the oracle's
+    arrays, BLAS (triangle boxes) and TLAS (instance world boxes), field for field"""
+    import nversion_lbvh as LB
+    xf = random_xforms(9, seed=21, spread=4.0)
+    for (v, t), inst in ((oracle.obj_load(CORNELL_OBJ), [(0, None)]), (triangle_soup(900, seed=17, extent=3.0, size=0.4), [(0, None)]),
+                         (scenes.blob_mesh(seed=3, level=1), [(0, x) for x in xf])):
+        sc = oracle.Scene()
+        sc.add_model(v, t)
+        for mi, x in inst:
+            sc.add_instance(mi, x)
+        sc.build()
+        P = v["position"][np.asarray(t).reshape(-1, 3)]
+        for which in (0, -1):
+            lo, hi = P.min(1), P.max(1)
+            if which == -1:
+                if len(inst) < 2:
+                    continue
+                boxes = [sc.instance_info(i)[0] for i in range(len(inst))]       # (the world boxes are S2.4's: restated in nversion_trace.trace)
+                lo, hi = np.array([b[:3] for b in boxes], np.float32), np.array([b[3:] for b in boxes], np.float32)
+                for i, (mi, x) in enumerate(inst):                                  # ... and checked here against the transformed vertices
+                    wp = NV.xform_point(np.asarray(x, np.float32).reshape(3, 4), v["position"][np.asarray(t).reshape(-1)])
+                    assert np.array_equal(wp.min(0), lo[i]) and np.array_equal(wp.max(0), hi[i])
+            nodes, keys, parents, _ = sc.bvh(which)
+            mine = LB.build(lo, hi)
+            assert np.array_equal(keys, mine["keys"])
+            assert np.array_equal(nodes["left"], mine["left"]) and np.array_equal(nodes["right"], mine["right"])
+            assert np.array_equal(nodes["bmin"], mine["bmin"]) and np.array_equal(nodes["bmax"], mine["bmax"])
+            assert np.array_equal(parents, mine["parent"])
