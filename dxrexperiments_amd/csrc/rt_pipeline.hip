@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(PBLOCK) RT_WAVES_PER_EU k_trace_shadow(SceneDe
     ShadowSrcN<BATCH> src;
     static_cast<ShadowQueue &>(src) = queues;
     ShadowSinkN sink = {queues};
-    trace_wave<RT_ROWS(STACK), PBLOCK, TWO_LEVEL, (!TWO_LEVEL && RT_ROWS(STACK) == RT_LDS_STACK_ROWS_SETS) ? RT_POOL_CHUNK_SETS : RT_POOL_CHUNK, RT_SHADOW_UNORDERED != 0, false, false, RT_REFS(STACK)>(sc, src, sink, pool, smem, stat);
+    trace_wave<RT_ROWS(STACK), PBLOCK, TWO_LEVEL, (!TWO_LEVEL && RT_ROWS(STACK) == RT_LDS_STACK_ROWS_SETS) ? RT_POOL_CHUNK_SETS_ANYHIT : RT_POOL_CHUNK, RT_SHADOW_UNORDERED != 0, false, false, RT_REFS(STACK)>(sc, src, sink, pool, smem, stat);
 }
 
 // the shadow stage on the re-packed engine (rt_trace_repack.h; single-level scenes, option repack=1): one stack row less than the launch

@@ -81,6 +81,9 @@ RT_DEV v4f ldg16(const void *base, size_t byte_off)
 #define RT_POOL_CHUNK_SETS 128u         // ... in the long launches of sets of frames (round 4, profiles/r04/pool_chunk.txt: 64 / 128 / 256 rays: 1.512 / 1.467 / 1.466 ms per frame
 #endif                                  //     in sets -- and 2.06 / 2.15 / 2.33 ms frame by frame, where the end of a launch is a third of it: single frames keep 64)
 
+#ifndef RT_POOL_CHUNK_SETS_ANYHIT
+#define RT_POOL_CHUNK_SETS_ANYHIT 256u  // ... and the any-hit launch of a set 256 (round 6, with the late refills of short-lived rays: any-hit stage 0.505 -> 0.491 ms; the closest-hit
+#endif                                  //     launches of the 10 M-triangle scene lose 2 % with it and keep 128: profiles/r06/refill_thresholds.txt)
 #ifndef RT_POOL_GROUPS
 #define RT_POOL_GROUPS 32u              // chunk counters per traversal launch (8: 3.08, 32: 3.07, 128: 3.09, 512: 3.12 ms; static: 3.21)
 #endif
@@ -101,7 +104,7 @@ RT_DEV v4f ldg16(const void *base, size_t byte_off)
 #define RT_REFILL_STOP_TESTS 32
 #endif
 #ifndef RT_REFILL_ENTER_TESTS_SETS
-#define RT_REFILL_ENTER_TESTS_SETS 40   // sets of frames (128-ray chunks)
+#define RT_REFILL_ENTER_TESTS_SETS 48   // sets of frames (256-ray chunks)
 #endif
 #ifndef RT_REFILL_STOP_TESTS_SETS
 #define RT_REFILL_STOP_TESTS_SETS 24
